@@ -1,0 +1,222 @@
+// extern "C" surface of the engine (include/apsu_he.h).  Exceptions are translated to status
+// codes the way the reference's callers expect to see SEAL's exceptions.
+#include "../../include/apsu_he.h"
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "engine.h"
+
+using namespace apsu_he;
+
+struct apsu_he_ctx { std::unique_ptr<Engine> eng; };
+struct apsu_he_relin { std::unique_ptr<RelinKeys> rk; };
+struct apsu_he_bundle { std::unique_ptr<Bundle> b; };
+struct apsu_he_powers { std::unique_ptr<Powers> p; };
+
+static thread_local std::string g_last_error;
+
+template <class F> static int guarded(F &&fn)
+{
+    try {
+        fn();
+        return APSU_HE_OK;
+    } catch (const std::invalid_argument &e) { g_last_error = e.what(); return APSU_HE_INVALID_ARGUMENT;
+    } catch (const std::logic_error &e) { g_last_error = e.what(); return APSU_HE_LOGIC_ERROR;
+    } catch (const std::bad_alloc &e) { g_last_error = e.what(); return APSU_HE_OUT_OF_MEMORY;
+    } catch (const HipError &e) {
+        g_last_error = e.what();
+        if (g_last_error.find("no HIP device") != std::string::npos) return APSU_HE_NO_DEVICE;
+        if (g_last_error.find("out of memory") != std::string::npos) return APSU_HE_OUT_OF_MEMORY;
+        return APSU_HE_RUNTIME_ERROR;
+    } catch (const std::exception &e) { g_last_error = e.what(); return APSU_HE_RUNTIME_ERROR;
+    } catch (...) { g_last_error = "unknown error"; return APSU_HE_RUNTIME_ERROR; }
+}
+
+#define REQUIRE(cond, msg) do { if (!(cond)) throw std::invalid_argument(msg); } while (0)
+
+extern "C" {
+
+const char *apsu_he_last_error(void) { return g_last_error.c_str(); }
+int apsu_he_abi_version(void) { return 1; }
+
+int apsu_he_create(const char *json, int device, apsu_he_ctx **out)
+{
+    return guarded([&] {
+        REQUIRE(json && out, "null argument");
+        PSUParams p = PSUParams::Load(json);
+        HeParams hp = HeParams::FromPSUParams(p);
+        auto c = new apsu_he_ctx;
+        try { c->eng = std::make_unique<Engine>(hp, &p, device); } catch (...) { delete c; throw; }
+        *out = c;
+    });
+}
+
+int apsu_he_create_raw(uint64_t n, const uint64_t *coeff_modulus, int k, uint64_t plain_modulus, int device, apsu_he_ctx **out)
+{
+    return guarded([&] {
+        REQUIRE(coeff_modulus && out && k > 0, "null argument");
+        HeParams hp = HeParams::Create((size_t)n, std::vector<u64>(coeff_modulus, coeff_modulus + k), plain_modulus);
+        auto c = new apsu_he_ctx;
+        try { c->eng = std::make_unique<Engine>(hp, nullptr, device); } catch (...) { delete c; throw; }
+        *out = c;
+    });
+}
+
+int apsu_he_destroy(apsu_he_ctx *ctx) { return guarded([&] { delete ctx; }); }
+
+int apsu_he_get_info(const apsu_he_ctx *ctx, apsu_he_info *out)
+{
+    return guarded([&] {
+        REQUIRE(ctx && out, "null argument");
+        const HeParams &hp = ctx->eng->he();
+        std::memset(out, 0, sizeof(*out));
+        out->poly_modulus_degree = hp.n;
+        out->plain_modulus = hp.t;
+        out->coeff_modulus_size = hp.K;
+        out->first_chain_idx = hp.first_chain_idx;
+        out->using_keyswitching = hp.using_keyswitching;
+        out->irrelevant_bit_count = hp.irrelevant_bit_count;
+        for (int j = 0; j < hp.K && j < 8; j++) out->coeff_modulus[j] = hp.key_q[j];
+        if (const PSUParams *p = ctx->eng->psu()) {
+            out->ps_low_degree = p->query_params.ps_low_degree;
+            out->max_items_per_bin = p->table_params.max_items_per_bin;
+            out->bundle_idx_count = p->bundle_idx_count;
+            out->items_per_bundle = p->items_per_bundle;
+            out->source_power_count = ctx->eng->dag().source_count();
+            out->target_power_count = (uint32_t)ctx->eng->dag().target_powers().size();
+            out->powers_dag_depth = ctx->eng->dag().depth();
+        }
+    });
+}
+
+int apsu_he_get_powers_dag(const apsu_he_ctx *ctx, apsu_he_dag_node *nodes, int capacity, int *n_nodes)
+{
+    return guarded([&] {
+        REQUIRE(ctx && n_nodes, "null argument");
+        const auto &m = ctx->eng->dag().nodes();
+        *n_nodes = (int)m.size();
+        int i = 0;
+        for (auto &kv : m) {
+            if (nodes && i < capacity)
+                nodes[i] = apsu_he_dag_node{ kv.second.power, kv.second.depth, kv.second.parents.first, kv.second.parents.second };
+            i++;
+        }
+    });
+}
+
+// ---- tier 1
+int apsu_he_transform_to_ntt(apsu_he_ctx *c, uint64_t *ct, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && ct && polys > 0, "null argument"); c->eng->transform_to_ntt(ct, polys, ci); }); }
+int apsu_he_transform_from_ntt(apsu_he_ctx *c, uint64_t *ct, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && ct && polys > 0, "null argument"); c->eng->transform_from_ntt(ct, polys, ci); }); }
+int apsu_he_transform_plain_to_ntt(apsu_he_ctx *c, const uint64_t *pt, size_t cnt, uint64_t *out, int ci)
+{ return guarded([&] { REQUIRE(c && pt && out, "null argument"); c->eng->transform_plain_to_ntt(pt, cnt, out, ci); }); }
+int apsu_he_multiply_plain_ntt(apsu_he_ctx *c, const uint64_t *ct, const uint64_t *pt, uint64_t *out, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && ct && pt && out && polys > 0, "null argument"); c->eng->multiply_plain_ntt(ct, pt, out, polys, ci); }); }
+int apsu_he_multiply_plain(apsu_he_ctx *c, const uint64_t *ct, const uint64_t *pt, size_t cnt, uint64_t *out, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && ct && pt && out && polys > 0, "null argument"); c->eng->multiply_plain(ct, pt, cnt, out, polys, ci); }); }
+int apsu_he_add(apsu_he_ctx *c, uint64_t *acc, const uint64_t *x, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && acc && x && polys > 0, "null argument"); c->eng->add(acc, x, polys, ci); }); }
+int apsu_he_add_plain(apsu_he_ctx *c, uint64_t *ct, const uint64_t *pt, size_t cnt, int ci)
+{ return guarded([&] { REQUIRE(c && ct && pt, "null argument"); c->eng->add_plain(ct, pt, cnt, ci); }); }
+int apsu_he_multiply(apsu_he_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, int ci)
+{ return guarded([&] { REQUIRE(c && a && b && out3, "null argument"); c->eng->multiply(a, b, out3, ci); }); }
+int apsu_he_square(apsu_he_ctx *c, const uint64_t *a, uint64_t *out3, int ci)
+{ return guarded([&] { REQUIRE(c && a && out3, "null argument"); c->eng->multiply(a, a, out3, ci); }); }
+int apsu_he_relinearize(apsu_he_ctx *c, uint64_t *ct3, const apsu_he_relin *rk, int ci)
+{ return guarded([&] { REQUIRE(c && ct3 && rk, "null argument"); c->eng->relinearize(ct3, *rk->rk, ci); }); }
+int apsu_he_mod_switch_to_next(apsu_he_ctx *c, uint64_t *ct, int polys, int ci)
+{ return guarded([&] { REQUIRE(c && ct && polys > 0, "null argument"); c->eng->mod_switch_to_next(ct, polys, ci); }); }
+int apsu_he_clear_irrelevant_bits(apsu_he_ctx *c, uint64_t *ct, int polys)
+{ return guarded([&] { REQUIRE(c && ct && polys > 0, "null argument"); c->eng->clear_irrelevant_bits(ct, polys); }); }
+
+// ---- tier 2
+int apsu_he_relin_upload(apsu_he_ctx *c, const uint64_t *ksk, apsu_he_relin **out)
+{
+    return guarded([&] {
+        REQUIRE(c && ksk && out, "null argument");
+        auto r = new apsu_he_relin;
+        try { r->rk = c->eng->upload_relin_keys(ksk); } catch (...) { delete r; throw; }
+        *out = r;
+    });
+}
+int apsu_he_relin_free(apsu_he_relin *rk) { return guarded([&] { delete rk; }); }
+
+int apsu_he_db_upload_bundle(apsu_he_ctx *c, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                             const uint64_t *const *coeff_ptrs, const uint8_t *is_ntt, apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && coeff_ptrs && is_ntt && out, "null argument");
+        auto b = new apsu_he_bundle;
+        try { b->b = c->eng->upload_bundle(bundle_idx, cache_idx, n_coeffs, coeff_ptrs, is_ntt); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
+int apsu_he_db_random_bundle(apsu_he_ctx *c, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, uint64_t seed,
+                             apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && out, "null argument");
+        auto b = new apsu_he_bundle;
+        try { b->b = c->eng->random_bundle(bundle_idx, cache_idx, degree, seed); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
+int apsu_he_bundle_free(apsu_he_bundle *b) { return guarded([&] { delete b; }); }
+int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes)
+{ return guarded([&] { REQUIRE(b && db_bytes, "null argument"); *db_bytes = b->b->db_bytes(); }); }
+
+int apsu_he_compute_powers(apsu_he_ctx *c, const uint32_t *bundle_indices, int nb, const uint64_t *const *src, int on_device,
+                           const apsu_he_relin *rk, apsu_he_powers **out)
+{
+    return guarded([&] {
+        REQUIRE(c && bundle_indices && src && out, "null argument");
+        auto p = new apsu_he_powers;
+        try { p->p = c->eng->compute_powers(bundle_indices, nb, src, on_device != 0, rk ? rk->rk.get() : nullptr); }
+        catch (...) { delete p; throw; }
+        *out = p;
+    });
+}
+int apsu_he_powers_free(apsu_he_powers *p) { return guarded([&] { delete p; }); }
+
+int apsu_he_powers_download(apsu_he_ctx *c, const apsu_he_powers *p, uint32_t bundle_idx, uint32_t power, uint64_t *out,
+                            size_t capacity_words, int *chain_idx, int *is_ntt)
+{
+    return guarded([&] {
+        REQUIRE(c && p && out, "null argument");
+        const Powers &pw = *p->p;
+        const PSUParams *psu = c->eng->psu();
+        REQUIRE(psu, "context has no PSUParams");
+        int b = pw.slot_of(bundle_idx);
+        REQUIRE(b >= 0, "bundle index not present");
+        const uint32_t ps = psu->query_params.ps_low_degree;
+        const size_t n = c->eng->he().n;
+        const bool low = !ps || power <= ps;
+        const int lvl = low ? pw.low_level : pw.high_level;
+        uint32_t idx;
+        if (low) { REQUIRE(power >= 1 && power <= pw.n_low, "power not available"); idx = power - 1; }
+        else { REQUIRE(power % (ps + 1) == 0 && power / (ps + 1) <= pw.n_high, "power not available"); idx = power / (ps + 1) - 1; }
+        const size_t words = (size_t)2 * (lvl + 1) * n;
+        REQUIRE(capacity_words >= words, "output buffer too small");
+        const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)idx * pw.nb + b) * words;
+        if (hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
+        if (chain_idx) *chain_idx = lvl;
+        if (is_ntt) *is_ntt = low ? 1 : 0;
+    });
+}
+
+int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, int count, const apsu_he_powers *powers,
+                         const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out, int out_on_device)
+{
+    return guarded([&] {
+        REQUIRE(c && bundles && powers && masks && out && count >= 0, "null argument");
+        std::vector<const Bundle *> bs(count);
+        for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); bs[i] = bundles[i]->b.get(); }
+        c->eng->eval_bundles(bs.data(), count, *powers->p, rk ? rk->rk.get() : nullptr, masks, masks_on_device != 0, out,
+                             out_on_device != 0);
+    });
+}
+
+} // extern "C"

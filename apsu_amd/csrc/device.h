@@ -1,0 +1,113 @@
+// Device-side constant blocks and kernel launch entry points of the query-evaluation engine.
+// Everything here is plain-old-data uploaded once per context; kernels read it through
+// wave-uniform (scalar) loads.  Layout of all polynomial data is SEAL's in-memory order
+// [poly][limb][coeff] of uint64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "modmath.h"
+#include "ntt_core.h"
+
+namespace apsu_he {
+
+constexpr int DMAXL = 8;            // limbs of q at a data level
+constexpr int DMAXB = DMAXL + 2;    // |Bsk|
+constexpr int DMAXE = DMAXL + DMAXB; // limbs of an extended (q u Bsk) polynomial
+
+struct ShoupConst { u64 w, wq; };
+
+// One level of the modulus chain (chain_idx = L-1).
+struct DevLevel {
+    int L, nB, nBsk, E;                         // E = L + nBsk limbs of an extended polynomial
+    Mod q[DMAXL];
+    Mod bsk[DMAXB];                             // B_0..B_{nB-1}, m_sk
+    Mod ext[DMAXE];                             // q_0..q_{L-1}, Bsk..   (modulus of each ext limb)
+    u64 t;
+    // add_plain (App. B7) and plaintext lift (B5)
+    u64 coeff_div_plain[DMAXL];
+    u64 q_mod_t, threshold;
+    u64 incr[DMAXL];
+    // drop-last-limb with rounding (B8)
+    u64 half;
+    u64 half_mod[DMAXL];
+    ShoupConst inv_q_last[DMAXL];
+    // BEHZ extension: fastbconv_m_tilde + sm_mrq (B9 steps 1-2)
+    ShoupConst ext_scale[DMAXL];                // m_tilde * (Q/q_j)^-1 mod q_j
+    u64 q_to_bsk[DMAXB][DMAXL];                 // (Q/q_j) mod Bsk_i
+    u32 q_to_mt[DMAXL];                         // (Q/q_j) mod 2^32
+    u32 neg_inv_q_mt;
+    u64 prod_q_bsk[DMAXB];
+    ShoupConst inv_mt_bsk[DMAXB];
+    // BEHZ finish: multiply by t, fast_floor, fastbconv_sk (B9 steps 6-8)
+    ShoupConst t_inv_punct_q[DMAXL];            // t * (Q/q_j)^-1 mod q_j
+    ShoupConst t_bsk[DMAXB];                    // t mod Bsk_i
+    ShoupConst inv_prod_q_bsk[DMAXB];
+    ShoupConst inv_punct_B[DMAXB];
+    u64 B_to_q[DMAXL][DMAXB];                   // (B/b_i) mod q_j
+    u64 B_to_msk[DMAXB];
+    ShoupConst inv_prod_B_msk;
+    u64 prod_B_q[DMAXL], neg_prod_B_q[DMAXL];
+    u64 msk_half;
+};
+
+// Key-switching constants (App. B10); moduli indexed by key limb.
+struct DevKey {
+    int K;
+    Mod q[DMAXL + 1];
+    u64 p_half;
+    u64 p_half_mod[DMAXL];
+    ShoupConst inv_p[DMAXL];
+};
+
+// Generic multiply-accumulate job: out[2][L][n] = sum_{j<cnt} PW_j (.) PT_j   (NTT domain).
+struct MacJob {
+    const u64 *pt;        // first plaintext; term j at pt + j*pt_stride ; limb l at + l*n
+    const u64 *pw;        // first ciphertext; term j at pw + j*pw_stride ; poly p at + p*pw_poly_stride
+    u64 *out;             // [2][L][n]
+    u32 cnt;
+    u32 pt_stride, pw_stride, pw_poly_stride;   // in u64 words
+};
+
+// ---- launch wrappers (all asynchronous on `st`) --------------------------------------------
+// NTT over `count` consecutive limb polynomials of n coefficients; limb g uses
+// tabs[modmap[g % period]].
+void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
+                int period, hipStream_t st);
+// out = a (.) b per limb; a:[batch][polys][L][n], b:[batch][L][n] (b_batch_stride may be 0)
+void launch_dyadic_plain(const DevLevel *lv, const u64 *ct, const u64 *pt, u64 *out, int polys, size_t n, int batch,
+                         size_t pt_batch_stride, hipStream_t st);
+void launch_add(const DevLevel *lv, u64 *acc, const u64 *x, int polys, size_t n, int batch, hipStream_t st);
+// acc[b] += sum_{i<terms} x[b][i]   (x: [batch][terms][polys][L][n]; acc: [batch] stride acc_stride words)
+void launch_add_many(const DevLevel *lv, u64 *acc, size_t acc_stride, const u64 *x, int terms, int polys, size_t n,
+                     int batch, hipStream_t st);
+struct PlainJob { u64 *ct; const u64 *pt; };        // ct: c0 limbs [L][n] ; pt: n coefficients mod t
+void launch_add_plain(const DevLevel *lv, const PlainJob *jobs, size_t n, int batch, hipStream_t st);
+void launch_lift(const DevLevel *lv, const u64 *pt, u64 *out, size_t n, int batch, const unsigned char *no_lift,
+                 hipStream_t st);
+// drop last limb: ct c at in + c*in_stride holds `polys` polys [L][n] -> out packed [c][polys][L-1][n]
+void launch_modswitch(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                      hipStream_t st);
+void launch_clear_bits(u64 *ct, size_t words, int bits, hipStream_t st);
+struct CtJob { const u64 *src; u64 *dst; };
+void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st);
+// drop last limb of `polys` polynomials per job: src [polys][L][n] -> dst [polys][L-1][n]
+void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
+void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
+// BEHZ
+// ct c at in + c*in_stride holds `polys` polys [L][n]; out packed [c][polys][E][n]
+void launch_behz_ext(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                     hipStream_t st);
+struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
+void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
+// finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)
+struct FinishJob { const u64 *d; u64 *out; int terms; int pad; };
+void launch_behz_finish(const DevLevel *lv, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st);
+// key switching
+void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
+                      hipStream_t st);
+void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
+                     hipStream_t st);
+void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
+                       hipStream_t st);
+void launch_mac(const DevLevel *lv, int L, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
+
+} // namespace apsu_he

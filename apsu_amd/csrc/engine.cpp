@@ -1,0 +1,993 @@
+// See engine.h.  Host orchestration of the HIP kernels; mirrors, step for step,
+//   Receiver::ComputePowers                 receiver/apsu/receiver_osn.cpp:395-488
+//   BatchedPlaintextPolyn::eval             receiver/apsu/bin_bundle.cpp:106-174
+//   BatchedPlaintextPolyn::eval_patstock    receiver/apsu/bin_bundle.cpp:192-360
+// Exact (rounding-free) steps are batched / re-associated freely; every rounding step
+// (drop-limb, BEHZ floor, key-switch mod-down) is applied per term exactly where the reference
+// applies it (SURVEY.md §2.4 note N1), so results are bit-identical to the CPU path.
+#include "engine.h"
+
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace apsu_he {
+
+void throw_hip(hipError_t e, const char *file, int line)
+{
+    throw HipError(std::string("HIP error: ") + hipGetErrorString(e) + " at " + file + ":" + std::to_string(line));
+}
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__); } while (0)
+
+namespace { struct ArenaOverflow { size_t need; }; }
+
+void DevBuf::alloc(size_t bytes)
+{
+    release();
+    if (!bytes) return;
+    HIP_CHECK(hipMalloc(&p_, bytes));
+    bytes_ = bytes;
+}
+void DevBuf::release()
+{
+    if (p_) (void)hipFree(p_);
+    p_ = nullptr;
+    bytes_ = 0;
+}
+
+int Powers::slot_of(uint32_t bundle_idx) const
+{
+    for (int i = 0; i < nb; i++) if (bundle_indices[i] == bundle_idx) return i;
+    return -1;
+}
+
+static ShoupConst shoup_const(u64 w, u64 q) { return ShoupConst{ w, (u64)(((u128)w << 64) / q) }; }
+static Mod make_mod(u64 q) { ModulusInfo m(q); return Mod{ q, m.ratio[0], m.ratio[1] }; }
+
+// ============================================================================ construction
+Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), device_(device)
+{
+    if (psu) { psu_ = *psu; has_psu_ = true; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        throw HipError("no HIP device available: the query-evaluation engine has no CPU fallback");
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+
+    const size_t n = hp_.n;
+    const int nmod = (int)hp_.ntt.size();
+    // twiddles: per modulus [fwd n][inv n] TwPair
+    {
+        std::vector<TwPair> tw((size_t)nmod * 2 * n);
+        for (int m = 0; m < nmod; m++) {
+            const NttTablesHost &t = hp_.ntt[m];
+            for (size_t k = 0; k < n; k++) {
+                tw[((size_t)m * 2 + 0) * n + k] = TwPair{ t.fwd[k], t.fwd_q[k] };
+                tw[((size_t)m * 2 + 1) * n + k] = TwPair{ t.inv[k], t.inv_q[k] };
+            }
+        }
+        d_tw_.alloc(tw.size() * sizeof(TwPair));
+        HIP_CHECK(hipMemcpy(d_tw_.p(), tw.data(), tw.size() * sizeof(TwPair), hipMemcpyHostToDevice));
+        std::vector<NttTable> tabs(nmod);
+        const TwPair *base = reinterpret_cast<const TwPair *>(d_tw_.p());
+        for (int m = 0; m < nmod; m++) {
+            tabs[m].q = hp_.ntt[m].mod.value;
+            tabs[m].ninv = hp_.ntt[m].ninv;
+            tabs[m].ninv_q = hp_.ntt[m].ninv_q;
+            tabs[m].fwd = base + ((size_t)m * 2 + 0) * n;
+            tabs[m].inv = base + ((size_t)m * 2 + 1) * n;
+        }
+        d_tabs_.alloc(tabs.size() * sizeof(NttTable));
+        HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
+    }
+    // level constants
+    {
+        const int nl = hp_.first_chain_idx + 1;
+        std::vector<DevLevel> lv(nl);
+        std::vector<int> map_ext((size_t)nl * DMAXE, 0), map_ks((size_t)nl * (DMAXL + 1) * DMAXL, 0),
+            map_ksacc((size_t)nl * (DMAXL + 1), 0);
+        const u64 mt = (u64)1 << 32;
+        for (int c = 0; c < nl; c++) {
+            const LevelConstants &h = hp_.level[c];
+            DevLevel &d = lv[c];
+            std::memset(&d, 0, sizeof(d));
+            const int L = h.L, nB = h.nB, nBsk = nB + 1;
+            if (L > DMAXL || nBsk > DMAXB) throw std::invalid_argument("too many RNS limbs");
+            d.L = L; d.nB = nB; d.nBsk = nBsk; d.E = L + nBsk;
+            std::vector<u64> bsk = h.B;
+            bsk.push_back(h.m_sk);
+            d.t = hp_.t;
+            d.q_mod_t = h.q_mod_t;
+            d.threshold = h.upper_half_threshold;
+            d.half = h.q[L - 1] >> 1;
+            for (int j = 0; j < L; j++) {
+                const u64 qj = h.q[j];
+                ModulusInfo mj(qj);
+                d.q[j] = make_mod(qj);
+                d.ext[j] = d.q[j];
+                d.coeff_div_plain[j] = h.coeff_div_plain[j];
+                d.incr[j] = h.upper_half_incr[j];
+                d.half_mod[j] = d.half % qj;
+                if (j + 1 < L) d.inv_q_last[j] = shoup_const(h.inv_q_last[j], qj);
+                d.ext_scale[j] = shoup_const(mj.mul(mt % qj, h.inv_punct_q[j]), qj);
+                d.q_to_mt[j] = (u32)h.q_to_mtilde[j];
+                d.t_inv_punct_q[j] = shoup_const(mj.mul(hp_.t % qj, h.inv_punct_q[j]), qj);
+                d.prod_B_q[j] = h.prod_B_mod_q[j];
+                d.neg_prod_B_q[j] = (qj - h.prod_B_mod_q[j]) % qj;
+                for (int i = 0; i < nB; i++) d.B_to_q[j][i] = h.B_to_q[j][i];
+                map_ext[(size_t)c * DMAXE + j] = j;
+            }
+            d.neg_inv_q_mt = (u32)h.neg_inv_q_mod_mtilde;
+            for (int i = 0; i < nBsk; i++) {
+                const u64 m = bsk[i];
+                d.bsk[i] = make_mod(m);
+                d.ext[L + i] = d.bsk[i];
+                for (int j = 0; j < L; j++) d.q_to_bsk[i][j] = h.q_to_bsk[i][j];
+                d.prod_q_bsk[i] = h.prod_q_mod_bsk[i];
+                d.inv_mt_bsk[i] = shoup_const(h.inv_mtilde_mod_bsk[i], m);
+                d.t_bsk[i] = shoup_const(hp_.t % m, m);
+                d.inv_prod_q_bsk[i] = shoup_const(h.inv_prod_q_mod_bsk[i], m);
+                if (i < nB) {
+                    d.inv_punct_B[i] = shoup_const(h.inv_punct_B[i], m);
+                    d.B_to_msk[i] = h.B_to_msk[i];
+                }
+                map_ext[(size_t)c * DMAXE + L + i] = hp_.bsk_id(nB, i);
+            }
+            d.inv_prod_B_msk = shoup_const(h.inv_prod_B_mod_msk, h.m_sk);
+            d.msk_half = h.m_sk >> 1;
+            // key-switch maps
+            for (int I = 0; I <= L; I++) {
+                const int id = I == L ? hp_.K - 1 : I;
+                for (int J = 0; J < L; J++) map_ks[(size_t)c * (DMAXL + 1) * DMAXL + (size_t)I * L + J] = id;
+                map_ksacc[(size_t)c * (DMAXL + 1) + I] = id;
+            }
+        }
+        d_levels_.alloc(lv.size() * sizeof(DevLevel));
+        HIP_CHECK(hipMemcpy(d_levels_.p(), lv.data(), lv.size() * sizeof(DevLevel), hipMemcpyHostToDevice));
+        auto up = [](DevBuf &b, const std::vector<int> &v) {
+            b.alloc(v.size() * sizeof(int));
+            HIP_CHECK(hipMemcpy(b.p(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        };
+        up(d_map_ext_, map_ext); up(d_map_ks_, map_ks); up(d_map_ksacc_, map_ksacc);
+        std::vector<int> ident(DMAXL + 1);
+        for (int i = 0; i <= DMAXL; i++) ident[i] = i;
+        up(d_map_ct_, ident);
+    }
+    // key-switching constants
+    {
+        DevKey k;
+        std::memset(&k, 0, sizeof(k));
+        k.K = hp_.K;
+        for (int j = 0; j < hp_.K; j++) k.q[j] = make_mod(hp_.key_q[j]);
+        if (hp_.K > 1) {
+            const u64 p = hp_.key_q[hp_.K - 1];
+            k.p_half = p >> 1;
+            for (int j = 0; j < hp_.K - 1; j++) {
+                k.p_half_mod[j] = k.p_half % hp_.key_q[j];
+                k.inv_p[j] = shoup_const(hp_.inv_p_mod_q[j], hp_.key_q[j]);
+            }
+        }
+        d_key_.alloc(sizeof(DevKey));
+        HIP_CHECK(hipMemcpy(d_key_.p(), &k, sizeof(DevKey), hipMemcpyHostToDevice));
+    }
+    if (has_psu_) {
+        auto targets = create_powers_set(psu_.query_params.ps_low_degree, psu_.table_params.max_items_per_bin);
+        if (!dag_.configure(psu_.query_params.query_powers, targets))
+            throw std::invalid_argument("failed to configure PowersDag");
+        build_schedule();
+    }
+    size_t init = 4096 * n * sizeof(u64);          // 256 MiB at n = 8192; grows on demand
+    if (const char *env = std::getenv("APSU_HE_ARENA_BYTES")) init = std::strtoull(env, nullptr, 10);
+    arena_.alloc(init);
+    stage_bytes_ = 4u << 20;
+    HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
+}
+
+Engine::~Engine()
+{
+    if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    if (stage_) (void)hipHostFree(stage_);
+}
+
+void Engine::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
+
+void Engine::check_level(int chain_idx) const
+{
+    if (chain_idx < 0 || chain_idx > hp_.first_chain_idx) throw std::invalid_argument("chain_idx is not a data level");
+}
+
+// ============================================================================ arena
+u64 *Engine::ws(size_t words)
+{
+    size_t bytes = (words * sizeof(u64) + 255) & ~(size_t)255;
+    if (arena_off_ + bytes > arena_.bytes()) throw ArenaOverflow{ arena_off_ + bytes };
+    u64 *p = reinterpret_cast<u64 *>(static_cast<char *>(arena_.p()) + arena_off_);
+    arena_off_ += bytes;
+    return p;
+}
+
+void Engine::ws_reset(size_t need)
+{
+    arena_off_ = 0;
+    if (need > arena_.bytes()) {
+        sync();
+        arena_.release();
+        arena_.alloc(need + need / 4);
+    }
+}
+
+template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
+{
+    if (v.empty()) return nullptr;
+    const size_t bytes = v.size() * sizeof(T);
+    u64 *d = ws((bytes + 7) / 8);
+    // job arrays go through a pinned staging area so the copy is truly asynchronous and the
+    // std::vector may die before the stream reaches it
+    const size_t aligned = (bytes + 63) & ~(size_t)63;
+    if (stage_off_ + aligned > stage_bytes_) {
+        sync();                                   // everything staged so far has been consumed
+        if (aligned > stage_bytes_) {
+            if (stage_) (void)hipHostFree(stage_);
+            stage_bytes_ = aligned * 2;
+            HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
+        }
+        stage_off_ = 0;
+    }
+    char *h = static_cast<char *>(stage_) + stage_off_;
+    std::memcpy(h, v.data(), bytes);
+    stage_off_ += aligned;
+    HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st_));
+    return reinterpret_cast<const T *>(d);
+}
+
+// run `fn` with the arena, growing it and retrying when the bump allocator overflows
+template <class F> static void with_arena(Engine *e, F &&fn, void (Engine::*reset)(size_t))
+{
+    size_t need = 0;
+    for (int attempt = 0; attempt < 40; attempt++) {
+        (e->*reset)(need);
+        try { fn(); return; }
+        catch (const ArenaOverflow &o) { need = std::max(o.need * 2, need); }
+    }
+    throw std::runtime_error("workspace arena could not be sized");
+}
+struct EngineAccess {
+    template <class F> static void run(Engine *e, F &&fn) { with_arena(e, fn, &Engine::ws_reset); }
+};
+#define WITH_ARENA(...) EngineAccess::run(this, [&]() __VA_ARGS__)
+
+// ============================================================================ device building blocks
+void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
+{
+    launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_);
+}
+
+void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx)
+{
+    const int L = chain_idx + 1;
+    const size_t n = hp_.n;
+    u64 *tdec = ws((size_t)batch * (L + 1) * L * n);
+    launch_ks_decomp(dkey(), L, ct3 + (size_t)2 * L * n, ct_stride, tdec, n, batch, st_);
+    d_ntt(tdec, (size_t)batch * (L + 1) * L, map_ks(chain_idx), (L + 1) * L, false);
+    u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
+    launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_);
+    d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
+    launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_);
+}
+
+// ============================================================================ tier 1
+#define H2D(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyHostToDevice, st_))
+#define D2H(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyDeviceToHost, st_))
+#define D2D(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyDeviceToDevice, st_))
+
+void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
+    WITH_ARENA({
+        u64 *d = ws(w);
+        H2D(d, ct, w);
+        d_ntt_ct(d, polys, chain_idx, false);
+        D2H(ct, d, w);
+        sync();
+    });
+}
+
+void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
+    WITH_ARENA({
+        u64 *d = ws(w);
+        H2D(d, ct, w);
+        d_ntt_ct(d, polys, chain_idx, true);
+        D2H(ct, d, w);
+        sync();
+    });
+}
+
+void Engine::multiply_plain_ntt(const u64 *ct, const u64 *pt_ntt, u64 *out, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
+    WITH_ARENA({
+        u64 *d = ws(w), *p = ws(L * n), *o = ws(w);
+        H2D(d, ct, w);
+        H2D(p, pt_ntt, L * n);
+        launch_dyadic_plain(dlevel(chain_idx), d, p, o, polys, n, 1, 0, st_);
+        D2H(out, o, w);
+        sync();
+    });
+}
+
+static bool is_monomial(const u64 *pt, size_t count)
+{
+    size_t nz = 0;
+    for (size_t k = 0; k < count && nz < 2; k++) nz += pt[k] != 0;
+    return nz == 1;
+}
+
+void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t n = hp_.n, L = chain_idx + 1;
+    if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
+    WITH_ARENA({
+        u64 *p = ws(n), *o = ws(L * n);
+        HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(u64), st_));
+        H2D(p, pt, pt_coeffs);
+        launch_lift(dlevel(chain_idx), p, o, n, 1, nullptr, st_);
+        d_ntt_ct(o, 1, chain_idx, false);
+        D2H(out, o, L * n);
+        sync();
+    });
+}
+
+// multiply_plain on coefficient-form ct and plaintext (bin_bundle.cpp:334): lift, NTT both,
+// dyadic product, INTT.  SEAL's monomial shortcut (no lift) is honoured.
+void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 *out, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
+    if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
+    const unsigned char mono = is_monomial(pt, pt_coeffs) ? 1 : 0;
+    WITH_ARENA({
+        u64 *d = ws(w), *p = ws(n), *pl = ws(L * n), *o = ws(w), *flag = ws(1);
+        H2D(d, ct, w);
+        HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(u64), st_));
+        H2D(p, pt, pt_coeffs);
+        HIP_CHECK(hipMemcpyAsync(flag, &mono, 1, hipMemcpyHostToDevice, st_));
+        launch_lift(dlevel(chain_idx), p, pl, n, 1, reinterpret_cast<const unsigned char *>(flag), st_);
+        d_ntt_ct(pl, 1, chain_idx, false);
+        d_ntt_ct(d, polys, chain_idx, false);
+        launch_dyadic_plain(dlevel(chain_idx), d, pl, o, polys, n, 1, 0, st_);
+        d_ntt_ct(o, polys, chain_idx, true);
+        D2H(out, o, w);
+        sync();
+    });
+}
+
+void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
+    WITH_ARENA({
+        u64 *a = ws(w), *b = ws(w);
+        H2D(a, acc, w);
+        H2D(b, x, w);
+        launch_add(dlevel(chain_idx), a, b, polys, hp_.n, 1, st_);
+        D2H(acc, a, w);
+        sync();
+    });
+}
+
+void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t n = hp_.n, L = chain_idx + 1;
+    if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
+    WITH_ARENA({
+        u64 *c0 = ws(L * n), *p = ws(n);
+        H2D(c0, ct, L * n);
+        HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(u64), st_));
+        H2D(p, pt, pt_coeffs);
+        std::vector<PlainJob> jobs{ PlainJob{ c0, p } };
+        launch_add_plain(dlevel(chain_idx), upload_jobs(jobs), n, 1, st_);
+        D2H(ct, c0, L * n);
+        sync();
+    });
+}
+
+void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    const size_t n = hp_.n, L = chain_idx + 1;
+    const int E = hlevel(chain_idx).L + hlevel(chain_idx).nB + 1;
+    const bool square = (a == b);
+    WITH_ARENA({
+        const int nop = square ? 1 : 2;
+        u64 *in = ws((size_t)nop * 2 * L * n);
+        H2D(in, a, 2 * L * n);
+        if (!square) H2D(in + 2 * L * n, b, 2 * L * n);
+        u64 *ext = ws((size_t)nop * 2 * E * n);
+        launch_behz_ext(dlevel(chain_idx), in, L * n, 1, ext, n, nop * 2, st_);
+        d_ntt(ext, (size_t)nop * 2 * E, map_ext(chain_idx), E, false);
+        u64 *d = ws((size_t)3 * E * n), *o = ws(3 * L * n);
+        std::vector<TensorJob> tj{ TensorJob{ ext, square ? ext : ext + (size_t)2 * E * n, d } };
+        launch_tensor(dlevel(chain_idx), upload_jobs(tj), n, 1, st_);
+        d_ntt(d, (size_t)3 * E, map_ext(chain_idx), E, true);
+        std::vector<FinishJob> fj{ FinishJob{ d, o, 1, 0 } };
+        launch_behz_finish(dlevel(chain_idx), upload_jobs(fj), false, n, 1, st_);
+        D2H(out3, o, 3 * L * n);
+        sync();
+    });
+}
+
+void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    if (!hp_.using_keyswitching) throw std::logic_error("parameters do not support key switching");
+    const size_t n = hp_.n, L = chain_idx + 1;
+    WITH_ARENA({
+        u64 *d = ws(3 * L * n);
+        H2D(d, ct3, 3 * L * n);
+        d_relinearize(d, 3 * L * n, 1, rk, chain_idx);
+        D2H(ct3, d, 2 * L * n);
+        sync();
+    });
+}
+
+void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    check_level(chain_idx);
+    if (chain_idx == 0) throw std::invalid_argument("end of modulus switching chain reached");
+    const size_t n = hp_.n, L = chain_idx + 1;
+    WITH_ARENA({
+        u64 *d = ws(polys * L * n), *o = ws(polys * (L - 1) * n);
+        H2D(d, ct, polys * L * n);
+        launch_modswitch(dlevel(chain_idx), d, polys * L * n, polys, o, n, 1, st_);
+        D2H(ct, o, polys * (L - 1) * n);
+        sync();
+    });
+}
+
+void Engine::clear_irrelevant_bits(u64 *ct, int polys)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    const size_t w = (size_t)polys * hp_.n;
+    WITH_ARENA({
+        u64 *d = ws(w);
+        H2D(d, ct, w);
+        launch_clear_bits(d, w, hp_.irrelevant_bit_count, st_);
+        D2H(ct, d, w);
+        sync();
+    });
+}
+
+// ============================================================================ tier 2: uploads
+std::unique_ptr<RelinKeys> Engine::upload_relin_keys(const u64 *rk_host)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!hp_.using_keyswitching) throw std::logic_error("parameters do not support key switching");
+    auto rk = std::make_unique<RelinKeys>();
+    const size_t w = (size_t)(hp_.K - 1) * 2 * hp_.K * hp_.n;
+    rk->data.alloc(w * sizeof(u64));
+    HIP_CHECK(hipMemcpy(rk->data.p(), rk_host, w * sizeof(u64), hipMemcpyHostToDevice));
+    return rk;
+}
+
+static void bundle_shape(const PSUParams &psu, const HeParams &hp, uint32_t degree, Bundle &b)
+{
+    const uint32_t ps = psu.query_params.ps_low_degree;
+    b.degree = degree;
+    b.use_ps = ps > 1 && ps < degree;                       // receiver_osn.cpp:520-522
+    const uint32_t h = ps + 1;
+    b.H = ps ? degree / h : 0;
+    b.r = ps ? degree % h : 0;
+    b.pt_level = std::min(hp.first_chain_idx, ps ? 2 : 1);  // bin_bundle.cpp:385-389
+    b.ntt_count = 0;
+    for (uint32_t i = 0; i <= degree; i++)
+        if ((!ps && i != 0) || (ps && (i % h) != 0)) b.ntt_count++;
+    if (!b.use_ps && ps && degree > ps)
+        throw std::invalid_argument("ps_low_degree == 1 leaves coefficient-form plaintexts that eval() cannot multiply");
+}
+
+std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                              const u64 *const *coeff_ptrs, const unsigned char *is_ntt)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (!n_coeffs) throw std::invalid_argument("batched_coeffs is empty");
+    if (n_coeffs - 1 > psu_.table_params.max_items_per_bin) throw std::invalid_argument("degree exceeds max_items_per_bin");
+    if (bundle_idx >= psu_.bundle_idx_count) throw std::invalid_argument("bundle_idx out of range");
+    auto b = std::make_unique<Bundle>();
+    b->bundle_idx = bundle_idx;
+    b->cache_idx = cache_idx;
+    bundle_shape(psu_, hp_, n_coeffs - 1, *b);
+    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
+    const size_t n = hp_.n, Lpt = b->pt_level + 1;
+    const int high = hp_.clamp_chain_idx(1);
+    const size_t Lh = high + 1;
+    for (uint32_t i = 0; i < n_coeffs; i++) {
+        bool want = (!ps && i != 0) || (ps && (i % h) != 0);
+        if ((is_ntt[i] != 0) != want) throw std::invalid_argument("plaintext NTT form does not match the BinBundle layout rule");
+    }
+    b->ntt.alloc(b->ntt_count * Lpt * n * sizeof(u64));
+    b->a0.alloc(n * sizeof(u64));
+    HIP_CHECK(hipMemcpy(b->a0.p(), coeff_ptrs[0], n * sizeof(u64), hipMemcpyHostToDevice));
+    size_t slot = 0;
+    std::vector<unsigned char> mono;
+    std::vector<const u64 *> cf;
+    for (uint32_t i = 1; i < n_coeffs; i++) {
+        if (is_ntt[i]) {
+            HIP_CHECK(hipMemcpy(b->ntt.u() + slot * Lpt * n, coeff_ptrs[i], Lpt * n * sizeof(u64), hipMemcpyHostToDevice));
+            slot++;
+        } else {
+            cf.push_back(coeff_ptrs[i]);
+            mono.push_back(is_monomial(coeff_ptrs[i], n) ? 1 : 0);
+        }
+    }
+    if (b->use_ps) {
+        // K4: pre-lift and pre-NTT the coefficient-form plaintexts a_{i*h} at the high level; this
+        // is what multiply_plain (bin_bundle.cpp:334) recomputes on every call in the reference.
+        const size_t H = cf.size();
+        b->lifted.alloc(H * Lh * n * sizeof(u64));
+        WITH_ARENA({
+            u64 *raw = ws(H * n), *flags = ws((H + 7) / 8 + 1);
+            for (size_t i = 0; i < H; i++) H2D(raw + i * n, cf[i], n);
+            HIP_CHECK(hipMemcpyAsync(flags, mono.data(), H, hipMemcpyHostToDevice, st_));
+            launch_lift(dlevel(high), raw, b->lifted.u(), n, (int)H, reinterpret_cast<const unsigned char *>(flags), st_);
+            d_ntt_ct(b->lifted.u(), H, high, false);
+            sync();
+        });
+    }
+    return b;
+}
+
+// ============================================================================ tier 2: ComputePowers
+void Engine::build_schedule()
+{
+    Sched &s = sched_;
+    const auto &nodes = dag_.nodes();
+    const uint32_t max_power = *dag_.target_powers().rbegin();
+    std::vector<char> is_parent(max_power + 1, 0);
+    for (auto &kv : nodes)
+        if (!kv.second.is_source()) { is_parent[kv.second.parents.first] = 1; is_parent[kv.second.parents.second] = 1; }
+    std::vector<PowersDag::PowersNode> order;
+    for (auto &kv : nodes) order.push_back(kv.second);
+    std::stable_sort(order.begin(), order.end(), [&](const auto &a, const auto &b) {
+        if (a.depth != b.depth) return a.depth < b.depth;
+        if (is_parent[a.power] != is_parent[b.power]) return is_parent[a.power] > is_parent[b.power];
+        return a.power < b.power;
+    });
+    s.slot_of.assign(max_power + 1, -1);
+    for (size_t i = 0; i < order.size(); i++) { s.slot_power.push_back(order[i].power); s.slot_of[order[i].power] = (int)i; }
+    s.levels.assign(dag_.depth() + 1, Sched::Level{ 0, 0, 0 });
+    for (uint32_t d = 0; d <= dag_.depth(); d++) {
+        int s0 = -1, s1 = -1, sp = -1;
+        for (size_t i = 0; i < order.size(); i++) {
+            if (order[i].depth != d) continue;
+            if (s0 < 0) s0 = (int)i;
+            s1 = (int)i + 1;
+            if (is_parent[order[i].power]) sp = (int)i + 1;
+        }
+        if (sp < 0) sp = s0;
+        s.levels[d] = Sched::Level{ s0, s1, sp };
+    }
+    for (size_t i = 0; i < order.size(); i++)
+        if (!order[i].is_source())
+            s.nodes.push_back({ (int)i, s.slot_of[order[i].parents.first], s.slot_of[order[i].parents.second] });
+    const uint32_t ps = psu_.query_params.ps_low_degree;
+    for (uint32_t p : dag_.target_powers()) {
+        if (!ps || p <= ps) s.low_powers.push_back(p);
+        else s.high_powers.push_back(p);
+    }
+}
+
+std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
+                                               const RelinKeys *rk)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (nb <= 0) throw std::invalid_argument("no bundle indices given");
+    if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
+    const Sched &s = sched_;
+    const size_t n = hp_.n;
+    const int first = hp_.first_chain_idx, high = hp_.clamp_chain_idx(1), low = hp_.clamp_chain_idx(2);
+    const uint32_t ps = psu_.query_params.ps_low_degree;
+    const int low_target = ps ? low : high;                 // receiver_osn.cpp:459-487
+    const size_t Lf = first + 1, Ef = dlevel(first) ? (size_t)(hlevel(first).L + hlevel(first).nB + 1) : 0;
+    const size_t P = s.slot_power.size();
+    const size_t slot_w = 3 * Lf * n;                       // (c0, c1, c2 scratch) per power and bundle index
+
+    auto pw = std::make_unique<Powers>();
+    pw->nb = nb;
+    pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
+    pw->low_level = low_target;
+    pw->high_level = high;
+    pw->n_low = (uint32_t)s.low_powers.size();
+    pw->n_high = (uint32_t)s.high_powers.size();
+    const size_t Ll = low_target + 1, Lh = high + 1, Eh = hlevel(high).L + hlevel(high).nB + 1;
+    pw->low.alloc((size_t)pw->n_low * nb * 2 * Ll * n * sizeof(u64));
+    if (pw->n_high) {
+        pw->high.alloc((size_t)pw->n_high * nb * 2 * Lh * n * sizeof(u64));
+        pw->hext.alloc((size_t)pw->n_high * nb * 2 * Eh * n * sizeof(u64));
+    }
+
+    WITH_ARENA({
+        u64 *pwf = ws(P * nb * slot_w);
+        auto slot_ptr = [&](int slot, int b) { return pwf + ((size_t)slot * nb + b) * slot_w; };
+        // sources (receiver_osn.cpp:304-317)
+        {
+            int si = 0;
+            for (auto &kv : dag_.nodes()) {
+                if (!kv.second.is_source()) continue;
+                for (int b = 0; b < nb; b++) {
+                    const u64 *sp = src[(size_t)b * dag_.source_count() + si];
+                    if (on_device) D2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
+                    else H2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
+                }
+                si++;
+            }
+        }
+        if (dag_.depth() > 0) {
+            u64 *ext = ws(P * nb * 2 * Ef * n);
+            auto ext_ptr = [&](int slot, int b) { return ext + ((size_t)slot * nb + b) * 2 * Ef * n; };
+            size_t max_nodes = 0;
+            for (size_t d = 1; d < s.levels.size(); d++) max_nodes = std::max(max_nodes, (size_t)(s.levels[d].s1 - s.levels[d].s0));
+            u64 *dbuf = ws(max_nodes * nb * 3 * Ef * n);
+            const size_t arena_mark = arena_off_;
+            for (size_t d = 1; d < s.levels.size(); d++) {
+                arena_off_ = arena_mark;
+                // extend + NTT the parents that became available at depth d-1
+                const auto &pl = s.levels[d - 1];
+                const int npar = pl.sp - pl.s0;
+                if (npar > 0) {
+                    launch_behz_ext(dlevel(first), slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_);
+                    d_ntt(ext_ptr(pl.s0, 0), (size_t)npar * nb * 2 * Ef, map_ext(first), (int)Ef, false);
+                }
+                const auto &cl = s.levels[d];
+                const int nn = cl.s1 - cl.s0;
+                std::vector<TensorJob> tj;
+                std::vector<FinishJob> fj;
+                for (auto &nd : s.nodes) {
+                    if (nd[0] < cl.s0 || nd[0] >= cl.s1) continue;
+                    for (int b = 0; b < nb; b++) {
+                        u64 *dd = dbuf + ((size_t)(nd[0] - cl.s0) * nb + b) * 3 * Ef * n;
+                        tj.push_back(TensorJob{ ext_ptr(nd[1], b), ext_ptr(nd[2], b), dd });
+                        fj.push_back(FinishJob{ dd, slot_ptr(nd[0], b), 1, 0 });
+                    }
+                }
+                launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_);                 // :422/:424
+                d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext(first), (int)Ef, true);
+                launch_behz_finish(dlevel(first), upload_jobs(fj), false, n, (int)fj.size(), st_);
+                if (hp_.using_keyswitching) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
+            }
+            arena_off_ = arena_mark;
+        }
+        // final per-power conversions (receiver_osn.cpp:459-487)
+        auto convert = [&](const std::vector<uint32_t> &powers, int target, u64 *out) {
+            if (powers.empty()) return;
+            const int cnt = (int)powers.size() * nb;
+            std::vector<CtJob> jobs;
+            int lvl = first;
+            u64 *cur = nullptr;
+            auto dst_for = [&](int level_after) -> u64 * {
+                return level_after == target ? out : ws((size_t)cnt * 2 * (level_after + 1) * n);
+            };
+            if (first == target) {
+                for (size_t i = 0; i < powers.size(); i++)
+                    for (int b = 0; b < nb; b++)
+                        jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), out + ((size_t)i * nb + b) * 2 * Lf * n });
+                launch_copy_jobs(upload_jobs(jobs), 2 * Lf * n, cnt, st_);
+                return;
+            }
+            cur = dst_for(first - 1);
+            for (size_t i = 0; i < powers.size(); i++)
+                for (int b = 0; b < nb; b++)
+                    jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), cur + ((size_t)i * nb + b) * 2 * (Lf - 1) * n });
+            launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_);                     // :463,471,478
+            lvl = first - 1;
+            while (lvl > target) {
+                u64 *nxt = dst_for(lvl - 1);
+                launch_modswitch(dlevel(lvl), cur, (size_t)2 * (lvl + 1) * n, 2, nxt, n, cnt, st_);
+                cur = nxt;
+                lvl--;
+            }
+        };
+        convert(s.low_powers, low_target, pw->low.u());
+        d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                          // :467,475
+        if (pw->n_high) {
+            convert(s.high_powers, high, pw->high.u());
+            // derived form used by eval_patstock's ct x ct products and coefficient-form plaintext products
+            launch_behz_ext(dlevel(high), pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_);
+            d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
+        }
+        sync();
+    });
+    return pw;
+}
+
+
+// ============================================================================ tier 2: synthetic DB
+std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (degree > psu_.table_params.max_items_per_bin) throw std::invalid_argument("degree exceeds max_items_per_bin");
+    auto b = std::make_unique<Bundle>();
+    b->bundle_idx = bundle_idx;
+    b->cache_idx = cache_idx;
+    bundle_shape(psu_, hp_, degree, *b);
+    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
+    const size_t n = hp_.n, Lpt = b->pt_level + 1;
+    const int high = hp_.clamp_chain_idx(1);
+    const size_t Lh = high + 1;
+    b->ntt.alloc(b->ntt_count * Lpt * n * sizeof(u64));
+    b->a0.alloc(n * sizeof(u64));
+    const size_t H = b->use_ps ? b->H : 0;
+    if (H) b->lifted.alloc(H * Lh * n * sizeof(u64));
+    // coefficient d of the batched polynomial = splitmix64 stream at offset d*n (mod t), coefficient form
+    const size_t chunk = 256;                                     // plaintexts per staging pass
+    WITH_ARENA({
+        u64 *raw = ws(chunk * n);
+        launch_fill_random(b->a0.u(), n, seed, hp_.t, st_);
+        size_t slot = 0, hi = 0;
+        std::vector<uint32_t> pend_ntt, pend_cf;
+        auto flush = [&]() {
+            if (!pend_ntt.empty()) {
+                for (size_t i = 0; i < pend_ntt.size(); i++)
+                    launch_fill_random(raw + i * n, n, seed + (u64)pend_ntt[i] * n * 0x9e3779b97f4a7c15ULL, hp_.t, st_);
+                launch_lift(dlevel(b->pt_level), raw, b->ntt.u() + slot * Lpt * n, n, (int)pend_ntt.size(), nullptr, st_);
+                d_ntt_ct(b->ntt.u() + slot * Lpt * n, pend_ntt.size(), b->pt_level, false);
+                slot += pend_ntt.size();
+                pend_ntt.clear();
+            }
+            if (!pend_cf.empty()) {
+                for (size_t i = 0; i < pend_cf.size(); i++)
+                    launch_fill_random(raw + i * n, n, seed + (u64)pend_cf[i] * n * 0x9e3779b97f4a7c15ULL, hp_.t, st_);
+                launch_lift(dlevel(high), raw, b->lifted.u() + hi * Lh * n, n, (int)pend_cf.size(), nullptr, st_);
+                d_ntt_ct(b->lifted.u() + hi * Lh * n, pend_cf.size(), high, false);
+                hi += pend_cf.size();
+                pend_cf.clear();
+            }
+        };
+        for (uint32_t d = 1; d <= degree; d++) {
+            const bool is_ntt = (!ps && d != 0) || (ps && (d % h) != 0);
+            if (is_ntt) { pend_ntt.push_back(d); if (pend_ntt.size() == chunk) flush(); }
+            else if (H) { pend_cf.push_back(d); if (pend_cf.size() == chunk) flush(); }
+        }
+        flush();
+        sync();
+    });
+    return b;
+}
+
+// ============================================================================ tier 2: BinBundle evaluation
+void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
+                          const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (count <= 0) return;
+    const size_t n = hp_.n;
+    const uint32_t ps = psu_.query_params.ps_low_degree, l = ps;
+    const int high = pw.high_level, low = pw.low_level;
+    const size_t Ll = low + 1, Lh = high + 1;
+    const size_t Eh = hlevel(high).L + hlevel(high).nB + 1;
+    const int nb = pw.nb;
+
+    // validation mirrors bin_bundle.cpp:116-118,204-213 ("not enough ciphertext powers available")
+    std::vector<int> bslot(count);
+    bool any_ps = false;
+    for (int i = 0; i < count; i++) {
+        const Bundle &b = *bundles[i];
+        bslot[i] = pw.slot_of(b.bundle_idx);
+        if (bslot[i] < 0) throw std::invalid_argument("no ciphertext powers for this bundle index");
+        if (b.use_ps) {
+            any_ps = true;
+            if (b.H > pw.n_high || l > pw.n_low) throw std::invalid_argument("not enough ciphertext powers available");
+            if (b.pt_level != low) throw std::logic_error("plaintext level does not match the low powers");
+        } else {
+            if (b.degree > pw.n_low) throw std::invalid_argument("not enough ciphertext powers available");
+            if (b.degree && b.pt_level != low) throw std::logic_error("plaintext level does not match the powers");
+        }
+    }
+    if (any_ps && hp_.using_keyswitching && !rk) throw std::invalid_argument("relinearization keys are required");
+
+    auto low_ptr = [&](uint32_t power, int b) { return pw.low.u() + (((size_t)(power - 1) * nb + b) * 2) * Ll * n; };
+    const u32 low_term_stride = (u32)((size_t)nb * 2 * Ll * n);
+    auto hext_ptr = [&](uint32_t i, int b) { return pw.hext.u() + (((size_t)(i - 1) * nb + b) * 2) * Eh * n; };
+
+    // workspace budget -> chunk size
+    size_t per_bundle_words = 0;
+    for (int i = 0; i < count; i++) {
+        const Bundle &b = *bundles[i];
+        size_t w = 16 * n;
+        if (b.use_ps) w += ((size_t)b.H * (2 * Ll + 2 * Lh + 2 * Eh + 3 * Eh) + (size_t)l * (2 * Ll + 2 * Lh) + 3 * Lh * (Lh + 4) + 8 * Lh) * n;
+        else w += (size_t)(6 * Ll + 8) * n;
+        per_bundle_words = std::max(per_bundle_words, w);
+    }
+    size_t budget = (size_t)6 << 30;
+    if (const char *env = std::getenv("APSU_HE_EVAL_WS_BYTES")) budget = std::strtoull(env, nullptr, 10);
+    int chunk = (int)std::max<size_t>(1, budget / (per_bundle_words * sizeof(u64)));
+    chunk = std::min(chunk, count);
+
+    for (int c0 = 0; c0 < count; c0 += chunk) {
+        const int B = std::min(chunk, count - c0);
+        WITH_ARENA({
+            u64 *res = ws((size_t)B * 2 * n);                       // final [B][2][1][n]
+            u64 *mask_d = nullptr;
+            if (!masks_on_device) {
+                mask_d = ws((size_t)B * n);
+                for (int i = 0; i < B; i++) H2D(mask_d + (size_t)i * n, masks[c0 + i], n);
+            }
+            auto mask_ptr = [&](int i) { return masks_on_device ? masks[c0 + i] : mask_d + (size_t)i * n; };
+
+            // split the chunk into Paterson-Stockmeyer and plain evaluations
+            std::vector<int> ps_ids, pl_ids;
+            for (int i = 0; i < B; i++) (bundles[c0 + i]->use_ps ? ps_ids : pl_ids).push_back(i);
+
+            // ---------------------------------------------------------------- plain: bin_bundle.cpp:106-174
+            if (!pl_ids.empty()) {
+                const int Bp = (int)pl_ids.size();
+                const int lvl = low;                                   // level of powers[1]
+                const size_t Lv = lvl + 1;
+                u64 *acc = ws((size_t)Bp * 2 * Lv * n);
+                std::vector<MacJob> mj;
+                std::vector<PlainJob> pj;
+                for (int x = 0; x < Bp; x++) {
+                    const Bundle &b = *bundles[c0 + pl_ids[x]];
+                    u64 *o = acc + (size_t)x * 2 * Lv * n;
+                    if (b.degree) mj.push_back(MacJob{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
+                                                       (u32)(Lv * n), low_term_stride, (u32)(Ll * n) });   // :140-149
+                    else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
+                    pj.push_back(PlainJob{ o, b.a0.u() });                                               // :159
+                }
+                for (int x = 0; x < Bp; x++) pj.push_back(PlainJob{ acc + (size_t)x * 2 * Lv * n, mask_ptr(pl_ids[x]) });   // :162
+                launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_);
+                d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
+                const PlainJob *pjd = upload_jobs(pj);
+                launch_add_plain(dlevel(lvl), pjd, n, Bp, st_);
+                launch_add_plain(dlevel(lvl), pjd + Bp, n, Bp, st_);
+                u64 *cur = acc;
+                for (int lv = lvl; lv > 0; lv--) {                                                        // :168-170
+                    u64 *nxt = ws((size_t)Bp * 2 * lv * n);
+                    launch_modswitch(dlevel(lv), cur, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bp, st_);
+                    cur = nxt;
+                }
+                std::vector<CtJob> cj;
+                for (int x = 0; x < Bp; x++) cj.push_back(CtJob{ cur + (size_t)x * 2 * n, res + (size_t)pl_ids[x] * 2 * n });
+                launch_copy_jobs(upload_jobs(cj), 2 * n, Bp, st_);
+            }
+
+            // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
+            if (!ps_ids.empty()) {
+                const int Bs = (int)ps_ids.size();
+                // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
+                std::vector<int> nin(Bs), in_off(Bs);
+                int NI = 0;
+                for (int x = 0; x < Bs; x++) {
+                    const Bundle &b = *bundles[c0 + ps_ids[x]];
+                    nin[x] = (int)b.H - (b.r == 0 ? 1 : 0);
+                    in_off[x] = NI;
+                    NI += nin[x];
+                }
+                u64 *inner = ws((size_t)NI * 2 * Ll * n);
+                std::vector<MacJob> mj;
+                for (int x = 0; x < Bs; x++) {
+                    const Bundle &b = *bundles[c0 + ps_ids[x]];
+                    const int bs = bslot[c0 + ps_ids[x]];
+                    for (int i = 1; i <= nin[x]; i++) {
+                        const u32 cnt = (u32)i < b.H ? l : b.r;
+                        mj.push_back(MacJob{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
+                                             inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
+                                             (u32)(Ll * n), low_term_stride, (u32)(Ll * n) });             // :258-264
+                    }
+                }
+                launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_);
+                d_ntt_ct(inner, (size_t)NI * 2, low, true);                                                 // :268,297
+                u64 *innerh = inner;
+                for (int lv = low; lv > high; lv--) {                                                       // :269,298
+                    u64 *nxt = ws((size_t)NI * 2 * lv * n);
+                    launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_);
+                    innerh = nxt;
+                }
+                // ct x ct with the high powers (:272,301): extend, NTT, tensor, INTT, finish (+ sum over i, :273,303)
+                u64 *ext = ws((size_t)NI * 2 * Eh * n);
+                launch_behz_ext(dlevel(high), innerh, Lh * n, 1, ext, n, NI * 2, st_);
+                d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
+                u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
+                u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
+                std::vector<TensorJob> tj;
+                std::vector<FinishJob> fj;
+                for (int x = 0; x < Bs; x++) {
+                    const int bs = bslot[c0 + ps_ids[x]];
+                    for (int i = 1; i <= nin[x]; i++) {
+                        const size_t job = (size_t)in_off[x] + i - 1;
+                        tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
+                    }
+                    fj.push_back(FinishJob{ dbuf + (size_t)in_off[x] * 3 * Eh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                }
+                launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_);
+                d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
+                launch_behz_finish(dlevel(high), upload_jobs(fj), false, n, Bs, st_);
+                if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
+
+                // i = 0 block: every term is rounded on its own before the sum (note N1)            :314-324
+                u64 *term = ws((size_t)Bs * l * 2 * Ll * n);
+                mj.clear();
+                for (int x = 0; x < Bs; x++) {
+                    const Bundle &b = *bundles[c0 + ps_ids[x]];
+                    const int bs = bslot[c0 + ps_ids[x]];
+                    for (u32 j = 1; j <= l; j++)
+                        mj.push_back(MacJob{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                             term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
+                                             (u32)(Ll * n) });
+                }
+                launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_);
+                d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
+                u64 *termh = term;
+                for (int lv = low; lv > high; lv--) {
+                    u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
+                    launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_);
+                    termh = nxt;
+                }
+                launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_);
+
+                // coefficient-form plaintexts a_{i*h} times the high powers (:328-337): exact, so the
+                // products are summed in the NTT domain and transformed back once
+                u64 *cf = ws((size_t)Bs * 2 * Lh * n);
+                mj.clear();
+                for (int x = 0; x < Bs; x++) {
+                    const Bundle &b = *bundles[c0 + ps_ids[x]];
+                    const int bs = bslot[c0 + ps_ids[x]];
+                    mj.push_back(MacJob{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
+                                         (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n) });
+                }
+                launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
+                d_ntt_ct(cf, (size_t)Bs * 2, high, true);
+                launch_add_many(dlevel(high), result, 3 * Lh * n, cf, 1, 2, n, Bs, st_);
+
+                std::vector<PlainJob> pj;
+                for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, bundles[c0 + ps_ids[x]]->a0.u() });   // :345
+                for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, mask_ptr(ps_ids[x]) });              // :346
+                const PlainJob *pjd = upload_jobs(pj);
+                launch_add_plain(dlevel(high), pjd, n, Bs, st_);
+                launch_add_plain(dlevel(high), pjd + Bs, n, Bs, st_);
+
+                u64 *cur = result;
+                size_t stride = 3 * Lh * n;
+                for (int lv = high; lv > 0; lv--) {                                                         // :354-356
+                    u64 *nxt = ws((size_t)Bs * 2 * lv * n);
+                    launch_modswitch(dlevel(lv), cur, stride, 2, nxt, n, Bs, st_);
+                    cur = nxt;
+                    stride = (size_t)2 * lv * n;
+                }
+                std::vector<CtJob> cj;
+                for (int x = 0; x < Bs; x++) cj.push_back(CtJob{ cur + (size_t)x * stride, res + (size_t)ps_ids[x] * 2 * n });
+                launch_copy_jobs(upload_jobs(cj), 2 * n, Bs, st_);
+            }
+            launch_clear_bits(res, (size_t)B * 2 * n, hp_.irrelevant_bit_count, st_);                       // :171,357
+            if (out_on_device) D2D(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
+            else D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
+            sync();
+        });
+    }
+}
+
+} // namespace apsu_he

@@ -1,0 +1,169 @@
+// Device-resident query-evaluation engine: the MI355X replacement for the seal::Evaluator calls
+// made by apsu::receiver::Receiver::ComputePowers (receiver/apsu/receiver_osn.cpp:395-488) and
+// BatchedPlaintextPolyn::eval / eval_patstock (receiver/apsu/bin_bundle.cpp:106-174,192-360).
+//
+// Tier 1 = one method per Evaluator call (host buffers in SEAL's [poly][limb][coeff] order),
+// used for parity testing and incremental adoption.  Tier 2 = the fused, HBM-resident path:
+// BinBundle plaintexts are uploaded once, ComputePowers runs level-synchronously over the
+// PowersDag for all bundle indices at once, and every BinBundle of a query is evaluated in a
+// few batched launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device.h"
+#include "params.h"
+#include "powers_dag.h"
+
+namespace apsu_he {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class DevBuf {                       // RAII device allocation
+public:
+    DevBuf() = default;
+    explicit DevBuf(size_t bytes) { alloc(bytes); }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; o.bytes_ = 0; } return *this; }
+    void alloc(size_t bytes);
+    void release();
+    u64 *u() const { return static_cast<u64 *>(p_); }
+    void *p() const { return p_; }
+    size_t bytes() const { return bytes_; }
+private:
+    void *p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+struct RelinKeys {                   // [decomp K-1][2][K][n], NTT form (SEAL KSwitchKeys data, index 0)
+    DevBuf data;
+};
+
+// One uploaded BinBundle cache = the batched matching polynomial of BatchedPlaintextPolyn
+// (bin_bundle.h:52-134): coefficient d for all bins, stored per the ctor's rule (bin_bundle.cpp:385-420).
+struct Bundle {
+    uint32_t bundle_idx = 0, cache_idx = 0;
+    uint32_t degree = 0;             // batched_coeffs.size() - 1
+    bool use_ps = false;             // (ps_low_degree > 1) && (ps_low_degree < degree)  receiver_osn.cpp:520-522
+    uint32_t H = 0, r = 0;           // degree / h, degree % h          (bin_bundle.cpp:225-227)
+    int pt_level = 0;                // chain index of the NTT-form plaintexts
+    size_t ntt_count = 0;            // NTT-form coefficients, packed in ascending degree order
+    DevBuf ntt;                      // [ntt_count][pt_level+1][n]
+    DevBuf lifted;                   // PS only: NTT(lift(a_{i*h})) at the high level, i = 1..H : [H][Lh][n]
+    DevBuf a0;                       // constant coefficient, n words mod t
+    size_t db_bytes() const { return ntt.bytes() + lifted.bytes() + a0.bytes(); }
+};
+
+// Output of ComputePowers for a set of bundle indices (CiphertextPowers, receiver_osn.h:41).
+struct Powers {
+    int nb = 0;                                  // bundle indices held
+    std::vector<uint32_t> bundle_indices;
+    int low_level = 0, high_level = 0;
+    uint32_t n_low = 0, n_high = 0;              // PS: l low powers, H high powers; no PS: all in `low`
+    DevBuf low;                                  // [power-1][nb][2][Ll][n]   NTT form
+    DevBuf high;                                 // [i-1][nb][2][Lh][n]       coefficient form (power i*h)
+    DevBuf hext;                                 // [i-1][nb][2][Eh][n]       extended + NTT form of the same
+    int slot_of(uint32_t bundle_idx) const;
+};
+
+class Engine {
+public:
+    Engine(const HeParams &hp, const PSUParams *psu, int device);
+    ~Engine();
+
+    const HeParams &he() const { return hp_; }
+    const PSUParams *psu() const { return has_psu_ ? &psu_ : nullptr; }
+    const PowersDag &dag() const { return dag_; }
+    hipStream_t stream() const { return st_; }
+    void sync();
+
+    // ---------------- tier 1 (host pointers; each call is H2D, kernels, D2H)
+    void transform_to_ntt(u64 *ct, int polys, int chain_idx);
+    void transform_from_ntt(u64 *ct, int polys, int chain_idx);
+    void multiply_plain_ntt(const u64 *ct, const u64 *pt_ntt, u64 *out, int polys, int chain_idx);
+    void multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 *out, int polys, int chain_idx);
+    void transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, int chain_idx);
+    void add(u64 *acc, const u64 *x, int polys, int chain_idx);
+    void add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx);
+    void multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx);
+    void relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx);
+    void mod_switch_to_next(u64 *ct, int polys, int chain_idx);
+    void clear_irrelevant_bits(u64 *ct, int polys);
+
+    // ---------------- tier 2 (device resident)
+    std::unique_ptr<RelinKeys> upload_relin_keys(const u64 *rk_host);
+    std::unique_ptr<Bundle> upload_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                          const u64 *const *coeff_ptrs, const unsigned char *is_ntt);
+    // Synthetic-DB helper for benchmarks: fills a bundle of the given degree with uniformly random
+    // plaintext coefficients generated and transformed on the GPU (no host data).
+    std::unique_ptr<Bundle> random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed);
+    // src[b * n_sources + s]: source power s (ascending power order) of bundle index bundle_indices[b],
+    // size-2 coefficient-form ct at the first data level.  on_device: pointers are device pointers.
+    std::unique_ptr<Powers> compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
+                                           const RelinKeys *rk);
+    // masks[i]: n words mod t (host, or device if on_device).  out: count * 2n words (host or device).
+    void eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
+                      const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device);
+
+    // introspection for tests
+    size_t workspace_bytes() const { return arena_.bytes(); }
+
+private:
+    // arena (bump allocator reset per top-level operation)
+    u64 *ws(size_t words);
+    void ws_reset(size_t need_bytes_hint = 0);
+    template <class T> const T *upload_jobs(const std::vector<T> &v);
+
+    const DevLevel *dlevel(int chain_idx) const { return d_levels_.u() ? reinterpret_cast<const DevLevel *>(d_levels_.p()) + chain_idx : nullptr; }
+    const LevelConstants &hlevel(int chain_idx) const { return hp_.level[chain_idx]; }
+    const NttTable *tabs() const { return reinterpret_cast<const NttTable *>(d_tabs_.p()); }
+    const DevKey *dkey() const { return reinterpret_cast<const DevKey *>(d_key_.p()); }
+    const int *map_ct() const { return reinterpret_cast<const int *>(d_map_ct_.p()); }
+    const int *map_ext(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ext_.p()) + chain_idx * DMAXE; }
+    const int *map_ks(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ks_.p()) + chain_idx * (DMAXL + 1) * DMAXL; }
+    const int *map_ksacc(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ksacc_.p()) + chain_idx * (DMAXL + 1); }
+
+    // device-pointer building blocks
+    void d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse);
+    void d_ntt_ct(u64 *data, size_t polys, int chain_idx, bool inverse) { d_ntt(data, polys * (chain_idx + 1), map_ct(), chain_idx + 1, inverse); }
+    // BFV multiply of `njobs` (a, b) pairs given as ext-NTT operands; writes size-3 results
+    void d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx);
+    void check_level(int chain_idx) const;
+
+    HeParams hp_;
+    PSUParams psu_;
+    bool has_psu_ = false;
+    PowersDag dag_;
+    int device_ = 0;
+    hipStream_t st_ = nullptr;
+    std::mutex mu_;                   // ABI calls are serialised per context (thread-safe)
+
+    DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ks_, d_map_ksacc_;
+    DevBuf arena_;
+    size_t arena_off_ = 0;
+    void *stage_ = nullptr;           // pinned host staging for job arrays
+    size_t stage_bytes_ = 0, stage_off_ = 0;
+    std::vector<DevBuf> retired_;     // arenas replaced while kernels may still reference them
+
+    // PowersDag schedule (slot order = depth, parents first, power)
+    struct Sched {
+        std::vector<uint32_t> slot_power;                 // slot -> power
+        std::vector<int> slot_of;                         // power -> slot (-1 if absent)
+        struct Level { int s0, s1, sp; };                 // slots [s0,s1) ; [s0,sp) are parents of later nodes
+        std::vector<Level> levels;
+        std::vector<std::array<int, 3>> nodes;           // per non-source slot: {slot, slot_p1, slot_p2}
+        std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
+    } sched_;
+    void build_schedule();
+
+    friend struct EngineAccess;
+};
+
+} // namespace apsu_he

@@ -1,0 +1,128 @@
+// CPU emulation of the product's host logic and of one NTT workgroup, for the no-GPU test tier.
+// The NTT emulation executes the SAME pass functions (ntt_core.h) the gfx950 kernel runs, with
+// the workgroup's threads stepped sequentially between barriers, so the index algebra, twiddle
+// addressing, LDS padding and lazy ranges are checked on the CPU.  This is NOT a fallback path:
+// it is not reachable from the C ABI and is only loaded by tests.
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ntt_core.h"
+#include "params.h"
+#include "powers_dag.h"
+
+using namespace apsu_he;
+
+template <int LOGN, bool INV, int PASS> static void emu_pass(u64 *lds, int T, const NttTable &tab)
+{
+    if constexpr (PASS < plan_passes(LOGN)) {
+        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, PASS>(lds, tid, T, tab);
+        emu_pass<LOGN, INV, PASS + 1>(lds, T, tab);
+    }
+}
+
+template <int LOGN, bool INV> static void emu_ntt(u64 *data, const NttTable &tab, int T)
+{
+    constexpr int N = 1 << LOGN;
+    std::vector<u64> lds(lds_slots(N));
+    for (int e = 0; e < N; e++) lds[lds_slot(e)] = data[e];
+    emu_pass<LOGN, INV, 0>(lds.data(), T, tab);
+    for (int e = 0; e < N; e++) {
+        u64 x = lds[lds_slot(e)];
+        data[e] = INV ? ntt_inv_finish(x, tab) : ntt_fwd_finish(x, tab.q);
+    }
+}
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *emu_last_error() { return g_err.c_str(); }
+
+// NTT of one limb with the product's tables for modulus q (n = 2^logn)
+int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
+{
+    try {
+        size_t n = (size_t)1 << logn;
+        HeParams hp;   // only need tables: build for this single modulus via Create with K=1
+        // plain modulus irrelevant for the tables; pick any value < q
+        hp = HeParams::Create(n, { q }, 65537 < q ? 65537 : 3);
+        const NttTablesHost &t = hp.ntt[0];
+        std::vector<TwPair> fwd(n), inv(n);
+        for (size_t k = 0; k < n; k++) { fwd[k] = { t.fwd[k], t.fwd_q[k] }; inv[k] = { t.inv[k], t.inv_q[k] }; }
+        NttTable tab{ q, t.ninv, t.ninv_q, fwd.data(), inv.data() };
+#define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
+        switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
+#undef CASE
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// PSUParams::Load + HeParams: returns derived numbers for comparison with the oracle
+int emu_params_info(const char *json, uint64_t *out, int cap)
+{
+    try {
+        PSUParams p = PSUParams::Load(json);
+        HeParams hp = HeParams::FromPSUParams(p);
+        std::vector<u64> v;
+        v.push_back(hp.n); v.push_back(hp.K); v.push_back(hp.first_chain_idx); v.push_back(hp.t);
+        for (u64 q : hp.key_q) v.push_back(q);
+        for (int j = 0; j < hp.K; j++) v.push_back(hp.ntt[j].psi);
+        const LevelConstants &lv = hp.level[hp.first_chain_idx];
+        v.push_back(lv.nB); v.push_back(lv.m_sk); v.push_back(lv.gamma);
+        for (u64 b : lv.B) v.push_back(b);
+        v.push_back(p.bundle_idx_count); v.push_back(p.items_per_bundle); v.push_back(p.item_bit_count);
+        v.push_back(hp.irrelevant_bit_count);
+        for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+        return (int)v.size();
+    } catch (const std::invalid_argument &e) { g_err = e.what(); return -1;
+    } catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
+
+// PowersDag::configure on explicit sets; nodes: [power, depth, p1, p2] ascending by power
+int emu_powers_dag(const uint32_t *sources, int ns, const uint32_t *targets, int nt, uint32_t *nodes)
+{
+    PowersDag d;
+    if (!d.configure(std::set<uint32_t>(sources, sources + ns), std::set<uint32_t>(targets, targets + nt))) return -1;
+    int i = 0;
+    for (auto &kv : d.nodes()) {
+        nodes[4 * i + 0] = kv.second.power; nodes[4 * i + 1] = kv.second.depth;
+        nodes[4 * i + 2] = kv.second.parents.first; nodes[4 * i + 3] = kv.second.parents.second;
+        i++;
+    }
+    return (int)d.depth();
+}
+
+int emu_create_powers_set(uint32_t ps_low, uint32_t target, uint32_t *out, int cap)
+{
+    try {
+        auto s = create_powers_set(ps_low, target);
+        int i = 0;
+        for (uint32_t p : s) { if (i < cap) out[i] = p; i++; }
+        return i;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// level constants flattened for diffing against the oracle (test_constants)
+int emu_level_constants(uint64_t n, const uint64_t *q, int k, uint64_t t, int chain_idx, uint64_t *out, int cap)
+{
+    try {
+        HeParams hp = HeParams::Create((size_t)n, std::vector<u64>(q, q + k), t);
+        const LevelConstants &lv = hp.level.at(chain_idx);
+        std::vector<u64> v;
+        auto put = [&](const std::vector<u64> &a) { for (u64 x : a) v.push_back(x); };
+        v.push_back(lv.L); v.push_back(lv.nB); v.push_back(lv.m_sk); v.push_back(lv.gamma);
+        put(lv.B); put(lv.coeff_div_plain); v.push_back(lv.q_mod_t); v.push_back(lv.upper_half_threshold);
+        put(lv.upper_half_incr); put(lv.inv_q_last); put(lv.inv_punct_q);
+        for (auto &r : lv.q_to_bsk) put(r);
+        put(lv.q_to_mtilde); v.push_back(lv.neg_inv_q_mod_mtilde);
+        put(lv.prod_q_mod_bsk); put(lv.inv_prod_q_mod_bsk); put(lv.inv_mtilde_mod_bsk); put(lv.inv_punct_B);
+        for (auto &r : lv.B_to_q) put(r);
+        put(lv.B_to_msk); v.push_back(lv.inv_prod_B_mod_msk); put(lv.prod_B_mod_q); put(hp.inv_p_mod_q);
+        for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+        return (int)v.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+} // extern "C"

@@ -1,0 +1,602 @@
+// Hand-written gfx950 kernels of the homomorphic query-evaluation engine.
+// Each kernel names the seal::Evaluator step it replaces and the reference call sites.
+// Conventions: 64-lane waves, 256-thread workgroups for coefficient-parallel kernels (one thread
+// per coefficient index, consecutive lanes on consecutive coefficients -> 512 B per wave access),
+// level constants read through wave-uniform loads.  No MFMA: the work is modular-integer
+// butterflies and dyadic products (BASELINE.json north_star).
+#include "device.h"
+
+#include <algorithm>
+
+namespace apsu_he {
+
+#define KERNEL_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__); } while (0)
+void throw_hip(hipError_t e, const char *file, int line);
+
+// ============================================================================ K1/K2: NTT
+// transform_to_ntt_inplace / transform_from_ntt_inplace
+// (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
+// multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
+template <int LOGN, bool INV, int T>
+__global__ __launch_bounds__(T) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
+                                           const int *__restrict__ modmap, int period)
+{
+    constexpr int N = 1 << LOGN;
+    __shared__ u64 lds[lds_slots(N)];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const NttTable tab = tabs[modmap[g % (size_t)period]];
+    u64 *p = data + g * N;
+
+    for (int e = 2 * tid; e < N; e += 2 * T) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + e);
+        lds[lds_slot(e)] = v.x;
+        lds[lds_slot(e + 1)] = v.y;
+    }
+    __syncthreads();
+    constexpr int P = plan_passes(LOGN);
+    ntt_pass<LOGN, INV, 0>(lds, tid, T, tab);
+    __syncthreads();
+    if constexpr (P > 1) { ntt_pass<LOGN, INV, 1>(lds, tid, T, tab); __syncthreads(); }
+    if constexpr (P > 2) { ntt_pass<LOGN, INV, 2>(lds, tid, T, tab); __syncthreads(); }
+    if constexpr (P > 3) { ntt_pass<LOGN, INV, 3>(lds, tid, T, tab); __syncthreads(); }
+    for (int e = 2 * tid; e < N; e += 2 * T) {
+        ulonglong2 v;
+        v.x = lds[lds_slot(e)];
+        v.y = lds[lds_slot(e + 1)];
+        if (INV) { v.x = ntt_inv_finish(v.x, tab); v.y = ntt_inv_finish(v.y, tab); }
+        else { v.x = ntt_fwd_finish(v.x, tab.q); v.y = ntt_fwd_finish(v.y, tab.q); }
+        *reinterpret_cast<ulonglong2 *>(p + e) = v;
+    }
+}
+
+template <int LOGN, int T>
+static void launch_ntt_t(bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
+                         hipStream_t st)
+{
+    if (inverse) hipLaunchKernelGGL((k_ntt<LOGN, true, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
+    else hipLaunchKernelGGL((k_ntt<LOGN, false, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
+}
+
+void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
+                hipStream_t st)
+{
+    if (!count) return;
+    switch (logn) {
+    case 13: launch_ntt_t<13, 512>(inverse, data, count, tabs, modmap, period, st); break;
+    case 12: launch_ntt_t<12, 256>(inverse, data, count, tabs, modmap, period, st); break;
+    case 11: launch_ntt_t<11, 128>(inverse, data, count, tabs, modmap, period, st); break;
+    case 10: launch_ntt_t<10, 64>(inverse, data, count, tabs, modmap, period, st); break;
+    case 8: launch_ntt_t<8, 64>(inverse, data, count, tabs, modmap, period, st); break;
+    case 6: launch_ntt_t<6, 64>(inverse, data, count, tabs, modmap, period, st); break;
+    default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+    KERNEL_CHECK();
+}
+
+// ============================================================================ coefficient-parallel helpers
+constexpr int EW_T = 256;
+static inline dim3 ew_grid(size_t n, int batch) { return dim3((unsigned)((n + EW_T - 1) / EW_T), (unsigned)batch); }
+
+// K3 (single term): multiply_plain on NTT ct x NTT plaintext (bin_bundle.cpp:147,258,287,320)
+__global__ __launch_bounds__(EW_T) void k_dyadic_plain(const DevLevel *__restrict__ lv, const u64 *__restrict__ ct,
+                                                       const u64 *__restrict__ pt, u64 *__restrict__ out, int polys,
+                                                       size_t n, size_t pt_batch_stride)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L;
+    const size_t b = blockIdx.y;
+    const u64 *a = ct + b * polys * L * n;
+    const u64 *p = pt + b * pt_batch_stride;
+    u64 *o = out + b * polys * L * n;
+    for (int j = 0; j < L; j++) {
+        const Mod m = lv->q[j];
+        const u64 pv = p[j * n + k];
+        for (int c = 0; c < polys; c++) o[(c * L + j) * n + k] = mulmod(a[(c * L + j) * n + k], pv, m);
+    }
+}
+
+void launch_dyadic_plain(const DevLevel *lv, const u64 *ct, const u64 *pt, u64 *out, int polys, size_t n, int batch,
+                         size_t pt_batch_stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dyadic_plain, ew_grid(n, batch), dim3(EW_T), 0, st, lv, ct, pt, out, polys, n, pt_batch_stride);
+    KERNEL_CHECK();
+}
+
+// K10: add_inplace (bin_bundle.cpp:148,264,273,293,303,323,336)
+__global__ __launch_bounds__(EW_T) void k_add(const DevLevel *__restrict__ lv, u64 *__restrict__ acc,
+                                              const u64 *__restrict__ x, int polys, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L;
+    const size_t off = (size_t)blockIdx.y * polys * L * n;
+    for (int j = 0; j < L; j++) {
+        const u64 q = lv->q[j].q;
+        for (int c = 0; c < polys; c++) {
+            const size_t i = off + (c * L + j) * n + k;
+            acc[i] = addmod(acc[i], x[i], q);
+        }
+    }
+}
+
+void launch_add(const DevLevel *lv, u64 *acc, const u64 *x, int polys, size_t n, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_add, ew_grid(n, batch), dim3(EW_T), 0, st, lv, acc, x, polys, n);
+    KERNEL_CHECK();
+}
+
+// acc[b] += sum_i x[b][i]  — exact modular sum of `terms` ciphertexts (order-insensitive)
+__global__ __launch_bounds__(EW_T) void k_add_many(const DevLevel *__restrict__ lv, u64 *__restrict__ acc, size_t acc_stride,
+                                                   const u64 *__restrict__ x, int terms, int polys, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L;
+    const size_t b = blockIdx.y;
+    const size_t ctw = (size_t)polys * L * n;
+    for (int j = 0; j < L; j++) {
+        const u64 q = lv->q[j].q;
+        for (int c = 0; c < polys; c++) {
+            const size_t o = (c * L + j) * n + k;
+            u64 s = acc[b * acc_stride + o];
+            for (int i = 0; i < terms; i++) s = addmod(s, x[(b * terms + i) * ctw + o], q);
+            acc[b * acc_stride + o] = s;
+        }
+    }
+}
+
+void launch_add_many(const DevLevel *lv, u64 *acc, size_t acc_stride, const u64 *x, int terms, int polys, size_t n,
+                     int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_add_many, ew_grid(n, batch), dim3(EW_T), 0, st, lv, acc, acc_stride, x, terms, polys, n);
+    KERNEL_CHECK();
+}
+
+// K8: add_plain_inplace (bin_bundle.cpp:159,162,345,346): c0 += round(m*Q/t) in RNS  (App. B7)
+__global__ __launch_bounds__(EW_T) void k_add_plain(const DevLevel *__restrict__ lv, const PlainJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const PlainJob job = jobs[blockIdx.y];
+    const u64 m = job.pt[k];
+    // fix = floor((m * (Q mod t) + floor((t+1)/2)) / t), exact 128-by-64 division (m < t < 2^61)
+    u128p num = mul128(m, lv->q_mod_t);
+    add128(num, u128p{ lv->threshold, 0 });
+    const u64 t = lv->t;
+    u64 rem = num.hi % t, lo = num.lo, fix = 0;
+    if (num.hi == 0) {
+        fix = lo / t;
+    } else {
+        for (int i = 0; i < 64; i++) {                  // shift-subtract; only for t > 2^32
+            rem = (rem << 1) | (lo >> 63);
+            lo <<= 1;
+            fix <<= 1;
+            if (rem >= t) { rem -= t; fix |= 1; }
+        }
+    }
+    u64 *c0 = job.ct;
+    for (int j = 0; j < lv->L; j++) {
+        const Mod mq = lv->q[j];
+        u128p s = mul128(m, lv->coeff_div_plain[j]);
+        add128(s, u128p{ fix, 0 });
+        const u64 scaled = barrett128(s, mq);
+        c0[j * n + k] = addmod(c0[j * n + k], scaled, mq.q);
+    }
+}
+
+void launch_add_plain(const DevLevel *lv, const PlainJob *jobs, size_t n, int batch, hipStream_t st)
+{
+    if (!batch) return;
+    hipLaunchKernelGGL(k_add_plain, ew_grid(n, batch), dim3(EW_T), 0, st, lv, jobs, n);
+    KERNEL_CHECK();
+}
+
+// K4 (first half): plaintext lift mod t -> RNS (App. B5); NTT follows as a separate launch.
+// no_lift[b] != 0 selects SEAL's monomial shortcut (value copied unlifted).
+__global__ __launch_bounds__(EW_T) void k_lift(const DevLevel *__restrict__ lv, const u64 *__restrict__ pt,
+                                               u64 *__restrict__ out, size_t n, const unsigned char *__restrict__ no_lift)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const size_t b = blockIdx.y;
+    const u64 v = pt[b * n + k];
+    const bool lift = (v >= lv->threshold) && !(no_lift && no_lift[b]);
+    const int L = lv->L;
+    for (int j = 0; j < L; j++) out[(b * L + j) * n + k] = lift ? v + lv->incr[j] : v;
+}
+
+void launch_lift(const DevLevel *lv, const u64 *pt, u64 *out, size_t n, int batch, const unsigned char *no_lift,
+                 hipStream_t st)
+{
+    hipLaunchKernelGGL(k_lift, ew_grid(n, batch), dim3(EW_T), 0, st, lv, pt, out, n, no_lift);
+    KERNEL_CHECK();
+}
+
+// K7: mod_switch_to_next_inplace / mod_switch_to_inplace
+// (receiver_osn.cpp:463,471,478 ; bin_bundle.cpp:169,269,298,322,335,355): drop q_last with rounding (B8)
+// in: ciphertext c at in + c*in_stride holds `polys` polynomials [L][n]; out: packed [c][polys][L-1][n]
+__global__ __launch_bounds__(EW_T) void k_modswitch(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
+                                                    size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L;
+    const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
+    const u64 *src = in + c * in_stride + p * (size_t)L * n;
+    u64 *dst = out + (size_t)blockIdx.y * (L - 1) * n;
+    const u64 ql = lv->q[L - 1].q;
+    const u64 last = addmod(src[(size_t)(L - 1) * n + k], lv->half, ql);
+    for (int j = 0; j + 1 < L; j++) {
+        const Mod m = lv->q[j];
+        const u64 tmp = submod(barrett64(last, m), lv->half_mod[j], m.q);
+        const u64 v = submod(src[(size_t)j * n + k], tmp, m.q);
+        dst[(size_t)j * n + k] = mul_shoup(v, lv->inv_q_last[j].w, lv->inv_q_last[j].wq, m.q);
+    }
+}
+
+void launch_modswitch(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                      hipStream_t st)
+{
+    if (!cts) return;
+    hipLaunchKernelGGL(k_modswitch, ew_grid(n, cts * polys), dim3(EW_T), 0, st, lv, in, in_stride, polys, out, n);
+    KERNEL_CHECK();
+}
+
+// job-addressed variant used when the source ciphertexts are scattered (PowersDag slot order)
+__global__ __launch_bounds__(EW_T) void k_modswitch_jobs(const DevLevel *__restrict__ lv, const CtJob *__restrict__ jobs,
+                                                         int polys, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L;
+    const CtJob job = jobs[blockIdx.y / polys];
+    const size_t p = blockIdx.y % polys;
+    const u64 *src = job.src + p * (size_t)L * n;
+    u64 *dst = job.dst + p * (size_t)(L - 1) * n;
+    const u64 ql = lv->q[L - 1].q;
+    const u64 last = addmod(src[(size_t)(L - 1) * n + k], lv->half, ql);
+    for (int j = 0; j + 1 < L; j++) {
+        const Mod m = lv->q[j];
+        const u64 tmp = submod(barrett64(last, m), lv->half_mod[j], m.q);
+        const u64 v = submod(src[(size_t)j * n + k], tmp, m.q);
+        dst[(size_t)j * n + k] = mul_shoup(v, lv->inv_q_last[j].w, lv->inv_q_last[j].wq, m.q);
+    }
+}
+
+void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_modswitch_jobs, ew_grid(n, njobs * polys), dim3(EW_T), 0, st, lv, jobs, polys, n);
+    KERNEL_CHECK();
+}
+
+__global__ __launch_bounds__(EW_T) void k_copy_jobs(const CtJob *__restrict__ jobs, size_t words)
+{
+    const CtJob job = jobs[blockIdx.y];
+    for (size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2; k < words; k += (size_t)gridDim.x * EW_T * 2)
+        *reinterpret_cast<ulonglong2 *>(job.dst + k) = *reinterpret_cast<const ulonglong2 *>(job.src + k);
+}
+
+void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    unsigned gx = (unsigned)std::min<size_t>((words / 2 + EW_T - 1) / EW_T, 64);
+    hipLaunchKernelGGL(k_copy_jobs, dim3(gx, (unsigned)njobs), dim3(EW_T), 0, st, jobs, words);
+    KERNEL_CHECK();
+}
+
+// counter-based generator for synthetic DB plaintexts: out[i] = splitmix64(seed + i) % bound
+// (documented so tests can regenerate the same values on the host)
+__global__ __launch_bounds__(EW_T) void k_fill_random(u64 *__restrict__ out, size_t words, u64 seed, u64 bound)
+{
+    const size_t i = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (i >= words) return;
+    u64 z = seed + (u64)i * 0x9e3779b97f4a7c15ULL + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    out[i] = z % bound;
+}
+
+void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st)
+{
+    if (!words) return;
+    hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((words + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, out, words, seed, bound);
+    KERNEL_CHECK();
+}
+
+// K9: try_clear_irrelevant_bits (bin_bundle.cpp:67-97)
+__global__ __launch_bounds__(EW_T) void k_clear_bits(u64 *__restrict__ ct, size_t words, u64 mask)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k < words) ct[k] &= mask;
+}
+
+void launch_clear_bits(u64 *ct, size_t words, int bits, hipStream_t st)
+{
+    if (bits <= 0) return;
+    hipLaunchKernelGGL(k_clear_bits, dim3((unsigned)((words + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, ct, words,
+                       ~(((u64)1 << bits) - 1));
+    KERNEL_CHECK();
+}
+
+// ============================================================================ K5: BFV multiply (BEHZ)
+// square / multiply / multiply_inplace (receiver_osn.cpp:422,424 ; bin_bundle.cpp:272,301)
+//
+// Step (1)+(2): q -> q u Bsk with Montgomery removal of the q-overflow (fastbconv_m_tilde + sm_mrq).
+// in: [batch] polynomials [L][n] at stride in_stride ; out: [batch][E][n] (q part copied, Bsk part computed)
+__global__ __launch_bounds__(EW_T) void k_behz_ext(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
+                                                   size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L, nBsk = lv->nBsk, E = lv->E;
+    const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
+    const u64 *src = in + c * in_stride + p * (size_t)L * n;
+    u64 *dst = out + (size_t)blockIdx.y * E * n;
+    u64 xs[DMAXL];
+    u32 mt_acc = 0;
+#pragma unroll
+    for (int j = 0; j < DMAXL; j++) {
+        if (j < L) {
+            const u64 x = src[j * n + k];
+            dst[j * n + k] = x;
+            xs[j] = mul_shoup(x, lv->ext_scale[j].w, lv->ext_scale[j].wq, lv->q[j].q);
+            mt_acc += (u32)xs[j] * lv->q_to_mt[j];           // arithmetic mod 2^32 = m_tilde
+        }
+    }
+    const u32 r32 = mt_acc * lv->neg_inv_q_mt;
+    for (int i = 0; i < nBsk; i++) {
+        const Mod m = lv->bsk[i];
+        u128p acc{ 0, 0 };
+#pragma unroll
+        for (int j = 0; j < DMAXL; j++)
+            if (j < L) mac128(acc, xs[j], lv->q_to_bsk[i][j]);
+        const u64 y = barrett128(acc, m);
+        // centred lift of r into Z_m (m_tilde is a power of two: ">=")
+        u64 r = r32;
+        if (r32 >= 0x80000000u) r += m.q - ((u64)1 << 32);
+        u128p v = mul128(r, lv->prod_q_bsk[i]);
+        add128(v, u128p{ y, 0 });
+        const u64 red = barrett128(v, m);
+        dst[(L + i) * n + k] = mul_shoup(red, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m.q);
+    }
+}
+
+void launch_behz_ext(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                     hipStream_t st)
+{
+    if (!cts) return;
+    hipLaunchKernelGGL(k_behz_ext, ew_grid(n, cts * polys), dim3(EW_T), 0, st, lv, in, in_stride, polys, out, n);
+    KERNEL_CHECK();
+}
+
+// Step (4): tensor product in the NTT domain over all E limbs: d0=a0b0, d1=a0b1+a1b0, d2=a1b1
+__global__ __launch_bounds__(EW_T) void k_tensor(const DevLevel *__restrict__ lv, const TensorJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const TensorJob job = jobs[blockIdx.y];
+    const int E = lv->E;
+    const size_t ps = (size_t)E * n;
+    for (int e = 0; e < E; e++) {
+        const Mod m = lv->ext[e];
+        const size_t o = e * n + k;
+        const u64 a0 = job.a[o], a1 = job.a[ps + o], b0 = job.b[o], b1 = job.b[ps + o];
+        job.d[o] = mulmod(a0, b0, m);
+        u128p mid = mul128(a0, b1);
+        mac128(mid, a1, b0);
+        job.d[ps + o] = barrett128(mid, m);
+        job.d[2 * ps + o] = mulmod(a1, b1, m);
+    }
+}
+
+void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tensor, ew_grid(n, batch), dim3(EW_T), 0, st, lv, jobs, n);
+    KERNEL_CHECK();
+}
+
+// Steps (6)-(8) for one coefficient of one extended polynomial: multiply by t, fast_floor
+// (q u Bsk -> Bsk), fastbconv_sk (Bsk -> q).  d points at limb 0 of the polynomial, stride n.
+__device__ __forceinline__ void behz_finish_coeff(const DevLevel *__restrict__ lv, const u64 *__restrict__ d, size_t n,
+                                                  u64 *res /* [L] */)
+{
+    const int L = lv->L, nB = lv->nB, nBsk = lv->nBsk;
+    u64 xq[DMAXL];
+#pragma unroll
+    for (int j = 0; j < DMAXL; j++)
+        if (j < L) xq[j] = mul_shoup(d[j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    u64 ys[DMAXB];
+    u64 fl_sk = 0;
+    for (int i = 0; i < nBsk; i++) {
+        const Mod m = lv->bsk[i];
+        u128p acc{ 0, 0 };
+#pragma unroll
+        for (int j = 0; j < DMAXL; j++)
+            if (j < L) mac128(acc, xq[j], lv->q_to_bsk[i][j]);
+        const u64 conv = barrett128(acc, m);
+        const u64 xb = mul_shoup(d[(L + i) * n], lv->t_bsk[i].w, lv->t_bsk[i].wq, m.q);
+        const u64 fl = mul_shoup(xb + (m.q - conv), lv->inv_prod_q_bsk[i].w, lv->inv_prod_q_bsk[i].wq, m.q);
+        if (i < nB) ys[i] = mul_shoup(fl, lv->inv_punct_B[i].w, lv->inv_punct_B[i].wq, m.q);
+        else fl_sk = fl;
+    }
+    const Mod msk = lv->bsk[nB];
+    u128p acc{ 0, 0 };
+    for (int i = 0; i < nB; i++) mac128(acc, ys[i], lv->B_to_msk[i]);
+    const u64 z_sk = barrett128(acc, msk);
+    const u64 alpha = mul_shoup(z_sk + (msk.q - fl_sk), lv->inv_prod_B_msk.w, lv->inv_prod_B_msk.wq, msk.q);
+    const bool neg = alpha > lv->msk_half;                     // alpha represents a negative value
+    const u64 a_abs = neg ? msk.q - alpha : alpha;
+    for (int j = 0; j < L; j++) {
+        u128p z{ 0, 0 };
+        for (int i = 0; i < nB; i++) mac128(z, ys[i], lv->B_to_q[j][i]);
+        mac128(z, a_abs, neg ? lv->prod_B_q[j] : lv->neg_prod_B_q[j]);
+        res[j] = barrett128(z, lv->q[j]);
+    }
+}
+
+// One job = one output polynomial triple: out[3][L][n] (+)= sum over `terms` consecutive extended
+// products d[term][3][E][n] (coefficient form).  The per-term rounding is kept (SURVEY note N1).
+__global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict__ lv, const FinishJob *__restrict__ jobs,
+                                                      int accumulate, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = lv->L, E = lv->E;
+    const FinishJob job = jobs[blockIdx.y / 3];
+    const size_t p = blockIdx.y % 3;
+    u64 sum[DMAXL];
+    u64 *o = job.out + p * (size_t)L * n + k;
+#pragma unroll
+    for (int j = 0; j < DMAXL; j++)
+        if (j < L) sum[j] = accumulate ? o[(size_t)j * n] : 0;
+    for (int i = 0; i < job.terms; i++) {
+        const u64 *dp = job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k;
+        u64 res[DMAXL];
+        behz_finish_coeff(lv, dp, n, res);
+#pragma unroll
+        for (int j = 0; j < DMAXL; j++)
+            if (j < L) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
+    }
+#pragma unroll
+    for (int j = 0; j < DMAXL; j++)
+        if (j < L) o[(size_t)j * n] = sum[j];
+}
+
+void launch_behz_finish(const DevLevel *lv, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_behz_finish, ew_grid(n, njobs * 3), dim3(EW_T), 0, st, lv, jobs, accumulate ? 1 : 0, n);
+    KERNEL_CHECK();
+}
+
+// ============================================================================ K6: relinearize (key switch of c2)
+// relinearize_inplace (receiver_osn.cpp:431 ; bin_bundle.cpp:309), App. B10.
+// decomp: out[b][I][J][k] = c2[b][J][k] mod m_I  for target modulus I in {q_0..q_{L-1}, p}, J < L
+__global__ __launch_bounds__(EW_T) void k_ks_decomp(const DevKey *__restrict__ key, int L, const u64 *__restrict__ c2,
+                                                    size_t c2_stride, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const size_t b = blockIdx.y;
+    const u64 *src = c2 + b * c2_stride;
+    u64 *dst = out + b * (size_t)(L + 1) * L * n;
+    for (int J = 0; J < L; J++) {
+        const u64 v = src[J * n + k];
+        for (int I = 0; I <= L; I++) {
+            const Mod m = key->q[I == L ? key->K - 1 : I];
+            dst[((size_t)I * L + J) * n + k] = barrett64(v, m);
+        }
+    }
+}
+
+void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ks_decomp, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n);
+    KERNEL_CHECK();
+}
+
+// inner product with the key: acc[b][comp][I][k] = sum_J tdec[b][I][J][k] * rk[J][comp][id(I)][k] mod m_I
+__global__ __launch_bounds__(EW_T) void k_ks_inner(const DevKey *__restrict__ key, int L, const u64 *__restrict__ tdec,
+                                                   const u64 *__restrict__ rk, u64 *__restrict__ acc, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const size_t b = blockIdx.y;
+    const int K = key->K;
+    const u64 *td = tdec + b * (size_t)(L + 1) * L * n;
+    u64 *o = acc + b * (size_t)2 * (L + 1) * n;
+    for (int I = 0; I <= L; I++) {
+        const int ki = I == L ? K - 1 : I;
+        const Mod m = key->q[ki];
+        u128p a0{ 0, 0 }, a1{ 0, 0 };
+        for (int J = 0; J < L; J++) {
+            const u64 tv = td[((size_t)I * L + J) * n + k];
+            mac128(a0, tv, rk[(((size_t)J * 2 + 0) * K + ki) * n + k]);
+            mac128(a1, tv, rk[(((size_t)J * 2 + 1) * K + ki) * n + k]);
+        }
+        o[(size_t)I * n + k] = barrett128(a0, m);
+        o[((size_t)(L + 1) + I) * n + k] = barrett128(a1, m);
+    }
+}
+
+void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ks_inner, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, tdec, rk, acc, n);
+    KERNEL_CHECK();
+}
+
+// mod-down by the special prime with rounding and add into (c0, c1):
+// acc: [batch][2][L+1][n] coefficient form ; ct[b]: [>=2][L][n] at stride ct_stride
+__global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ key, int L, const u64 *__restrict__ acc,
+                                                     u64 *__restrict__ ct, size_t ct_stride, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const size_t b = blockIdx.y;
+    const Mod pm = key->q[key->K - 1];
+    for (int comp = 0; comp < 2; comp++) {
+        const u64 *a = acc + (b * 2 + comp) * (size_t)(L + 1) * n;
+        u64 *c = ct + b * ct_stride + (size_t)comp * L * n;
+        const u64 tl = barrett64(a[(size_t)L * n + k] + key->p_half, pm);
+        for (int j = 0; j < L; j++) {
+            const Mod m = key->q[j];
+            const u64 tk = submod(barrett64(tl, m), key->p_half_mod[j], m.q);
+            const u64 v = mul_shoup(submod(a[(size_t)j * n + k], tk, m.q), key->inv_p[j].w, key->inv_p[j].wq, m.q);
+            c[(size_t)j * n + k] = addmod(c[(size_t)j * n + k], v, m.q);
+        }
+    }
+}
+
+void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ks_moddown, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n);
+    KERNEL_CHECK();
+}
+
+// ============================================================================ K3: dyadic multiply-accumulate
+// The inner loops of BatchedPlaintextPolyn::eval / eval_patstock
+// (bin_bundle.cpp:140-149, 250-265, 279-294): out = sum_j C^j (.) a_j in the NTT domain.
+// 128-bit lazy accumulation, one Barrett reduction per output coefficient.  Streams the
+// HBM-resident plaintexts once; the ciphertext powers are re-read from L2 / Infinity Cache.
+__global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const MacJob job = jobs[blockIdx.z];
+    const int j = blockIdx.y;                                  // limb
+    const Mod m = lv->q[j];
+    const u64 *pt = job.pt + (size_t)j * n + k;
+    const u64 *p0 = job.pw + (size_t)j * n + k;
+    const u64 *p1 = p0 + job.pw_poly_stride;
+    u128p a0{ 0, 0 }, a1{ 0, 0 };
+    // lazy budget: products < 2^(2*bits(q)); reduce every `chunk` terms so the sum stays < 2^128
+    for (u32 i = 0; i < job.cnt; i++) {
+        const u64 a = pt[(size_t)i * job.pt_stride];
+        mac128(a0, a, p0[(size_t)i * job.pw_stride]);
+        mac128(a1, a, p1[(size_t)i * job.pw_stride]);
+        if ((i & 31) == 31) {                                  // q < 2^61: 32 products < 2^127
+            a0 = u128p{ barrett128(a0, m), 0 };
+            a1 = u128p{ barrett128(a1, m), 0 };
+        }
+    }
+    const int L = lv->L;
+    job.out[(size_t)j * n + k] = barrett128(a0, m);
+    job.out[((size_t)L + j) * n + k] = barrett128(a1, m);
+}
+
+void launch_mac(const DevLevel *lv, int L, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n + EW_T - 1) / EW_T), (unsigned)L, (unsigned)njobs), dim3(EW_T), 0, st,
+                       lv, jobs, n);
+    KERNEL_CHECK();
+}
+
+} // namespace apsu_he

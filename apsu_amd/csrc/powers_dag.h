@@ -1,0 +1,41 @@
+// PowersDag: depth-optimal DAG from the query's source powers to every target power.
+// Mirrors apsu::PowersDag (common/apsu/powers.h:53-77,88,158 ; common/apsu/powers.cpp:22-107):
+// same parent choice (first minimal-depth split in ascending s1 order), same node fields.
+// parallel_apply's spin scheduler (powers.h:158-278) is replaced by level-synchronous batches:
+// all nodes of equal depth are independent and run as one set of GPU launches.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <set>
+#include <utility>
+#include <vector>
+
+namespace apsu_he {
+
+class PowersDag {
+public:
+    struct PowersNode {
+        uint32_t power = 0;
+        uint32_t depth = 0;
+        std::pair<uint32_t, uint32_t> parents{ 0, 0 };
+        bool is_source() const { return parents.first == 0 && parents.second == 0; }
+    };
+
+    bool configure(std::set<uint32_t> source_powers, std::set<uint32_t> target_powers);
+    bool is_configured() const { return configured_; }
+    uint32_t depth() const { return depth_; }
+    uint32_t source_count() const { return source_count_; }
+    const std::set<uint32_t> &target_powers() const { return target_powers_; }
+    const std::map<uint32_t, PowersNode> &nodes() const { return nodes_; }
+    // nodes grouped by depth (index 0 = sources), ascending power inside a level
+    std::vector<std::vector<PowersNode>> levels() const;
+    void reset();
+
+private:
+    std::map<uint32_t, PowersNode> nodes_;
+    std::set<uint32_t> target_powers_;
+    bool configured_ = false;
+    uint32_t depth_ = 0, source_count_ = 0;
+};
+
+} // namespace apsu_he

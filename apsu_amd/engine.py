@@ -1,0 +1,278 @@
+"""ctypes binding of the engine's C ABI (include/apsu_he.h).
+
+Names follow the reference interface this path replaces:
+  seal::Evaluator::{transform_to_ntt_inplace, transform_from_ntt_inplace, multiply_plain,
+  add_inplace, add_plain_inplace, multiply, square, relinearize_inplace,
+  mod_switch_to_next_inplace}            receiver/apsu/receiver_osn.cpp:422-478, bin_bundle.cpp:143-357
+  Receiver::ComputePowers                receiver/apsu/receiver_osn.cpp:395-488
+  BatchedPlaintextPolyn::eval{,_patstock} receiver/apsu/bin_bundle.cpp:106-174,192-360
+Errors: APSU_HE_INVALID_ARGUMENT -> ValueError (std::invalid_argument in the reference),
+everything else -> ApsuHeError (std::runtime_error / std::logic_error).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+u64p = C.POINTER(C.c_uint64)
+
+
+class ApsuHeError(RuntimeError):
+    pass
+
+
+class _Info(C.Structure):
+    _fields_ = [
+        ("poly_modulus_degree", C.c_uint64), ("plain_modulus", C.c_uint64),
+        ("coeff_modulus_size", C.c_int32), ("first_chain_idx", C.c_int32),
+        ("using_keyswitching", C.c_int32), ("irrelevant_bit_count", C.c_int32),
+        ("coeff_modulus", C.c_uint64 * 8),
+        ("ps_low_degree", C.c_uint32), ("max_items_per_bin", C.c_uint32),
+        ("bundle_idx_count", C.c_uint32), ("items_per_bundle", C.c_uint32),
+        ("source_power_count", C.c_uint32), ("target_power_count", C.c_uint32),
+        ("powers_dag_depth", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libapsu_he_gpu.so")
+
+
+def load_library():
+    """Loads libapsu_he_gpu.so; raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ApsuHeError(
+                "HIP extension %s is missing: build it with `make -C apsu_amd/csrc` "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+        _LIB = C.CDLL(path)
+        _LIB.apsu_he_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = load_library().apsu_he_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise ApsuHeError("apsu_he status %d: %s" % (rc, msg))
+
+
+def _p(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need contiguous uint64"
+    return a.ctypes.data_as(u64p)
+
+
+def _ptr_array(items):
+    """items: numpy arrays (host) or ints (device pointers) -> (const uint64_t* const*)"""
+    arr = (C.c_void_p * len(items))()
+    for i, it in enumerate(items):
+        arr[i] = it.ctypes.data if isinstance(it, np.ndarray) else int(it)
+    return arr
+
+
+class RelinKeys:
+    def __init__(self, ctx, handle):
+        self._ctx, self.h = ctx, handle
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().apsu_he_relin_free(self.h)
+        except Exception:
+            pass
+
+
+class Bundle:
+    """Device-resident BinBundleCache.batched_matching_polyn (receiver/apsu/bin_bundle.h:52-134)."""
+
+    def __init__(self, ctx, handle, bundle_idx, cache_idx, degree):
+        self._ctx, self.h = ctx, handle
+        self.bundle_idx, self.cache_idx, self.degree = bundle_idx, cache_idx, degree
+
+    @property
+    def db_bytes(self):
+        v = C.c_uint64()
+        _check(load_library().apsu_he_bundle_bytes(self.h, C.byref(v)))
+        return v.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().apsu_he_bundle_free(self.h)
+        except Exception:
+            pass
+
+
+class Powers:
+    """Device-resident CiphertextPowers (receiver/apsu/receiver_osn.h:41) for some bundle indices."""
+
+    def __init__(self, ctx, handle, bundle_indices):
+        self._ctx, self.h, self.bundle_indices = ctx, handle, list(bundle_indices)
+
+    def download(self, bundle_idx, power):
+        """-> (ct [2][L][n], chain_idx, is_ntt) in the form receiver_osn.cpp:459-487 leaves it."""
+        ctx = self._ctx
+        buf = np.empty(2 * (ctx.first_chain_idx + 1) * ctx.n, dtype=np.uint64)
+        ci, ntt = C.c_int(), C.c_int()
+        _check(load_library().apsu_he_powers_download(ctx.h, self.h, bundle_idx, power, _p(buf), C.c_size_t(buf.size),
+                                                     C.byref(ci), C.byref(ntt)))
+        L = ci.value + 1
+        return buf[: 2 * L * ctx.n].reshape(2, L, ctx.n).copy(), ci.value, bool(ntt.value)
+
+    def __del__(self):
+        try:
+            if self.h:
+                load_library().apsu_he_powers_free(self.h)
+        except Exception:
+            pass
+
+
+class HeContext:
+    """CryptoContext + seal::Evaluator replacement (common/apsu/crypto_context.h:28-125)."""
+
+    def __init__(self, psu_params_json=None, device=0, n=None, coeff_modulus=None, plain_modulus=None):
+        L = load_library()
+        h = C.c_void_p()
+        if psu_params_json is not None:
+            if os.path.exists(psu_params_json):
+                with open(psu_params_json) as f:
+                    psu_params_json = f.read()
+            _check(L.apsu_he_create(psu_params_json.encode(), device, C.byref(h)))
+        else:
+            q = np.array(coeff_modulus, dtype=np.uint64)
+            _check(L.apsu_he_create_raw(C.c_uint64(n), _p(q), len(q), C.c_uint64(plain_modulus), device, C.byref(h)))
+        self.h = h
+        info = _Info()
+        _check(L.apsu_he_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.n = int(info.poly_modulus_degree)
+        self.t = int(info.plain_modulus)
+        self.K = int(info.coeff_modulus_size)
+        self.first_chain_idx = int(info.first_chain_idx)
+        self.q = [int(info.coeff_modulus[i]) for i in range(self.K)]
+        self.ps_low_degree = int(info.ps_low_degree)
+        self.max_items_per_bin = int(info.max_items_per_bin)
+        self.bundle_idx_count = int(info.bundle_idx_count)
+        self.source_power_count = int(info.source_power_count)
+        self.irrelevant_bit_count = int(info.irrelevant_bit_count)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().apsu_he_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def powers_dag(self):
+        cnt = C.c_int()
+        L = load_library()
+        _check(L.apsu_he_get_powers_dag(self.h, None, 0, C.byref(cnt)))
+        nodes = np.zeros((cnt.value, 4), dtype=np.uint32)
+        _check(L.apsu_he_get_powers_dag(self.h, C.c_void_p(nodes.ctypes.data), cnt.value, C.byref(cnt)))
+        return [tuple(int(v) for v in r) for r in nodes]
+
+    # ---- tier 1: Evaluator methods (in place on numpy arrays shaped [polys][L][n])
+    def transform_to_ntt_inplace(self, ct, chain_idx):
+        _check(load_library().apsu_he_transform_to_ntt(self.h, _p(ct), ct.shape[0], chain_idx))
+
+    def transform_from_ntt_inplace(self, ct, chain_idx):
+        _check(load_library().apsu_he_transform_from_ntt(self.h, _p(ct), ct.shape[0], chain_idx))
+
+    def transform_plain_to_ntt(self, pt, chain_idx):
+        out = np.empty((chain_idx + 1, self.n), dtype=np.uint64)
+        _check(load_library().apsu_he_transform_plain_to_ntt(self.h, _p(pt), C.c_size_t(pt.size), _p(out), chain_idx))
+        return out
+
+    def multiply_plain_ntt(self, ct, pt_ntt, chain_idx):
+        out = np.empty_like(ct)
+        _check(load_library().apsu_he_multiply_plain_ntt(self.h, _p(ct), _p(pt_ntt), _p(out), ct.shape[0], chain_idx))
+        return out
+
+    def multiply_plain(self, ct, pt, chain_idx):
+        out = np.empty_like(ct)
+        _check(load_library().apsu_he_multiply_plain(self.h, _p(ct), _p(pt), C.c_size_t(pt.size), _p(out), ct.shape[0], chain_idx))
+        return out
+
+    def add_inplace(self, acc, x, chain_idx):
+        _check(load_library().apsu_he_add(self.h, _p(acc), _p(x), acc.shape[0], chain_idx))
+
+    def add_plain_inplace(self, ct, pt, chain_idx):
+        _check(load_library().apsu_he_add_plain(self.h, _p(ct), _p(pt), C.c_size_t(pt.size), chain_idx))
+
+    def multiply(self, a, b, chain_idx):
+        out = np.empty((3, chain_idx + 1, self.n), dtype=np.uint64)
+        _check(load_library().apsu_he_multiply(self.h, _p(a), _p(b), _p(out), chain_idx))
+        return out
+
+    def square(self, a, chain_idx):
+        out = np.empty((3, chain_idx + 1, self.n), dtype=np.uint64)
+        _check(load_library().apsu_he_square(self.h, _p(a), _p(out), chain_idx))
+        return out
+
+    def relinearize(self, ct3, rk, chain_idx):
+        work = np.ascontiguousarray(ct3.copy())
+        _check(load_library().apsu_he_relinearize(self.h, _p(work), rk.h, chain_idx))
+        return np.ascontiguousarray(work[:2])
+
+    def mod_switch_to_next(self, ct, chain_idx):
+        work = np.ascontiguousarray(ct.copy())
+        polys = ct.shape[0]
+        _check(load_library().apsu_he_mod_switch_to_next(self.h, _p(work), polys, chain_idx))
+        return np.ascontiguousarray(work.reshape(-1)[: polys * chain_idx * self.n].reshape(polys, chain_idx, self.n))
+
+    def clear_irrelevant_bits(self, ct):
+        _check(load_library().apsu_he_clear_irrelevant_bits(self.h, _p(ct), ct.shape[0]))
+
+    # ---- tier 2
+    def upload_relin_keys(self, rk):
+        h = C.c_void_p()
+        _check(load_library().apsu_he_relin_upload(self.h, _p(np.ascontiguousarray(rk)), C.byref(h)))
+        return RelinKeys(self, h)
+
+    def upload_bundle(self, bundle_idx, cache_idx, coeffs, is_ntt):
+        """coeffs: list of uint64 arrays (batched_coeffs as Plaintext.data()); is_ntt: list of bool."""
+        h = C.c_void_p()
+        flags = (C.c_uint8 * len(coeffs))(*[1 if f else 0 for f in is_ntt])
+        keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in coeffs]
+        _check(load_library().apsu_he_db_upload_bundle(self.h, bundle_idx, cache_idx, len(keep), _ptr_array(keep), flags,
+                                                       C.byref(h)))
+        return Bundle(self, h, bundle_idx, cache_idx, len(keep) - 1)
+
+    def random_bundle(self, bundle_idx, cache_idx, degree, seed):
+        h = C.c_void_p()
+        _check(load_library().apsu_he_db_random_bundle(self.h, bundle_idx, cache_idx, degree, C.c_uint64(seed), C.byref(h)))
+        return Bundle(self, h, bundle_idx, cache_idx, degree)
+
+    def compute_powers(self, bundle_indices, sources, rk, on_device=False):
+        """Receiver::ComputePowers.  sources[b][s]: ct (numpy [2][L][n]) or device pointer (int) of the
+        s-th source power (ascending) for bundle index bundle_indices[b]."""
+        idx = np.array(bundle_indices, dtype=np.uint32)
+        flat = [s for per_b in sources for s in per_b]
+        h = C.c_void_p()
+        _check(load_library().apsu_he_compute_powers(self.h, C.c_void_p(idx.ctypes.data), len(idx), _ptr_array(flat),
+                                                     1 if on_device else 0, rk.h if rk is not None else None, C.byref(h)))
+        return Powers(self, h, bundle_indices)
+
+    def eval_bundles(self, bundles, powers, rk, masks, out=None, masks_on_device=False, out_on_device=False):
+        """ProcessBinBundleCache for every bundle: returns [count][2][1][n] (host) unless out is a device pointer."""
+        count = len(bundles)
+        hs = (C.c_void_p * count)(*[b.h for b in bundles])
+        if not out_on_device:
+            out = np.empty((count, 2, 1, self.n), dtype=np.uint64)
+            outp = _p(out)
+        else:
+            outp = C.c_void_p(int(out))
+        _check(load_library().apsu_he_eval_bundles(self.h, hs, count, powers.h, rk.h if rk is not None else None,
+                                                   _ptr_array(list(masks)), 1 if masks_on_device else 0, outp,
+                                                   1 if out_on_device else 0))
+        return out

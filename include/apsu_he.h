@@ -1,0 +1,149 @@
+/*
+ * apsu_he.h — C ABI of the MI355X homomorphic query-evaluation engine for APSU.
+ *
+ * Drop-in boundary: these entry points replace the seal::Evaluator calls that the DB-holding
+ * party (apsu::receiver::Receiver) makes on its hot path.  The reference has no FFI for this
+ * path; the replaced interface is the C++ class seal::Evaluator reached through
+ * CryptoContext::evaluator() (common/apsu/crypto_context.h:101-104).  Each function below
+ * cites the reference call site(s) it replaces.  INTEGRATION.md shows the adapter a maintainer
+ * adds to receiver/apsu/receiver_osn.cpp and receiver/apsu/bin_bundle.cpp.
+ *
+ * Conventions
+ *  - Buffers are raw uint64_t limb arrays in SEAL's in-memory order [poly][limb][coeff], i.e.
+ *    exactly Ciphertext::data() / Plaintext::data().
+ *  - Levels are named by SEAL's chain_index (0 = last level); get_parms_id_for_chain_idx
+ *    (common/apsu/util/utils.cpp:179-189) gives the mapping on the SEAL side.
+ *  - Every function returns 0 on success or a negative apsu_he_status; the message of the last
+ *    failure on the calling thread is available from apsu_he_last_error().  C++ callers map
+ *    APSU_HE_INVALID_ARGUMENT -> std::invalid_argument, others -> std::runtime_error, which is
+ *    what the reference's callers see from SEAL (bin_bundle.cpp:116-118,204-213).
+ *  - All-zero operands are legal (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT=OFF, bin_bundle.cpp:111-114).
+ *  - Calls on one context are thread-safe (serialised internally); the reference calls the
+ *    Evaluator from a thread pool (receiver_osn.cpp:334-364).
+ *  - There is NO CPU fallback: apsu_he_create fails with APSU_HE_NO_DEVICE without a GPU.
+ */
+#ifndef APSU_HE_H
+#define APSU_HE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    APSU_HE_OK = 0,
+    APSU_HE_INVALID_ARGUMENT = -1,   /* std::invalid_argument in the reference */
+    APSU_HE_LOGIC_ERROR = -2,        /* std::logic_error */
+    APSU_HE_RUNTIME_ERROR = -3,      /* std::runtime_error (incl. HIP failures) */
+    APSU_HE_NO_DEVICE = -4,          /* no MI355X / HIP device visible */
+    APSU_HE_OUT_OF_MEMORY = -5
+} apsu_he_status;
+
+typedef struct apsu_he_ctx apsu_he_ctx;         /* CryptoContext + Evaluator replacement */
+typedef struct apsu_he_relin apsu_he_relin;     /* device-resident seal::RelinKeys */
+typedef struct apsu_he_bundle apsu_he_bundle;   /* device-resident BinBundleCache::batched_matching_polyn */
+typedef struct apsu_he_powers apsu_he_powers;   /* device-resident CiphertextPowers for some bundle indices */
+
+typedef struct {
+    uint64_t poly_modulus_degree;
+    uint64_t plain_modulus;
+    int32_t coeff_modulus_size;      /* K, limbs at key level */
+    int32_t first_chain_idx;         /* chain_index of the first data level */
+    int32_t using_keyswitching;
+    int32_t irrelevant_bit_count;    /* bin_bundle.cpp:67-97 */
+    uint64_t coeff_modulus[8];
+    /* PSUParams-derived (zero when created without PSUParams) */
+    uint32_t ps_low_degree, max_items_per_bin, bundle_idx_count, items_per_bundle;
+    uint32_t source_power_count, target_power_count, powers_dag_depth, reserved;
+} apsu_he_info;
+
+typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   /* powers.h:53-77 */
+
+const char *apsu_he_last_error(void);
+/* Exported symbol list (for binding checks). */
+int apsu_he_abi_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* PSUParams::Load(json) + CryptoContext(params) (psu_params.cpp:290-374, crypto_context.h:32-37) */
+int apsu_he_create(const char *psu_params_json, int device, apsu_he_ctx **out);
+/* SEALContext from explicit primes (tests / tier-1 use without PSUParams) */
+int apsu_he_create_raw(uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, int coeff_modulus_size,
+                       uint64_t plain_modulus, int device, apsu_he_ctx **out);
+int apsu_he_destroy(apsu_he_ctx *ctx);
+int apsu_he_get_info(const apsu_he_ctx *ctx, apsu_he_info *out);
+/* PowersDag::configure result (powers.cpp:22-107); nodes ascending by power. Returns count via *n_nodes. */
+int apsu_he_get_powers_dag(const apsu_he_ctx *ctx, apsu_he_dag_node *nodes, int capacity, int *n_nodes);
+
+/* ---- tier 1: one call per Evaluator method (host buffers) ---------------------------------- */
+/* Evaluator::transform_to_ntt_inplace(Ciphertext)        receiver_osn.cpp:467,475 */
+int apsu_he_transform_to_ntt(apsu_he_ctx *ctx, uint64_t *ct, int polys, int chain_idx);
+/* Evaluator::transform_from_ntt_inplace                  bin_bundle.cpp:154,268,297,321 */
+int apsu_he_transform_from_ntt(apsu_he_ctx *ctx, uint64_t *ct, int polys, int chain_idx);
+/* Evaluator::transform_to_ntt_inplace(Plaintext, parms)  bin_bundle.cpp:419 ; out: (chain_idx+1)*n words */
+int apsu_he_transform_plain_to_ntt(apsu_he_ctx *ctx, const uint64_t *pt_mod_t, size_t pt_coeff_count, uint64_t *out,
+                                   int chain_idx);
+/* Evaluator::multiply_plain, NTT ct x NTT plaintext      bin_bundle.cpp:147,258,287,320 */
+int apsu_he_multiply_plain_ntt(apsu_he_ctx *ctx, const uint64_t *ct, const uint64_t *pt_ntt, uint64_t *out, int polys,
+                               int chain_idx);
+/* Evaluator::multiply_plain, coefficient ct x coefficient plaintext   bin_bundle.cpp:334 */
+int apsu_he_multiply_plain(apsu_he_ctx *ctx, const uint64_t *ct, const uint64_t *pt_mod_t, size_t pt_coeff_count,
+                           uint64_t *out, int polys, int chain_idx);
+/* Evaluator::add_inplace                                  bin_bundle.cpp:148,264,273,293,303,323,336 */
+int apsu_he_add(apsu_he_ctx *ctx, uint64_t *acc, const uint64_t *x, int polys, int chain_idx);
+/* Evaluator::add_plain_inplace (adds to c0)               bin_bundle.cpp:159,162,345,346 */
+int apsu_he_add_plain(apsu_he_ctx *ctx, uint64_t *ct, const uint64_t *pt_mod_t, size_t pt_coeff_count, int chain_idx);
+/* Evaluator::multiply / multiply_inplace (size 2 x size 2 -> size 3)   receiver_osn.cpp:424 ; bin_bundle.cpp:272,301 */
+int apsu_he_multiply(apsu_he_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out3, int chain_idx);
+/* Evaluator::square                                        receiver_osn.cpp:422 */
+int apsu_he_square(apsu_he_ctx *ctx, const uint64_t *a, uint64_t *out3, int chain_idx);
+/* Evaluator::relinearize_inplace (size 3 -> size 2, in place in the first two polys)
+ *                                                          receiver_osn.cpp:431 ; bin_bundle.cpp:309 */
+int apsu_he_relinearize(apsu_he_ctx *ctx, uint64_t *ct3, const apsu_he_relin *rk, int chain_idx);
+/* Evaluator::mod_switch_to_next_inplace; result packed [polys][chain_idx][n] at the front of ct
+ *                                                          receiver_osn.cpp:463,471,478 ; bin_bundle.cpp:169,269,298,322,355 */
+int apsu_he_mod_switch_to_next(apsu_he_ctx *ctx, uint64_t *ct, int polys, int chain_idx);
+/* try_clear_irrelevant_bits (last level, one limb)         bin_bundle.cpp:67-97 */
+int apsu_he_clear_irrelevant_bits(apsu_he_ctx *ctx, uint64_t *ct_last_level, int polys);
+
+/* ---- tier 2: fused, HBM-resident ------------------------------------------------------------ */
+/* RelinKeys of the query: [decomp K-1][component 2][limb K][n] = key_vector[J].data() of
+ * KSwitchKeys::data()[0], NTT form (query.cpp:46-52, crypto_context.h:45-49) */
+int apsu_he_relin_upload(apsu_he_ctx *ctx, const uint64_t *ksk, apsu_he_relin **out);
+int apsu_he_relin_free(apsu_he_relin *rk);
+/* BatchedPlaintextPolyn ctor output (bin_bundle.cpp:366-430): coeff_ptrs[d] = Plaintext::data() of
+ * batched_coeffs[d]; is_ntt[d] per the rule at :418-420 (checked).  NTT-form plaintexts have
+ * (plain_level+1)*n words, coefficient-form ones n words.  The engine copies; caller may free.
+ * Called from ReceiverDB::generate_caches (receiver_db.cpp:808-820). */
+int apsu_he_db_upload_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                             const uint64_t *const *coeff_ptrs, const uint8_t *is_ntt, apsu_he_bundle **out);
+/* Synthetic BinBundle for benchmarks: coefficient d, index k of the batched polynomial (coefficient
+ * form, mod t) = splitmix64_mix(seed + (d*n + k + 1) * 0x9e3779b97f4a7c15) % t; generated on the GPU. */
+int apsu_he_db_random_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, uint64_t seed,
+                             apsu_he_bundle **out);
+int apsu_he_bundle_free(apsu_he_bundle *b);
+int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes);
+/* Receiver::ComputePowers for n_bundle_idx bundle indices at once (receiver_osn.cpp:320-328,395-488).
+ * src_cts[b * source_power_count + s] = query ciphertext of the s-th source power (ascending) for
+ * bundle index bundle_indices[b]: size 2, coefficient form, first data level (receiver_osn.cpp:304-317).
+ * src_on_device != 0: the pointers are device pointers (inputs already resident in HBM). */
+int apsu_he_compute_powers(apsu_he_ctx *ctx, const uint32_t *bundle_indices, int n_bundle_idx,
+                           const uint64_t *const *src_cts, int src_on_device, const apsu_he_relin *rk,
+                           apsu_he_powers **out);
+int apsu_he_powers_free(apsu_he_powers *p);
+/* test hook: copy one computed power back (form/level per receiver_osn.cpp:459-487); words = 2*(level+1)*n */
+int apsu_he_powers_download(apsu_he_ctx *ctx, const apsu_he_powers *p, uint32_t bundle_idx, uint32_t power,
+                            uint64_t *out, size_t capacity_words, int *chain_idx, int *is_ntt);
+/* Receiver::ProcessBinBundleCache -> BatchedPlaintextPolyn::eval / eval_patstock for `count`
+ * BinBundles (receiver_osn.cpp:490-540 ; bin_bundle.cpp:106-174,192-360).  masks[i] = random_plain
+ * (n coefficients mod t, receiver_osn.cpp:217-284).  out_cts: count * 2 * n words, result i at
+ * out_cts + i*2*n, last level, irrelevant bits cleared.  *_on_device: pointers are device pointers. */
+int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles, int count, const apsu_he_powers *powers,
+                         const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out_cts,
+                         int out_on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APSU_HE_H */
