@@ -219,4 +219,21 @@ int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, i
     });
 }
 
+int apsu_he_profile_enable(apsu_he_ctx *c, int on)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->profile_enable(on != 0); }); }
+
+int apsu_he_profile_read(apsu_he_ctx *c, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset)
+{
+    return guarded([&] {
+        REQUIRE(c, "null argument");
+        Engine::ProfStats st;
+        c->eng->profile_read(&st, reset != 0);
+        for (int i = 0; i < capacity && i < Engine::P_COUNT; i++) {
+            if (ms) ms[i] = st.ms[i];
+            if (launches) launches[i] = st.launches[i];
+            if (units) units[i] = st.units[i];
+        }
+    });
+}
+
 } // extern "C"

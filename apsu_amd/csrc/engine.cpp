@@ -193,7 +193,70 @@ Engine::~Engine()
     if (stage_) (void)hipHostFree(stage_);
 }
 
-void Engine::sync() { HIP_CHECK(hipStreamSynchronize(st_)); }
+void Engine::sync()
+{
+    HIP_CHECK(hipStreamSynchronize(st_));
+    if (prof_on_) prof_collect();
+}
+
+// ---- profiling: one HIP event pair per launch on the engine's stream, resolved at the next sync
+void Engine::profile_enable(bool on)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    HIP_CHECK(hipStreamSynchronize(st_));
+    prof_collect();
+    prof_on_ = on;
+}
+
+void Engine::profile_read(ProfStats *out, bool reset)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    HIP_CHECK(hipStreamSynchronize(st_));
+    prof_collect();
+    if (out) *out = prof_;
+    if (reset) prof_ = ProfStats{};
+}
+
+void Engine::prof_begin(int kind, uint64_t units)
+{
+    if (!prof_on_) return;
+    ProfRec r{ nullptr, nullptr, kind, units };
+    for (hipEvent_t *e : { &r.a, &r.b }) {
+        if (!prof_pool_.empty()) { *e = prof_pool_.back(); prof_pool_.pop_back(); }
+        else HIP_CHECK(hipEventCreate(e));
+    }
+    HIP_CHECK(hipEventRecord(r.a, st_));
+    prof_recs_.push_back(r);
+}
+
+void Engine::prof_end()
+{
+    if (!prof_on_ || prof_recs_.empty()) return;
+    HIP_CHECK(hipEventRecord(prof_recs_.back().b, st_));
+}
+
+void Engine::prof_collect()
+{
+    for (auto &r : prof_recs_) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            prof_.ms[r.kind] += ms;
+            prof_.launches[r.kind] += 1;
+            prof_.units[r.kind] += r.units;
+        }
+        prof_pool_.push_back(r.a);
+        prof_pool_.push_back(r.b);
+    }
+    prof_recs_.clear();
+}
+
+struct ProfScope {
+    Engine *e;
+    ProfScope(Engine *e_, int kind, uint64_t units) : e(e_) { e->prof_begin(kind, units); }
+    ~ProfScope() { e->prof_end(); }
+};
+#define PROF(kind, units) ProfScope prof_scope_(this, kind, units)
+static uint64_t mac_units(const std::vector<MacJob> &mj, size_t L) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * L; return u; }
 
 void Engine::check_level(int chain_idx) const
 {
@@ -263,6 +326,7 @@ struct EngineAccess {
 // ============================================================================ device building blocks
 void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
 {
+    PROF(inverse ? P_NTT_INV : P_NTT_FWD, count);
     launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_);
 }
 
@@ -271,12 +335,12 @@ void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
     const int L = chain_idx + 1;
     const size_t n = hp_.n;
     u64 *tdec = ws((size_t)batch * (L + 1) * L * n);
-    launch_ks_decomp(dkey(), L, ct3 + (size_t)2 * L * n, ct_stride, tdec, n, batch, st_);
+    { PROF(P_KEYSWITCH, 0); launch_ks_decomp(dkey(), L, ct3 + (size_t)2 * L * n, ct_stride, tdec, n, batch, st_); }
     d_ntt(tdec, (size_t)batch * (L + 1) * L, map_ks(chain_idx), (L + 1) * L, false);
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
-    launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_);
+    { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
-    launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_);
+    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_); }
 }
 
 // ============================================================================ tier 1
@@ -403,7 +467,7 @@ void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
         HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(u64), st_));
         H2D(p, pt, pt_coeffs);
         std::vector<PlainJob> jobs{ PlainJob{ c0, p } };
-        launch_add_plain(dlevel(chain_idx), upload_jobs(jobs), n, 1, st_);
+        { PROF(P_OTHER, 0); launch_add_plain(dlevel(chain_idx), upload_jobs(jobs), n, 1, st_); }
         D2H(ct, c0, L * n);
         sync();
     });
@@ -422,14 +486,14 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
         H2D(in, a, 2 * L * n);
         if (!square) H2D(in + 2 * L * n, b, 2 * L * n);
         u64 *ext = ws((size_t)nop * 2 * E * n);
-        launch_behz_ext(dlevel(chain_idx), in, L * n, 1, ext, n, nop * 2, st_);
+        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(chain_idx), in, L * n, 1, ext, n, nop * 2, st_); }
         d_ntt(ext, (size_t)nop * 2 * E, map_ext(chain_idx), E, false);
         u64 *d = ws((size_t)3 * E * n), *o = ws(3 * L * n);
         std::vector<TensorJob> tj{ TensorJob{ ext, square ? ext : ext + (size_t)2 * E * n, d } };
-        launch_tensor(dlevel(chain_idx), upload_jobs(tj), n, 1, st_);
+        { PROF(P_TENSOR, 0); launch_tensor(dlevel(chain_idx), upload_jobs(tj), n, 1, st_); }
         d_ntt(d, (size_t)3 * E, map_ext(chain_idx), E, true);
         std::vector<FinishJob> fj{ FinishJob{ d, o, 1, 0 } };
-        launch_behz_finish(dlevel(chain_idx), upload_jobs(fj), false, n, 1, st_);
+        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), upload_jobs(fj), false, n, 1, st_); }
         D2H(out3, o, 3 * L * n);
         sync();
     });
@@ -459,7 +523,7 @@ void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
     WITH_ARENA({
         u64 *d = ws(polys * L * n), *o = ws(polys * (L - 1) * n);
         H2D(d, ct, polys * L * n);
-        launch_modswitch(dlevel(chain_idx), d, polys * L * n, polys, o, n, 1, st_);
+        { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(chain_idx), d, polys * L * n, polys, o, n, 1, st_); }
         D2H(ct, o, polys * (L - 1) * n);
         sync();
     });
@@ -657,7 +721,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 const auto &pl = s.levels[d - 1];
                 const int npar = pl.sp - pl.s0;
                 if (npar > 0) {
-                    launch_behz_ext(dlevel(first), slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_);
+                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
                     d_ntt(ext_ptr(pl.s0, 0), (size_t)npar * nb * 2 * Ef, map_ext(first), (int)Ef, false);
                 }
                 const auto &cl = s.levels[d];
@@ -672,9 +736,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                         fj.push_back(FinishJob{ dd, slot_ptr(nd[0], b), 1, 0 });
                     }
                 }
-                launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_);                 // :422/:424
+                { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }                 // :422/:424
                 d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext(first), (int)Ef, true);
-                launch_behz_finish(dlevel(first), upload_jobs(fj), false, n, (int)fj.size(), st_);
+                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 if (hp_.using_keyswitching) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
             }
             arena_off_ = arena_mark;
@@ -693,18 +757,18 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 for (size_t i = 0; i < powers.size(); i++)
                     for (int b = 0; b < nb; b++)
                         jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), out + ((size_t)i * nb + b) * 2 * Lf * n });
-                launch_copy_jobs(upload_jobs(jobs), 2 * Lf * n, cnt, st_);
+                { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(jobs), 2 * Lf * n, cnt, st_); }
                 return;
             }
             cur = dst_for(first - 1);
             for (size_t i = 0; i < powers.size(); i++)
                 for (int b = 0; b < nb; b++)
                     jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), cur + ((size_t)i * nb + b) * 2 * (Lf - 1) * n });
-            launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_);                     // :463,471,478
+            { PROF(P_MODSWITCH, 0); launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_); }                     // :463,471,478
             lvl = first - 1;
             while (lvl > target) {
                 u64 *nxt = dst_for(lvl - 1);
-                launch_modswitch(dlevel(lvl), cur, (size_t)2 * (lvl + 1) * n, 2, nxt, n, cnt, st_);
+                { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lvl), cur, (size_t)2 * (lvl + 1) * n, 2, nxt, n, cnt, st_); }
                 cur = nxt;
                 lvl--;
             }
@@ -714,7 +778,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         if (pw->n_high) {
             convert(s.high_powers, high, pw->high.u());
             // derived form used by eval_patstock's ct x ct products and coefficient-form plaintext products
-            launch_behz_ext(dlevel(high), pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_);
+            { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
             d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
         }
         sync();
@@ -859,20 +923,20 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     pj.push_back(PlainJob{ o, b.a0.u() });                                               // :159
                 }
                 for (int x = 0; x < Bp; x++) pj.push_back(PlainJob{ acc + (size_t)x * 2 * Lv * n, mask_ptr(pl_ids[x]) });   // :162
-                launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_);
+                { PROF(P_MAC, mac_units(mj, Lv)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
                 const PlainJob *pjd = upload_jobs(pj);
-                launch_add_plain(dlevel(lvl), pjd, n, Bp, st_);
-                launch_add_plain(dlevel(lvl), pjd + Bp, n, Bp, st_);
+                { PROF(P_OTHER, 0); launch_add_plain(dlevel(lvl), pjd, n, Bp, st_); }
+                { PROF(P_OTHER, 0); launch_add_plain(dlevel(lvl), pjd + Bp, n, Bp, st_); }
                 u64 *cur = acc;
                 for (int lv = lvl; lv > 0; lv--) {                                                        // :168-170
                     u64 *nxt = ws((size_t)Bp * 2 * lv * n);
-                    launch_modswitch(dlevel(lv), cur, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bp, st_);
+                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), cur, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bp, st_); }
                     cur = nxt;
                 }
                 std::vector<CtJob> cj;
                 for (int x = 0; x < Bp; x++) cj.push_back(CtJob{ cur + (size_t)x * 2 * n, res + (size_t)pl_ids[x] * 2 * n });
-                launch_copy_jobs(upload_jobs(cj), 2 * n, Bp, st_);
+                { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * n, Bp, st_); }
             }
 
             // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
@@ -899,17 +963,17 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                              (u32)(Ll * n), low_term_stride, (u32)(Ll * n) });             // :258-264
                     }
                 }
-                launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_);
+                { PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(inner, (size_t)NI * 2, low, true);                                                 // :268,297
                 u64 *innerh = inner;
                 for (int lv = low; lv > high; lv--) {                                                       // :269,298
                     u64 *nxt = ws((size_t)NI * 2 * lv * n);
-                    launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_);
+                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
                     innerh = nxt;
                 }
                 // ct x ct with the high powers (:272,301): extend, NTT, tensor, INTT, finish (+ sum over i, :273,303)
                 u64 *ext = ws((size_t)NI * 2 * Eh * n);
-                launch_behz_ext(dlevel(high), innerh, Lh * n, 1, ext, n, NI * 2, st_);
+                { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                 d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
                 u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
                 u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
@@ -923,9 +987,9 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     }
                     fj.push_back(FinishJob{ dbuf + (size_t)in_off[x] * 3 * Eh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                 }
-                launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_);
+                { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
                 d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
-                launch_behz_finish(dlevel(high), upload_jobs(fj), false, n, Bs, st_);
+                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), upload_jobs(fj), false, n, Bs, st_); }
                 if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
 
                 // i = 0 block: every term is rounded on its own before the sum (note N1)            :314-324
@@ -939,15 +1003,15 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                              term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
                                              (u32)(Ll * n) });
                 }
-                launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_);
+                { PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
                 u64 *termh = term;
                 for (int lv = low; lv > high; lv--) {
                     u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
-                    launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_);
+                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
                     termh = nxt;
                 }
-                launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_);
+                { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
 
                 // coefficient-form plaintexts a_{i*h} times the high powers (:328-337): exact, so the
                 // products are summed in the NTT domain and transformed back once
@@ -959,28 +1023,28 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     mj.push_back(MacJob{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
                                          (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n) });
                 }
-                launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
+                { PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(cf, (size_t)Bs * 2, high, true);
-                launch_add_many(dlevel(high), result, 3 * Lh * n, cf, 1, 2, n, Bs, st_);
+                { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, cf, 1, 2, n, Bs, st_); }
 
                 std::vector<PlainJob> pj;
                 for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, bundles[c0 + ps_ids[x]]->a0.u() });   // :345
                 for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, mask_ptr(ps_ids[x]) });              // :346
                 const PlainJob *pjd = upload_jobs(pj);
-                launch_add_plain(dlevel(high), pjd, n, Bs, st_);
-                launch_add_plain(dlevel(high), pjd + Bs, n, Bs, st_);
+                { PROF(P_OTHER, 0); launch_add_plain(dlevel(high), pjd, n, Bs, st_); }
+                { PROF(P_OTHER, 0); launch_add_plain(dlevel(high), pjd + Bs, n, Bs, st_); }
 
                 u64 *cur = result;
                 size_t stride = 3 * Lh * n;
                 for (int lv = high; lv > 0; lv--) {                                                         // :354-356
                     u64 *nxt = ws((size_t)Bs * 2 * lv * n);
-                    launch_modswitch(dlevel(lv), cur, stride, 2, nxt, n, Bs, st_);
+                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), cur, stride, 2, nxt, n, Bs, st_); }
                     cur = nxt;
                     stride = (size_t)2 * lv * n;
                 }
                 std::vector<CtJob> cj;
                 for (int x = 0; x < Bs; x++) cj.push_back(CtJob{ cur + (size_t)x * stride, res + (size_t)ps_ids[x] * 2 * n });
-                launch_copy_jobs(upload_jobs(cj), 2 * n, Bs, st_);
+                { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * n, Bs, st_); }
             }
             launch_clear_bits(res, (size_t)B * 2 * n, hp_.irrelevant_bit_count, st_);                       // :171,357
             if (out_on_device) D2D(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);

@@ -115,6 +115,12 @@ public:
     // introspection for tests
     size_t workspace_bytes() const { return arena_.bytes(); }
 
+    // ---------------- per-kernel timing with HIP events on the engine's stream (bench.py roofline)
+    enum ProfKind { P_NTT_FWD = 0, P_NTT_INV, P_MAC, P_BEHZ_EXT, P_TENSOR, P_BEHZ_FINISH, P_KEYSWITCH, P_MODSWITCH, P_OTHER, P_COUNT };
+    struct ProfStats { double ms[P_COUNT]; uint64_t launches[P_COUNT]; uint64_t units[P_COUNT]; };
+    void profile_enable(bool on);
+    void profile_read(ProfStats *out, bool reset);
+
 private:
     // arena (bump allocator reset per top-level operation)
     u64 *ws(size_t words);
@@ -163,7 +169,18 @@ private:
     } sched_;
     void build_schedule();
 
+    // profiling state
+    struct ProfRec { hipEvent_t a, b; int kind; uint64_t units; };
+    bool prof_on_ = false;
+    std::vector<ProfRec> prof_recs_;
+    std::vector<hipEvent_t> prof_pool_;
+    ProfStats prof_{};
+    void prof_begin(int kind, uint64_t units);
+    void prof_end();
+    void prof_collect();
+
     friend struct EngineAccess;
+    friend struct ProfScope;
 };
 
 } // namespace apsu_he

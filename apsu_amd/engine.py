@@ -181,6 +181,21 @@ class HeContext:
         _check(L.apsu_he_get_powers_dag(self.h, C.c_void_p(nodes.ctypes.data), cnt.value, C.byref(cnt)))
         return [tuple(int(v) for v in r) for r in nodes]
 
+    PROFILE_CLASSES = ("ntt_fwd", "ntt_inv", "dyadic_mac", "behz_ext", "behz_tensor", "behz_finish", "keyswitch",
+                       "modswitch", "other")
+
+    def profile_enable(self, on=True):
+        _check(load_library().apsu_he_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        """-> {class: (ms, launches, units)} of device time measured with HIP events on the engine's stream."""
+        k = len(self.PROFILE_CLASSES)
+        ms = (C.c_double * k)()
+        la = (C.c_uint64 * k)()
+        un = (C.c_uint64 * k)()
+        _check(load_library().apsu_he_profile_read(self.h, ms, la, un, k, 1 if reset else 0))
+        return {name: (ms[i], int(la[i]), int(un[i])) for i, name in enumerate(self.PROFILE_CLASSES)}
+
     # ---- tier 1: Evaluator methods (in place on numpy arrays shaped [polys][L][n])
     def transform_to_ntt_inplace(self, ct, chain_idx):
         _check(load_library().apsu_he_transform_to_ntt(self.h, _p(ct), ct.shape[0], chain_idx))

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py — DB-side query evaluation (ComputePowers + every BinBundle) on MI355X.
+
+One "step" = one pass of the hot path over one query: Receiver::ComputePowers for every bundle
+index (receiver/apsu/receiver_osn.cpp:320-328,395-488) + ProcessBinBundleCache for every BinBundle
+(:334-364,490-540 -> bin_bundle.cpp:106-174,192-360) + the gather of the result ciphertexts.
+Inputs (query ciphertexts, relin keys, masks, the whole BinBundle DB) are resident in HBM when the
+timed region starts.  Metric = BASELINE.json's "sender query-eval ms" on the 16M-4096 parameters
+(lower is better; strong scaling: the query is fixed, BinBundles are sharded over ranks).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Synthetic data: ciphertext / key limbs are uniform
+residues, BinBundle plaintexts come from the engine's documented GPU generator.
+The CPU oracle (oracle/) is used ONLY in the cpu_baseline leg (rank 0, N=1) as the timed CPU
+restatement and as the bit-exactness checker of the GPU result; it is never on the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GOLD = 0x9E3779B97F4A7C15
+SEED0 = 0x41505355             # "APSU"
+
+# synthetic DB shape per parameter set: BinBundles per bundle index, degrees
+WORKLOADS = {
+    "16M-4096": dict(bundles_per_idx=7, degrees=lambda D: [D] * 6 + [170]),
+    "1M-1024-com": dict(bundles_per_idx=17, degrees=lambda D: [D] * 17),
+    "100K-1": dict(bundles_per_idx=16, degrees=lambda D: [D] * 16),
+    "256M-4096": dict(bundles_per_idx=34, degrees=lambda D: [D] * 34),
+}
+
+
+def splitmix_values(seed, d, n, t):
+    """host replica of the engine's synthetic plaintext generator (include/apsu_he.h:
+    apsu_he_db_random_bundle): value(d, k) = mix(seed + (d*n + k + 1) * GOLD) % t"""
+    idx = (np.arange(n, dtype=np.uint64) + np.uint64(d * n + 1))
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(GOLD)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % np.uint64(t)
+
+
+def partition(units, bundle_idx_count, world):
+    """units: [(bundle_idx, cache_idx, degree)].  GPUs go to bundle indices first, then an index's
+    BinBundles are split over its GPUs by cost ~ degree (LPT greedy) — SURVEY.md §8e."""
+    ranks_of = {b: [] for b in range(bundle_idx_count)}
+    if world >= bundle_idx_count:
+        for r in range(world):
+            ranks_of[r % bundle_idx_count].append(r)
+    else:
+        for b in range(bundle_idx_count):
+            ranks_of[b].append(b % world)
+    assign = {r: [] for r in range(world)}
+    for b in range(bundle_idx_count):
+        load = {r: sum(u[2] + 64 for u in assign[r]) for r in ranks_of[b]}
+        for u in sorted([u for u in units if u[0] == b], key=lambda u: -u[2]):
+            r = min(load, key=lambda k: load[k])
+            assign[r].append(u)
+            load[r] += u[2] + 64
+    return assign
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="16M-4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed steps")
+    args = ap.parse_args()
+
+    import torch
+    import apsu_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm (xGMI)
+
+    with open(os.path.join(ROOT, "tests", "params", args.config + ".json")) as f:
+        params_json = f.read()
+    ctx = apsu_amd.HeContext(params_json, device=local_rank)
+    n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
+    Lf = first + 1
+    wl = WORKLOADS[args.config]
+    D = ctx.max_items_per_bin - 1
+    units = []
+    for b in range(ctx.bundle_idx_count):
+        for ci, deg in enumerate(wl["degrees"](D)):
+            units.append((b, ci, deg))
+    mine = partition(units, ctx.bundle_idx_count, world)[rank]
+    my_indices = sorted({u[0] for u in mine})
+
+    # ---- HBM-resident inputs ------------------------------------------------------------------
+    t_setup = time.time()
+    bundles = [ctx.random_bundle(b, ci, deg, SEED0 + 1000003 * b + 7919 * ci) for (b, ci, deg) in mine]
+    db_bytes = sum(bd.db_bytes for bd in bundles)
+    rng = np.random.default_rng(SEED0)                    # identical on every rank
+    ns = ctx.source_power_count
+    src_host = np.stack([np.stack([np.stack([np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in ctx.q[:Lf]])
+                                             for _ in range(2)]) for _ in range(ns)])
+                         for _ in range(ctx.bundle_idx_count)])          # [idx][source][2][Lf][n]
+    rk_host = None
+    rk = None
+    if K > 1:
+        rk_host = np.stack([np.stack([np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in ctx.q])
+                                      for _ in range(2)]) for _ in range(K - 1)])
+        rk = ctx.upload_relin_keys(rk_host)
+    mask_host = rng.integers(0, t, (len(units), n), dtype=np.uint64)
+    unit_pos = {(u[0], u[1]): i for i, u in enumerate(units)}
+    src_dev = torch.from_numpy(src_host.view(np.int64)).to(dev)
+    mask_dev = torch.from_numpy(mask_host.view(np.int64)).to(dev)
+    esz = 8
+    src_ptrs = [[src_dev.data_ptr() + ((b * ns + s) * 2 * Lf * n) * esz for s in range(ns)] for b in my_indices]
+    mask_ptrs = [mask_dev.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine]
+    max_local = max(len(v) for v in partition(units, ctx.bundle_idx_count, world).values())
+    out_dev = torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev)
+    gathered = torch.zeros((world * max_local, 2, n), dtype=torch.int64, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step():
+        pw = ctx.compute_powers(my_indices, src_ptrs, rk, on_device=True) if my_indices else None
+        if bundles:
+            ctx.eval_bundles(bundles, pw, rk, mask_ptrs, out=out_dev.data_ptr(), masks_on_device=True, out_on_device=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out_dev)           # the path's only collective
+        return pw
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+    ms_local = elapsed * 1e3 / max(1, args.steps)
+    ms_step = ms_local
+    if world > 1:
+        tt = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_step = float(tt.item())
+
+    result = {
+        "metric": "sender query-eval ms (ComputePowers + all BinBundles + gather), %s params" % args.config,
+        "value": round(ms_step, 4), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: n=%d, %d bundle indices x %d BinBundles (degrees %s), %d source -> %d target powers, "
+                               "ps_low_degree=%d" % (args.config, n, ctx.bundle_idx_count, wl["bundles_per_idx"],
+                                                     sorted(set(wl["degrees"](D)), reverse=True), ns,
+                                                     int(ctx.info.target_power_count), ctx.ps_low_degree),
+                   "db_bytes_rank0": db_bytes, "binbundles_rank0": len(mine), "parallelism": "binbundle-shard x%d" % world,
+                   "setup_s": round(t_setup, 2)},
+    }
+
+    if prof is not None:
+        steps = max(1, args.steps)
+        ntt_ms = prof["ntt_fwd"][0] + prof["ntt_inv"][0]
+        ntt_launches = prof["ntt_fwd"][1] + prof["ntt_inv"][1]
+        ntt_limbs = prof["ntt_fwd"][2] + prof["ntt_inv"][2]
+        ntt_bytes = ntt_limbs * 16 * n                                  # 16*n bytes per limb transform
+        achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "k_ntt (forward+inverse, in-path launches of the timed steps)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": int(ntt_bytes / max(1, ntt_launches)),
+            "avg_launch_us": round(ntt_ms * 1e3 / max(1, ntt_launches), 2),
+            "launches_per_step": ntt_launches / steps, "limb_transforms_per_step": ntt_limbs / steps,
+            "note": "working sets of in-path launches are mostly Infinity-Cache resident; see ntt_stream for >=1 GiB batches",
+        }
+        mac_ms, _, mac_units = prof["dyadic_mac"]
+        mac_bytes = mac_units * n * 8                                   # plaintext bytes streamed from HBM
+        result["kernels_ms_per_step"] = {k: round(v[0] / steps, 4) for k, v in prof.items()}
+        result["dyadic_mac"] = {"db_GBps": round(mac_bytes / (mac_ms * 1e-3) / 1e9, 1) if mac_ms > 0 else 0.0,
+                                "db_bytes_per_step": int(mac_bytes / steps)}
+
+    # ---- NTT streaming micro-measurement: >= 1 GiB of distinct limbs (HBM, not cache) -----------
+    if rank == 0 and not args.no_profile:
+        try:
+            limbs = max(1, (1 << 30) // (n * 8))
+            polys = limbs // Lf
+            big = np.zeros((polys, Lf, n), dtype=np.uint64)
+            big[:] = src_host[0, 0, 0]                                  # valid residues
+            # tier-1 call moves data over PCIe; time only the kernel via the event profile
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            ctx.transform_to_ntt_inplace(big, first)
+            ctx.transform_from_ntt_inplace(big, first)
+            p2 = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+            ms = p2["ntt_fwd"][0] + p2["ntt_inv"][0]
+            by = (p2["ntt_fwd"][2] + p2["ntt_inv"][2]) * 16 * n
+            result["ntt_stream"] = {"limbs": polys * Lf, "bytes": int(by), "GBps": round(by / (ms * 1e-3) / 1e9, 1),
+                                    "frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "fwd_ms": round(p2["ntt_fwd"][0], 3), "inv_ms": round(p2["ntt_inv"][0], 3)}
+            del big
+        except Exception as e:                                          # never lose the main line
+            result["ntt_stream"] = {"error": str(e)}
+
+    # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host,
+                                              unit_pos, out_dev, n, t)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host, unit_pos, out_dev, n, t):
+    """Times the CPU restatement (oracle/, the reference's op order, 1 thread) on a bounded sample
+    of the SAME workload: ComputePowers for one bundle index + eval of one full BinBundle, and
+    checks the GPU result of that BinBundle bit-for-bit."""
+    from oracle import ref
+    p = ref.load_params(params_json)
+    C = ref.RefContext.from_params(p)
+    ps = p["ps_low_degree"]
+    targets = ref.create_powers_set(ps, p["max_items_per_bin"])
+    _, nodes = ref.powers_dag(p["query_powers"], targets)
+    sources = sorted(p["query_powers"])
+    b0, ci0, deg0 = mine[0]
+    srcs = {e: np.ascontiguousarray(src_host[b0, s]) for s, e in enumerate(sources)}
+    t0 = time.perf_counter()
+    pw = C.compute_powers(srcs, nodes, rk_host, ps)
+    powers_ms = (time.perf_counter() - t0) * 1e3
+    # host replica of the synthetic BinBundle (DB build: not timed)
+    seed = SEED0 + 1000003 * b0 + 7919 * ci0
+    pci = C.plain_chain_idx(ps)
+    coeffs = []
+    for d in range(deg0 + 1):
+        raw = splitmix_values(seed, d, n, t)
+        coeffs.append(C.plain_lift_ntt(raw, pci) if ref.coeff_is_ntt(ps, d) else raw)
+    plist = [None] * (p["max_items_per_bin"] + 1)
+    for k, v in pw.items():
+        plist[k] = v
+    mask = np.ascontiguousarray(mask_host[unit_pos[(b0, ci0)]])
+    t0 = time.perf_counter()
+    if ps > 1 and ps < deg0:
+        exp = C.eval_patstock(plist, coeffs, ps, rk_host, mask)
+    else:
+        exp = C.eval(plist, coeffs, plist[1].shape[1] - 1, mask)
+    bundle_ms = (time.perf_counter() - t0) * 1e3
+    got = out_dev[0].cpu().numpy().view(np.uint64).reshape(2, 1, n)
+    bit_exact = bool((got == exp).all())
+    # extrapolate to the whole query: powers once per bundle index, bundles by degree
+    nb = len({u[0] for u in units})
+    full = powers_ms * nb + sum(bundle_ms * (u[2] / deg0) for u in units)
+    return {"value": round(full, 1), "unit": "ms", "cores": 1, "kind": "port",
+            "sample": "ComputePowers for 1 of %d bundle indices (%.0f ms) + eval of 1 BinBundle of degree %d (%.0f ms); "
+                      "whole query extrapolated = %d x powers + sum over %d BinBundles scaled by degree; CPU restatement of "
+                      "SEAL (oracle/), not Microsoft SEAL" % (nb, powers_ms, deg0, bundle_ms, nb, len(units)),
+            "powers_ms_per_bundle_idx": round(powers_ms, 1), "bundle_ms": round(bundle_ms, 1),
+            "gpu_result_bit_exact_vs_cpu": bit_exact}
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,14 @@ int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles,
                          const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out_cts,
                          int out_on_device);
 
+/* ---- measurement hooks (replace the reference's STOPWATCH timers, receiver_osn.cpp:167,403,504) ----
+ * Per-kernel-class device time from HIP events recorded on the engine's stream around each launch.
+ * Classes (index): 0 ntt_fwd, 1 ntt_inv, 2 dyadic_mac, 3 behz_ext, 4 behz_tensor, 5 behz_finish,
+ * 6 keyswitch, 7 modswitch, 8 other.  units: limb polynomials for 0/1, plaintext limb-terms for 2. */
+#define APSU_HE_PROFILE_CLASSES 9
+int apsu_he_profile_enable(apsu_he_ctx *ctx, int on);
+int apsu_he_profile_read(apsu_he_ctx *ctx, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset);
+
 #ifdef __cplusplus
 }
 #endif
