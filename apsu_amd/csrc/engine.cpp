@@ -805,37 +805,30 @@ std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cach
     b->a0.alloc(n * sizeof(u64));
     const size_t H = b->use_ps ? b->H : 0;
     if (H) b->lifted.alloc(H * Lh * n * sizeof(u64));
-    // coefficient d of the batched polynomial = splitmix64 stream at offset d*n (mod t), coefficient form
-    const size_t chunk = 256;                                     // plaintexts per staging pass
+    // coefficient d of the batched polynomial = splitmix64 stream at offset d*n (mod t), coefficient form.
+    // The whole polynomial is generated in one launch, then lifted + NTT'd in runs of consecutive degrees.
     WITH_ARENA({
-        u64 *raw = ws(chunk * n);
-        launch_fill_random(b->a0.u(), n, seed, hp_.t, st_);
+        u64 *raw = ws((size_t)(degree + 1) * n);
+        launch_fill_random(raw, (size_t)(degree + 1) * n, seed, hp_.t, st_);
+        D2D(b->a0.u(), raw, n);
         size_t slot = 0, hi = 0;
-        std::vector<uint32_t> pend_ntt, pend_cf;
-        auto flush = [&]() {
-            if (!pend_ntt.empty()) {
-                for (size_t i = 0; i < pend_ntt.size(); i++)
-                    launch_fill_random(raw + i * n, n, seed + (u64)pend_ntt[i] * n * 0x9e3779b97f4a7c15ULL, hp_.t, st_);
-                launch_lift(dlevel(b->pt_level), raw, b->ntt.u() + slot * Lpt * n, n, (int)pend_ntt.size(), nullptr, st_);
-                d_ntt_ct(b->ntt.u() + slot * Lpt * n, pend_ntt.size(), b->pt_level, false);
-                slot += pend_ntt.size();
-                pend_ntt.clear();
-            }
-            if (!pend_cf.empty()) {
-                for (size_t i = 0; i < pend_cf.size(); i++)
-                    launch_fill_random(raw + i * n, n, seed + (u64)pend_cf[i] * n * 0x9e3779b97f4a7c15ULL, hp_.t, st_);
-                launch_lift(dlevel(high), raw, b->lifted.u() + hi * Lh * n, n, (int)pend_cf.size(), nullptr, st_);
-                d_ntt_ct(b->lifted.u() + hi * Lh * n, pend_cf.size(), high, false);
-                hi += pend_cf.size();
-                pend_cf.clear();
-            }
-        };
-        for (uint32_t d = 1; d <= degree; d++) {
+        uint32_t d = 1;
+        while (d <= degree) {
             const bool is_ntt = (!ps && d != 0) || (ps && (d % h) != 0);
-            if (is_ntt) { pend_ntt.push_back(d); if (pend_ntt.size() == chunk) flush(); }
-            else if (H) { pend_cf.push_back(d); if (pend_cf.size() == chunk) flush(); }
+            uint32_t e = d;
+            while (e + 1 <= degree && (((!ps) || ((e + 1) % h) != 0) == is_ntt)) e++;
+            const size_t run = e - d + 1;
+            if (is_ntt) {
+                launch_lift(dlevel(b->pt_level), raw + (size_t)d * n, b->ntt.u() + slot * Lpt * n, n, (int)run, nullptr, st_);
+                slot += run;
+            } else if (H) {
+                launch_lift(dlevel(high), raw + (size_t)d * n, b->lifted.u() + hi * Lh * n, n, (int)run, nullptr, st_);
+                hi += run;
+            }
+            d = e + 1;
         }
-        flush();
+        d_ntt_ct(b->ntt.u(), b->ntt_count, b->pt_level, false);
+        if (H) d_ntt_ct(b->lifted.u(), H, high, false);
         sync();
     });
     return b;

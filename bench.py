@@ -53,26 +53,6 @@ def splitmix_values(seed, d, n, t):
     return z % np.uint64(t)
 
 
-def partition(units, bundle_idx_count, world):
-    """units: [(bundle_idx, cache_idx, degree)].  GPUs go to bundle indices first, then an index's
-    BinBundles are split over its GPUs by cost ~ degree (LPT greedy) — SURVEY.md §8e."""
-    ranks_of = {b: [] for b in range(bundle_idx_count)}
-    if world >= bundle_idx_count:
-        for r in range(world):
-            ranks_of[r % bundle_idx_count].append(r)
-    else:
-        for b in range(bundle_idx_count):
-            ranks_of[b].append(b % world)
-    assign = {r: [] for r in range(world)}
-    for b in range(bundle_idx_count):
-        load = {r: sum(u[2] + 64 for u in assign[r]) for r in ranks_of[b]}
-        for u in sorted([u for u in units if u[0] == b], key=lambda u: -u[2]):
-            r = min(load, key=lambda k: load[k])
-            assign[r].append(u)
-            load[r] += u[2] + 64
-    return assign
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +65,7 @@ def main():
 
     import torch
     import apsu_amd
+    from apsu_amd.sharding import gather_slots, partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +92,8 @@ def main():
     for b in range(ctx.bundle_idx_count):
         for ci, deg in enumerate(wl["degrees"](D)):
             units.append((b, ci, deg))
-    mine = partition(units, ctx.bundle_idx_count, world)[rank]
+    assign = partition(units, ctx.bundle_idx_count, world)
+    mine = assign[rank]
     my_indices = sorted({u[0] for u in mine})
 
     # ---- HBM-resident inputs ------------------------------------------------------------------
@@ -136,7 +118,7 @@ def main():
     esz = 8
     src_ptrs = [[src_dev.data_ptr() + ((b * ns + s) * 2 * Lf * n) * esz for s in range(ns)] for b in my_indices]
     mask_ptrs = [mask_dev.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine]
-    max_local = max(len(v) for v in partition(units, ctx.bundle_idx_count, world).values())
+    max_local, _rows = gather_slots(assign)
     out_dev = torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev)
     gathered = torch.zeros((world * max_local, 2, n), dtype=torch.int64, device=dev) if world > 1 else None
     torch.cuda.synchronize()

@@ -1,0 +1,201 @@
+"""GPU tier (pytest -m gpu): the fused tier-2 path — Receiver::ComputePowers and
+BatchedPlaintextPolyn::eval / eval_patstock for batches of BinBundles — against the CPU oracle on the
+same seeded inputs (bit-exact), the golden path vectors, the reference's error behaviour, and
+size-independent properties at BASELINE.json's full 16M-4096 size."""
+import numpy as np
+import pytest
+
+import apsu_amd
+import common
+from golden_util import arr, load
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+
+def run_scenario(js, degrees, roots_frac=0.5):
+    S = common.make_scenario(js, degrees, roots_frac=roots_frac)
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    assert G.powers_dag() == S.nodes
+    rk = G.upload_relin_keys(S.rk) if S.rk is not None else None
+    srcs = [[S.src[b][e] for e in S.sources] for b in S.bundle_indices]
+    pw = G.compute_powers(S.bundle_indices, srcs, rk)
+    for b in S.bundle_indices:
+        for p in S.targets:
+            ct, ci, is_ntt = pw.download(b, p)
+            exp = opw[b][p]
+            assert ct.shape == exp.shape and (ct == exp).all(), "power %d of bundle index %d" % (p, b)
+            assert is_ntt == (S.ps_low == 0 or p <= S.ps_low)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    out = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
+    for i, b in enumerate(S.bundles):
+        exp = common.oracle_eval(S, opw, b)
+        assert (out[i] == exp).all(), "bundle idx=%d degree=%d" % (b["bundle_idx"], b["degree"])
+        ok, budget = common.check_semantics(S, b, out[i])
+        assert ok and budget > 0
+    return S, G, pw, rk, gb, out
+
+
+def test_toy_paterson_stockmeyer_ragged_degrees():
+    # degrees: full, == ps_low (plain eval at the low level), multiples of h (r == 0), h exactly, h+1, 1, 0
+    run_scenario(common.toy_json(), {0: [11, 10, 3, 8, 4, 5, 1, 0], 1: [7, 2]})
+
+
+def test_toy_without_paterson_stockmeyer():
+    run_scenario(common.toy_json(ps_low=0, max_items=6, query_powers=(1, 2, 3, 5)), {0: [6, 2, 0], 1: [5]})
+
+
+def test_toy_two_limb_key_level():
+    # K = 2: first = last level, relinearisation at chain index 0
+    # (all target powers are sources, so the only ct x ct product is eval_patstock's: one 60-bit limb has budget for it)
+    run_scenario(common.toy_json(n=256, coeff_bits=(60, 40), plain_bits=14, ps_low=2, max_items=5, query_powers=(1, 2, 3),
+                                 felts=7), {0: [5, 4, 2]})
+
+
+def test_config_100K_1():
+    run_scenario(common.param_json("100K-1"), {0: [19, 7, 1]})
+
+
+def test_config_1M_1024_com():
+    run_scenario(common.param_json("1M-1024-com"), {0: [124, 30, 6], 1: [124, 5]})
+
+
+def test_config_16M_4096_reduced():
+    # one full BinBundle (D = 1303, H = 28, r = 43) and the short one of the synthetic DB
+    run_scenario(common.param_json("16M-4096"), {0: [1303], 3: [170]})
+
+
+def test_config_256M_4096_reduced():
+    # first level has 4 limbs: low powers ARE mod-switched once (4 -> 3), high powers twice (4 -> 2)
+    run_scenario(common.param_json("256M-4096"), {1: [700]}, roots_frac=0.02)
+
+
+def test_golden_path_on_gpu():
+    g = load("path_n64.json")
+    js = common.toy_json(n=g["n"], coeff_bits=g["coeff_bits"], plain_bits=g["plain_bits"], ps_low=g["ps_low_degree"],
+                         max_items=g["max_items_per_bin"], query_powers=g["query_powers"])
+    G = apsu_amd.HeContext(js)
+    assert [list(nd) for nd in G.powers_dag()] == g["dag_nodes"]
+    rk = G.upload_relin_keys(arr(g["rk"]))
+    srcs = [[arr(g["sources"][str(e)]) for e in sorted(g["query_powers"])]]
+    pw = G.compute_powers([0], srcs, rk)
+    for p, ct in g["powers"].items():
+        got, _, _ = pw.download(0, int(p))
+        assert (got == arr(ct)).all()
+    gb = [G.upload_bundle(0, i, [arr(c) for c in b["coeffs"]], b["is_ntt"]) for i, b in enumerate(g["bundles"])]
+    out = G.eval_bundles(gb, pw, rk, [arr(b["mask"]) for b in g["bundles"]])
+    for i, b in enumerate(g["bundles"]):
+        assert (out[i] == arr(b["result"])).all()
+    G.close()
+
+
+def test_special_plaintexts_zero_and_monomial():
+    """all-zero coefficients are legal (bin_bundle.cpp:111-114); a coefficient-form a_{i*h} whose
+    encoding is a monomial takes SEAL's no-lift shortcut"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11]})
+    b = S.bundles[0]
+    C = S.C
+    pci = C.plain_chain_idx(S.ps_low)
+    b["A"][5] = 0                                            # NTT-form coefficient identically zero
+    b["coeffs"][5] = C.plain_lift_ntt(C.encode(b["A"][5]), pci)
+    b["A"][8] = C.t - 1                                      # a_{2h}: all bins equal -> constant polynomial -> monomial
+    b["coeffs"][8] = C.encode(b["A"][8])
+    assert np.count_nonzero(b["coeffs"][8]) == 1 and b["coeffs"][8][0] >= (C.t + 1) // 2
+    b["A"][4] = 0                                            # a_h identically zero (coefficient form)
+    b["coeffs"][4] = C.encode(b["A"][4])
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    gb = G.upload_bundle(0, 0, b["coeffs"], b["flags"])
+    out = G.eval_bundles([gb], pw, rk, [b["mask"]])
+    assert (out[0] == common.oracle_eval(S, opw, b)).all()
+    assert common.check_semantics(S, b, out[0])[0]
+    G.close()
+
+
+def test_error_behaviour_matches_reference():
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [10], 1: [3]})
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    b0, b1 = S.bundles
+    with pytest.raises(ValueError):                          # layout rule of the ctor violated (bin_bundle.cpp:418-420)
+        G.upload_bundle(0, 0, b0["coeffs"], [not f for f in b0["flags"]])
+    with pytest.raises(ValueError):                          # degree beyond max_items_per_bin
+        G.upload_bundle(0, 0, b0["coeffs"] * 2, b0["flags"] * 2)
+    with pytest.raises(ValueError):
+        G.upload_bundle(9, 0, b0["coeffs"], b0["flags"])     # bundle index out of range
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    gb1 = G.upload_bundle(1, 0, b1["coeffs"], b1["flags"])
+    with pytest.raises(ValueError):                          # no powers for bundle index 1
+        G.eval_bundles([gb1], pw, rk, [b1["mask"]])
+    gb0 = G.upload_bundle(0, 0, b0["coeffs"], b0["flags"])
+    with pytest.raises(ValueError):                          # relin keys are required for eval_patstock
+        G.eval_bundles([gb0], pw, None, [b0["mask"]])
+    assert G.eval_bundles([], pw, rk, []).shape[0] == 0      # empty batch
+    G.close()
+
+
+def test_device_resident_io_and_profile_hooks():
+    """inputs/outputs as device pointers (bench.py's mode) give the same bits as host buffers"""
+    import torch
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 17]})
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    src = np.stack([S.src[0][e] for e in S.sources])
+    src_d = torch.from_numpy(src.view(np.int64)).cuda()
+    w = src[0].size
+    ptrs = [[src_d.data_ptr() + i * w * 8 for i in range(len(S.sources))]]
+    G.profile_enable(True)
+    pw_h = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    pw_d = G.compute_powers([0], ptrs, rk, on_device=True)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = np.stack([b["mask"] for b in S.bundles])
+    mask_d = torch.from_numpy(masks.view(np.int64)).cuda()
+    out_d = torch.zeros((len(gb), 2, G.n), dtype=torch.int64, device="cuda")
+    out_h = G.eval_bundles(gb, pw_h, rk, list(masks))
+    G.eval_bundles(gb, pw_d, rk, [mask_d.data_ptr() + i * G.n * 8 for i in range(len(gb))], out=out_d.data_ptr(),
+                   masks_on_device=True, out_on_device=True)
+    assert (out_d.cpu().numpy().view(np.uint64).reshape(out_h.shape) == out_h).all()
+    prof = G.profile_read()
+    assert prof["ntt_fwd"][1] > 0 and prof["ntt_fwd"][2] > 0 and prof["ntt_fwd"][0] > 0
+    assert prof["dyadic_mac"][1] > 0
+    G.close()
+
+
+def test_full_size_16M_properties():
+    """BASELINE.json size (n = 8192, D = 1303, 241 MB per BinBundle) on the synthetic GPU-generated DB:
+    (1) a second evaluation is bit-identical (determinism / no stale workspace);
+    (2) decrypt(result) == P(x) + mask per slot with P rebuilt on the host from the documented generator;
+    (3) changing only the mask shifts the decrypted slots by exactly the mask difference."""
+    from bench import SEED0, splitmix_values
+    js = common.param_json("16M-4096")
+    S = common.make_scenario(js, {2: []})                    # keys + one encrypted query, no host-built bundles
+    C = S.C
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([2], [[S.src[2][e] for e in S.sources]], rk)
+    seed = SEED0 + 4242
+    D = G.max_items_per_bin - 1
+    gb = G.random_bundle(2, 0, D, seed)
+    assert gb.db_bytes > 240 * 2**20
+    m1 = ref.fill_uniform(1, C.t, C.n)
+    m2 = ref.fill_uniform(2, C.t, C.n)
+    o1 = G.eval_bundles([gb], pw, rk, [C.encode(m1)])
+    o1b = G.eval_bundles([gb], pw, rk, [C.encode(m1)])
+    assert (o1 == o1b).all()
+    o2 = G.eval_bundles([gb], pw, rk, [C.encode(m2)])
+    A = np.stack([C.decode(splitmix_values(seed, d, C.n, C.t)) for d in range(D + 1)])
+    x = S.x[2].astype(object)
+    acc = np.zeros(C.n, dtype=object)
+    for d in range(D, -1, -1):
+        acc = (acc * x + A[d].astype(object)) % C.t
+    s1 = C.decode(C.decrypt(S.sk, o1[0], 0)[0]).astype(object)
+    s2 = C.decode(C.decrypt(S.sk, o2[0], 0)[0]).astype(object)
+    assert (s1 == (acc + m1.astype(object)) % C.t).all()
+    assert ((s2 - s1) % C.t == (m2.astype(object) - m1.astype(object)) % C.t).all()
+    G.close()

@@ -1,0 +1,209 @@
+"""CPU tier: the product's host logic (apsu_amd/csrc/params.cpp, powers_dag.cpp, ntt_core.h) checked
+against the oracle, plus the C-ABI export check.  No GPU compute is attempted here."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+u64p = C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(ROOT, "apsu_amd", "libapsu_he_hostemu.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "apsu_amd", "csrc"), "-s", "../libapsu_he_hostemu.so"])
+    lib = C.CDLL(so)
+    lib.emu_last_error.restype = C.c_char_p
+    return lib
+
+
+CONFIGS = ["100K-1", "1M-1024-com", "16M-4096", "256M-4096"]
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_params_match_oracle_and_survey(emu, name):
+    js = common.param_json(name)
+    out = np.zeros(64, dtype=np.uint64)
+    k = emu.emu_params_info(js.encode(), out.ctypes.data_as(u64p), 64)
+    assert k > 0, emu.emu_last_error()
+    p = ref.load_params(js)
+    Cx = ref.RefContext.from_params(p)
+    v = [int(x) for x in out[:k]]
+    K = Cx.K
+    assert v[0] == Cx.n and v[1] == K and v[2] == Cx.first and v[3] == Cx.t
+    assert v[4:4 + K] == Cx.q
+    assert v[4 + K:4 + 2 * K] == Cx.psi
+    rest = v[4 + 2 * K:]
+    assert rest[0] == Cx.nB and rest[1] == Cx.m_sk and rest[2] == Cx.gamma and rest[3:3 + Cx.nB] == Cx.B
+    tail = rest[3 + Cx.nB:]
+    assert tail[0] == p["bundle_idx_count"] and tail[1] == p["items_per_bundle"]
+    assert tail[3] == Cx.irrelevant_bit_count()
+
+
+def test_known_seal_constants():
+    """sanity anchors quoted in SURVEY.md §8c(3) / App. A"""
+    assert ref.RefContext(8192, [56, 56, 56, 50], 0, 20).t == 1032193          # PlainModulus::Batching(8192, 20)
+    assert ref.RefContext(4096, [48, 36, 25], 0, 18).q == [0xffffffffc001, 0xffffee001, 0x1ffc001]
+    c = ref.RefContext(8192, [56, 56, 56, 50], 0, 22)
+    assert c.t == 0x3e4001 and c.q == [0xfffffffff70001, 0xfffffffff78001, 0xfffffffffb4001, 0x3ffffffffc001]
+    assert c.irrelevant_bit_count() == 21
+    assert ref.RefContext(8192, [50, 50, 50, 38, 30], 0, 26).irrelevant_bit_count() == 11
+
+
+@pytest.mark.parametrize("n,bits", [(64, [40, 40, 40, 36]), (4096, [48, 36, 25]), (8192, [56, 56, 56, 50])])
+def test_level_constants_match_oracle_semantics(emu, n, bits):
+    """the product's BEHZ / scaling constants reproduce the oracle's operation results: checked by
+    re-deriving a few of them in Python big ints"""
+    Cx = ref.RefContext(n, bits, 0, 17 if n == 64 else 18 if n == 4096 else 22)
+    q = np.array(Cx.q, dtype=np.uint64)
+    for ci in range(Cx.first + 1):
+        out = np.zeros(512, dtype=np.uint64)
+        k = emu.emu_level_constants(C.c_uint64(n), q.ctypes.data_as(u64p), len(q), C.c_uint64(Cx.t), ci,
+                                    out.ctypes.data_as(u64p), 512)
+        assert k > 0, emu.emu_last_error()
+        v = [int(x) for x in out[:k]]
+        L, nB, m_sk, gamma = v[0], v[1], v[2], v[3]
+        assert L == ci + 1 and m_sk == Cx.m_sk and gamma == Cx.gamma
+        B = v[4:4 + nB]
+        assert B == Cx.B[:nB] or nB == Cx.nB
+        Q = 1
+        for x in Cx.q[:L]:
+            Q *= x
+        pos = 4 + nB
+        cdp = v[pos:pos + L]
+        assert cdp == [(Q // Cx.t) % qq for qq in Cx.q[:L]]
+        pos += L
+        assert v[pos] == Q % Cx.t and v[pos + 1] == (Cx.t + 1) // 2
+        pos += 2
+        assert v[pos:pos + L] == [qq - Cx.t for qq in Cx.q[:L]]
+        pos += L
+        inv_last = v[pos:pos + L - 1]
+        assert inv_last == [pow(Cx.q[L - 1], -1, Cx.q[j]) for j in range(L - 1)]
+        pos += L - 1
+        assert v[pos:pos + L] == [pow(Q // Cx.q[j], -1, Cx.q[j]) for j in range(L)]
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+def test_powers_dag_matches_oracle(emu, name):
+    p = ref.load_params(common.param_json(name))
+    tg = ref.create_powers_set(p["ps_low_degree"], p["max_items_per_bin"])
+    out = np.zeros(len(tg) + 4, dtype=np.uint32)
+    k = emu.emu_create_powers_set(p["ps_low_degree"], p["max_items_per_bin"], C.c_void_p(out.ctypes.data), len(out))
+    assert [int(x) for x in out[:k]] == tg
+    depth, nodes = ref.powers_dag(p["query_powers"], tg)
+    s = np.array(sorted(p["query_powers"]), dtype=np.uint32)
+    t = np.array(tg, dtype=np.uint32)
+    nd = np.zeros((len(tg), 4), dtype=np.uint32)
+    d = emu.emu_powers_dag(C.c_void_p(s.ctypes.data), len(s), C.c_void_p(t.ctypes.data), len(t), C.c_void_p(nd.ctypes.data))
+    assert d == depth and [tuple(int(x) for x in r) for r in nd] == nodes
+    # SURVEY App. A statistics
+    stats = {"100K-1": (20, 0), "1M-1024-com": (25, 1), "16M-4096": (72, 3), "256M-4096": (322, 3)}[name]
+    assert (len(tg), depth) == stats
+
+
+def test_powers_dag_rejects_bad_sets(emu):
+    bad = [([2, 3], [1, 2, 3]), ([0, 1], [0, 1, 2]), ([1, 5], [1, 2, 3])]
+    for src, tgt in bad:
+        s, t = np.array(src, dtype=np.uint32), np.array(tgt, dtype=np.uint32)
+        nd = np.zeros((len(tgt), 4), dtype=np.uint32)
+        assert emu.emu_powers_dag(C.c_void_p(s.ctypes.data), len(s), C.c_void_p(t.ctypes.data), len(t),
+                                  C.c_void_p(nd.ctypes.data)) == -1
+        with pytest.raises(ValueError):
+            ref.powers_dag(src, tgt)
+
+
+def test_psu_params_validation_mirrors_reference(emu):
+    """psu_params.cpp:95-180: each broken field raises invalid_argument (-1), malformed JSON runtime_error (-2)"""
+    base = json.loads(common.param_json("16M-4096"))
+    out = np.zeros(64, dtype=np.uint64)
+
+    def rc(j):
+        return emu.emu_params_info(json.dumps(j).encode(), out.ctypes.data_as(u64p), 64)
+
+    assert rc(base) > 0
+    for path, val in [(("table_params", "table_size"), 0), (("table_params", "max_items_per_bin"), 0),
+                      (("table_params", "hash_func_count"), 9), (("item_params", "felts_per_item"), 1),
+                      (("query_params", "ps_low_degree"), 5000), (("table_params", "table_size"), 6553),
+                      (("query_params", "query_powers"), [1, 46]), (("query_params", "query_powers"), [0, 1])]:
+        j = json.loads(json.dumps(base))
+        j[path[0]][path[1]] = val
+        assert rc(j) == -1, (path, val)
+    j = json.loads(json.dumps(base))
+    j["seal_params"]["plain_modulus_bits"] = 12           # no 12-bit prime = 1 mod 2n: logic_error like SEAL's get_primes
+    assert rc(j) == -2
+    j = json.loads(json.dumps(base))
+    j["seal_params"]["plain_modulus"] = 65537
+    assert rc(j) == -2                                    # both plain_modulus and plain_modulus_bits
+    j = json.loads(json.dumps(base))
+    del j["seal_params"]["plain_modulus_bits"]
+    assert rc(j) == -2                                    # neither
+    assert emu.emu_params_info(b"{not json", out.ctypes.data_as(u64p), 64) == -2
+    j = json.loads(json.dumps(base))
+    del j["query_params"]
+    assert rc(j) == -2
+
+
+@pytest.mark.parametrize("n,bits", [(64, 40), (256, 50), (1024, 56), (2048, 48), (4096, 36), (8192, 56), (8192, 60)])
+def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
+    """the kernel's pass functions (ntt_core.h), stepped on the CPU, equal the oracle's NTT bit for bit"""
+    logn = n.bit_length() - 1
+    c = ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20)
+    q = c.q[0]
+    for seed, T in ((5, 64), (6, 512)):
+        x = ref.fill_uniform(seed, q, n)
+        x[:4] = [0, q - 1, 1, q - 2]                      # range edges
+        a = x.copy()
+        assert emu.emu_ntt_limb(logn, 0, C.c_uint64(q), a.ctypes.data_as(u64p), T) == 0, emu.emu_last_error()
+        e = x.copy().reshape(1, 1, n)
+        c.transform_to_ntt(e, 0)
+        assert (a == e.reshape(-1)).all()
+        assert emu.emu_ntt_limb(logn, 1, C.c_uint64(q), a.ctypes.data_as(u64p), T) == 0
+        assert (a == x).all()
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """the shared library loads and exports exactly the functions include/apsu_he.h declares"""
+    import apsu_amd
+    hdr = open(os.path.join(ROOT, "include", "apsu_he.h")).read()
+    declared = set(re.findall(r"\b(apsu_he_[a-z_0-9]+)\s*\(", hdr))
+    lib = apsu_amd.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export " + name
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", apsu_amd.lib_path()]).decode()
+    exported = set(re.findall(r" T (apsu_he_[a-z_0-9]+)", nm))
+    assert exported == declared
+    assert lib.apsu_he_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """without a HIP device context creation must fail loudly (APSU_HE_NO_DEVICE), never fall back"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import apsu_amd
+    with pytest.raises(apsu_amd.ApsuHeError) as ei:
+        apsu_amd.HeContext(common.param_json("100K-1"))
+    assert "no HIP device" in str(ei.value)
+
+
+def test_product_does_not_reference_oracle():
+    """the product path must not import, include, link or call anything under oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "apsu_amd")):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                continue
+            for line in open(os.path.join(dirpath, f), errors="replace"):
+                low = line.lower()
+                if "oracle" in low:
+                    assert not re.search(r"^\s*(import|from|#include)|cdll|dlopen|-lapsu_he_ref", low), (f, line)
+    ldd = subprocess.check_output(["ldd", os.path.join(ROOT, "apsu_amd", "libapsu_he_gpu.so")]).decode()
+    assert "apsu_he_ref" not in ldd
