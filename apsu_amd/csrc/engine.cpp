@@ -78,6 +78,9 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].q = hp_.ntt[m].mod.value;
             tabs[m].ninv = hp_.ntt[m].ninv;
             tabs[m].ninv_q = hp_.ntt[m].ninv_q;
+            tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
+            tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
+            tabs[m].pad = 0;
             tabs[m].fwd = base + ((size_t)m * 2 + 0) * n;
             tabs[m].inv = base + ((size_t)m * 2 + 1) * n;
         }

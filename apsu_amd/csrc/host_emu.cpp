@@ -3,6 +3,7 @@
 // the workgroup's threads stepped sequentially between barriers, so the index algebra, twiddle
 // addressing, LDS padding and lazy ranges are checked on the CPU.  This is NOT a fallback path:
 // it is not reachable from the C ABI and is only loaded by tests.
+#define APSU_HOST_EMU 1
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -14,24 +15,29 @@
 
 using namespace apsu_he;
 
-template <int LOGN, bool INV, int PASS> static void emu_pass(u64 *lds, int T, const NttTable &tab)
+template <int LOGN, bool INV, bool NARROW, int PASS> static void emu_pass(u64 *lds, u64 *glob, int T, const NttTable &tab)
 {
     if constexpr (PASS < plan_passes(LOGN)) {
-        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, PASS>(lds, tid, T, tab);
-        emu_pass<LOGN, INV, PASS + 1>(lds, T, tab);
+        // in-place global reads/writes of a pass touch disjoint 16-coefficient sets per work item, so
+        // stepping the threads sequentially is equivalent to the barrier-separated parallel execution
+        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, NARROW, PASS>(lds, glob, tid, T, tab);
+        emu_pass<LOGN, INV, NARROW, PASS + 1>(lds, glob, T, tab);
     }
+}
+
+template <int LOGN, bool INV, bool NARROW> static void emu_ntt_n(u64 *data, const NttTable &tab, int T)
+{
+    constexpr int N = 1 << LOGN;
+    std::vector<u64> lds(lds_slots(N));
+    if (INV) for (int e = 0; e < N; e++) lds[lds_slot(e)] = data[e];
+    emu_pass<LOGN, INV, NARROW, 0>(lds.data(), data, T, tab);
+    if (!INV) for (int e = 0; e < N; e++) data[e] = ntt_fwd_finish<NARROW>(lds[lds_slot(e)], tab);
 }
 
 template <int LOGN, bool INV> static void emu_ntt(u64 *data, const NttTable &tab, int T)
 {
-    constexpr int N = 1 << LOGN;
-    std::vector<u64> lds(lds_slots(N));
-    for (int e = 0; e < N; e++) lds[lds_slot(e)] = data[e];
-    emu_pass<LOGN, INV, 0>(lds.data(), T, tab);
-    for (int e = 0; e < N; e++) {
-        u64 x = lds[lds_slot(e)];
-        data[e] = INV ? ntt_inv_finish(x, tab) : ntt_fwd_finish(x, tab.q);
-    }
+    if (tab.narrow) emu_ntt_n<LOGN, INV, true>(data, tab, T);
+    else emu_ntt_n<LOGN, INV, false>(data, tab, T);
 }
 
 static thread_local std::string g_err;
@@ -51,7 +57,7 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
         const NttTablesHost &t = hp.ntt[0];
         std::vector<TwPair> fwd(n), inv(n);
         for (size_t k = 0; k < n; k++) { fwd[k] = { t.fwd[k], t.fwd_q[k] }; inv[k] = { t.inv[k], t.inv_q[k] }; }
-        NttTable tab{ q, t.ninv, t.ninv_q, fwd.data(), inv.data() };
+        NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), inv.data(), ntt_is_narrow(q, logn) ? 1 : 0, 0 };
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
         switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE

@@ -17,37 +17,43 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
+template <int LOGN, bool INV, bool NARROW, int T>
+__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid)
+{
+    constexpr int N = 1 << LOGN;
+    constexpr int P = plan_passes(LOGN);
+    if (INV) {                                   // stage the limb in LDS: the first inverse pass reads 16 contiguous coefficients per lane
+        for (int e = 2 * tid; e < N; e += 2 * T)
+            *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = *reinterpret_cast<const u64x2 *>(p + e);
+        __syncthreads();
+    }
+    ntt_pass<LOGN, INV, NARROW, 0>(lds, p, tid, T, tab);
+    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 1>(lds, p, tid, T, tab); }
+    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 2>(lds, p, tid, T, tab); }
+    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 3>(lds, p, tid, T, tab); }
+    if (!INV) {                                  // forward: the last pass left 16 contiguous coefficients per lane in LDS
+        __syncthreads();
+        for (int e = 2 * tid; e < N; e += 2 * T) {
+            u64x2 v = *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
+            v[0] = ntt_fwd_finish<NARROW>(v[0], tab);
+            v[1] = ntt_fwd_finish<NARROW>(v[1], tab);
+            *reinterpret_cast<u64x2 *>(p + e) = v;
+        }
+    }
+}
+
 template <int LOGN, bool INV, int T>
-__global__ __launch_bounds__(T) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
+__global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
                                            const int *__restrict__ modmap, int period)
 {
     constexpr int N = 1 << LOGN;
-    __shared__ u64 lds[lds_slots(N)];
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
     const int tid = threadIdx.x;
     const size_t g = blockIdx.x;
     const NttTable tab = tabs[modmap[g % (size_t)period]];
     u64 *p = data + g * N;
-
-    for (int e = 2 * tid; e < N; e += 2 * T) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p + e);
-        lds[lds_slot(e)] = v.x;
-        lds[lds_slot(e + 1)] = v.y;
-    }
-    __syncthreads();
-    constexpr int P = plan_passes(LOGN);
-    ntt_pass<LOGN, INV, 0>(lds, tid, T, tab);
-    __syncthreads();
-    if constexpr (P > 1) { ntt_pass<LOGN, INV, 1>(lds, tid, T, tab); __syncthreads(); }
-    if constexpr (P > 2) { ntt_pass<LOGN, INV, 2>(lds, tid, T, tab); __syncthreads(); }
-    if constexpr (P > 3) { ntt_pass<LOGN, INV, 3>(lds, tid, T, tab); __syncthreads(); }
-    for (int e = 2 * tid; e < N; e += 2 * T) {
-        ulonglong2 v;
-        v.x = lds[lds_slot(e)];
-        v.y = lds[lds_slot(e + 1)];
-        if (INV) { v.x = ntt_inv_finish(v.x, tab); v.y = ntt_inv_finish(v.y, tab); }
-        else { v.x = ntt_fwd_finish(v.x, tab.q); v.y = ntt_fwd_finish(v.y, tab.q); }
-        *reinterpret_cast<ulonglong2 *>(p + e) = v;
-    }
+    if (tab.narrow) ntt_body<LOGN, INV, true, T>(lds, p, tab, tid);       // wave-uniform branch
+    else ntt_body<LOGN, INV, false, T>(lds, p, tab, tid);
 }
 
 template <int LOGN, int T>
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(EW_T) void k_copy_jobs(const CtJob *__restrict__ jo
 {
     const CtJob job = jobs[blockIdx.y];
     for (size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2; k < words; k += (size_t)gridDim.x * EW_T * 2)
-        *reinterpret_cast<ulonglong2 *>(job.dst + k) = *reinterpret_cast<const ulonglong2 *>(job.src + k);
+        *reinterpret_cast<u64x2 *>(job.dst + k) = *reinterpret_cast<const u64x2 *>(job.src + k);
 }
 
 void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st)

@@ -16,6 +16,14 @@
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// 16-byte pair of coefficients for 128-bit global / LDS accesses.  may_alias: the pair is always a
+// view of two adjacent u64 array elements (no strict-aliasing assumptions for the compiler to exploit).
+#if defined(__clang__)
+typedef u64 u64x2 __attribute__((ext_vector_type(2), __may_alias__));
+#else
+typedef u64 u64x2 __attribute__((vector_size(16), __may_alias__));
+#endif
+
 struct u128p { u64 lo, hi; };   // 128-bit value as a pair
 
 HD u64 mulhi64(u64 a, u64 b)

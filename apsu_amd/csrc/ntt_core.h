@@ -9,9 +9,20 @@
 //             psi = minimal primitive 2n-th root;   inverse = exact inverse incl. n^-1.
 //
 // Structure: one workgroup owns one limb polynomial (n <= 8192 coefficients = 64 KiB of the CU's
-// 160 KiB LDS).  The log2(n) butterfly stages are grouped into register-resident passes of K
-// stages (radix 2^K); between passes the data is exchanged through LDS.  Butterflies are Harvey
-// lazy butterflies: forward values live in [0,4q), inverse values in [0,2q).
+// 160 KiB LDS).  Every thread keeps 16 coefficients in registers per pass: a pass covers K
+// consecutive butterfly stages (radix 2^K) on 16 >> K independent groups (adjacent columns, so one
+// twiddle load feeds all groups and global / LDS accesses are 16 B per lane).  Between passes data
+// is exchanged through LDS; the first forward pass reads straight from global memory and the last
+// inverse pass writes straight to it.
+//
+// Arithmetic (q < 2^61): Shoup multiplication with an APPROXIMATE high product (three 32x32
+// products instead of four; quotient under-estimated by <= 2), so a lazy product lies in [0,4q).
+//   narrow moduli ((4*log2(n)+1)*q < 2^64, e.g. the 48..58-bit coefficient primes): the forward
+//     transform needs NO conditional subtraction at all (values grow by < 4q per stage) and ends with
+//     one Barrett reduction per coefficient;
+//   wide moduli (the 61-bit BEHZ primes): values live in [0,8q), one conditional subtraction per
+//     butterfly;  inverse (any modulus): values in [0,4q), one conditional subtraction per butterfly.
+// All of this is invisible in the results: outputs are canonical residues.
 // The pass functions are __host__ __device__ so tests can emulate a workgroup on the CPU.
 #pragma once
 #include "modmath.h"
@@ -22,89 +33,195 @@ struct TwPair { u64 w, wq; };          // twiddle and its Shoup quotient, 16 B -
 struct NttTable {
     u64 q;
     u64 ninv, ninv_q;                  // n^-1 mod q and its Shoup quotient
+    u64 r1;                            // floor(2^64 / q): single-word Barrett ratio
     const TwPair *fwd;
     const TwPair *inv;
+    int narrow;                        // (4*logn+1)*q < 2^64
+    int pad;
 };
 
-// LDS padding: one 8-byte slot per 16 elements, so that the last pass (16 contiguous
-// coefficients per lane, lane stride 128 B) is bank-conflict free for ds_read/write_b64.
-HD int lds_slot(int e) { return e + (e >> 4); }
-constexpr int lds_slots(int n) { return n + (n >> 4); }
+HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
 
-// One forward (Cooley-Tukey) pass over stages s .. s+K-1 for work item w in [0, n >> K).
-template <int LOGN, int K>
-HD void ntt_fwd_pass(u64 *lds, int w, int s, const TwPair *__restrict__ W, u64 q)
+// LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
+// makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).
+HD int lds_slot(int e) { return e + ((e >> 4) << 1); }
+constexpr int lds_slots(int n) { return n + (n >> 3); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define UNIFORM_INT(x) (x)
+#endif
+
+// x * w mod q, lazy in [0,4q), for any 64-bit x.  nq = 2^64 - q.
+HD u64 mul_lazy4(u64 x, u64 w, u64 wq, u64 nq)
 {
-    constexpr int R = 1 << K;
-    const int lowbits = LOGN - s - K;
-    const int block = w >> lowbits;
-    const int col = w & ((1 << lowbits) - 1);
-    const int base = (block << (LOGN - s)) | col;
-    const u64 q2 = q << 1;
-    u64 r[R];
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u64 t1 = (u64)x1 * a0, t2 = (u64)x0 * a1;
+    const u64 h = (u64)x1 * a1 + (t1 >> 32) + (t2 >> 32);          // floor(x*wq / 2^64) - {0,1,2}
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    const u64 lo = (u64)x0 * w0 + (u64)h0 * n0;
+    const u64 mid = (u64)x0 * w1 + (u64)x1 * w0 + (u64)h0 * n1 + (u64)h1 * n0;
+    return lo + (mid << 32);                                       // x*w - h*q  (mod 2^64)
+}
+
+enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
+
+// One pass over stages S .. S+K-1 for work item w in [0, n/16).
+//   forward: Cooley-Tukey, stages ascending; inverse: Gentleman-Sande, stages descending.
+//   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
+template <int LOGN, int S, int K, bool INV, bool NARROW, int IN, int OUT>
+HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
+{
+    constexpr int R = 1 << K;                  // radix
+    constexpr int G = 16 >> K;                 // independent groups per thread
+    constexpr int LOWBITS = LOGN - S - K;      // bits of the column index
+    constexpr bool COLS = (1 << LOWBITS) >= G; // groups = adjacent columns (else adjacent blocks)
+    constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;      // column groups per block
+    constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);      // every lane of a wave shares the twiddles
+    const TwPair *__restrict__ W = INV ? tab.inv : tab.fwd;
+    const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2;
+
+    int block, c0;
+    if (COLS) { block = w / CG; c0 = (w % CG) * G; }
+    else { block = w * G; c0 = 0; }
+    // element index of group g, row j
+    auto idx = [&](int g, int j) -> int {
+        return COLS ? ((block << (LOGN - S)) | (j << LOWBITS) | (c0 + g)) : (((block + g) << K) | j);
+    };
+
+    // access modes: PAIR_G = adjacent columns (g, g+1) form a 16-byte pair; PAIR_J = the 16 coefficients
+    // are contiguous so rows (j, j+1) pair up; otherwise single 8-byte accesses.
+    constexpr bool PAIR_G = COLS && G >= 2;
+    constexpr bool PAIR_J = !PAIR_G && LOWBITS == 0;
+    u64 r[G][R];
+    if (PAIR_G) {
 #pragma unroll
-    for (int j = 0; j < R; j++) r[j] = lds[lds_slot(base | (j << lowbits))];
+        for (int j = 0; j < R; j++)
 #pragma unroll
-    for (int u = 0; u < K; u++) {
+            for (int g = 0; g < G; g += 2) {
+                const int e = idx(g, j);
+                const u64x2 v = (IN == IO_GLOBAL) ? *reinterpret_cast<const u64x2 *>(glob + e)
+                                                   : *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
+                r[g][j] = v[0]; r[g + 1][j] = v[1];
+            }
+    } else if (PAIR_J) {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j += 2) {
+                const int e = idx(g, j);
+                const u64x2 v = (IN == IO_GLOBAL) ? *reinterpret_cast<const u64x2 *>(glob + e)
+                                                   : *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
+                r[g][j] = v[0]; r[g][j + 1] = v[1];
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int e = idx(g, j);
+                r[g][j] = (IN == IO_GLOBAL) ? glob[e] : lds[lds_slot(e)];
+            }
+    }
+
+#pragma unroll
+    for (int uu = 0; uu < K; uu++) {
+        const int u = INV ? K - 1 - uu : uu;
         const int bit = 1 << (K - 1 - u);
-        const int tw_base = (1 << (s + u)) + (block << u);
 #pragma unroll
         for (int j = 0; j < R; j++) {
             if (j & bit) continue;
-            const TwPair t = W[tw_base + (j >> (K - u))];
-            u64 x = csub(r[j], q2);
-            u64 v = mul_shoup_lazy(r[j | bit], t.w, t.wq, q);
-            r[j] = x + v;
-            r[j | bit] = x - v + q2;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (COLS && g > 0) continue;   // column groups share the twiddle: handled below
+                int ti = (1 << (S + u)) + (((COLS ? block : block + g)) << u) + (j >> (K - u));
+                if (UNIFORM_TW) ti = UNIFORM_INT(ti);
+                const TwPair t = W[ti];
+#pragma unroll
+                for (int gg = 0; gg < G; gg++) {
+                    if (!COLS && gg != g) continue;
+                    u64 &x = r[gg][j], &y = r[gg][j | bit];
+                    if (!INV) {
+                        const u64 v = mul_lazy4(y, t.w, t.wq, nq);
+                        const u64 a = NARROW ? x : csub(x, q4);
+                        x = a + v;
+                        y = a - v + q4;
+                    } else {
+                        const u64 a = x, b = y;
+                        x = csub(a + b, q4);
+                        y = mul_lazy4(a - b + q4, t.w, t.wq, nq);
+                    }
+                }
+            }
         }
     }
+
+    if (OUT == IO_GLOBAL) {                    // leaving the transform: canonical residues
 #pragma unroll
-    for (int j = 0; j < R; j++) lds[lds_slot(base | (j << lowbits))] = r[j];
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                u64 v = r[g][j];
+                if (INV) v = mul_shoup(v, tab.ninv, tab.ninv_q, q);
+                else if (NARROW) { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }
+                else v = csub(csub(csub(v, q4), q << 1), q);
+                r[g][j] = v;
+            }
+    }
+    if (PAIR_G) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+            for (int g = 0; g < G; g += 2) {
+                const int e = idx(g, j);
+                u64x2 v; v[0] = r[g][j]; v[1] = r[g + 1][j];
+                if (OUT == IO_GLOBAL) *reinterpret_cast<u64x2 *>(glob + e) = v;
+                else *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = v;
+            }
+    } else if (PAIR_J) {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j += 2) {
+                const int e = idx(g, j);
+                u64x2 v; v[0] = r[g][j]; v[1] = r[g][j + 1];
+                if (OUT == IO_GLOBAL) *reinterpret_cast<u64x2 *>(glob + e) = v;
+                else *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = v;
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int e = idx(g, j);
+                if (OUT == IO_GLOBAL) glob[e] = r[g][j];
+                else lds[lds_slot(e)] = r[g][j];
+            }
+    }
 }
 
-// One inverse (Gentleman-Sande) pass over stages s+K-1 .. s (same index algebra, reverse order).
-template <int LOGN, int K>
-HD void ntt_inv_pass(u64 *lds, int w, int s, const TwPair *__restrict__ W, u64 q)
+// Final range fix-up when the last pass leaves its result in LDS (forward transform).
+template <bool NARROW>
+HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 {
-    constexpr int R = 1 << K;
-    const int lowbits = LOGN - s - K;
-    const int block = w >> lowbits;
-    const int col = w & ((1 << lowbits) - 1);
-    const int base = (block << (LOGN - s)) | col;
-    const u64 q2 = q << 1;
-    u64 r[R];
-#pragma unroll
-    for (int j = 0; j < R; j++) r[j] = lds[lds_slot(base | (j << lowbits))];
-#pragma unroll
-    for (int u = K - 1; u >= 0; u--) {
-        const int bit = 1 << (K - 1 - u);
-        const int tw_base = (1 << (s + u)) + (block << u);
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            if (j & bit) continue;
-            const TwPair t = W[tw_base + (j >> (K - u))];
-            u64 x = r[j], y = r[j | bit];
-            r[j] = csub(x + y, q2);
-            r[j | bit] = mul_shoup_lazy(x - y + q2, t.w, t.wq, q);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < R; j++) lds[lds_slot(base | (j << lowbits))] = r[j];
+    if (NARROW) { v = v - mulhi64(v, tab.r1) * tab.q; return csub(v, tab.q); }
+    return csub(csub(csub(v, tab.q << 2), tab.q << 1), tab.q);
 }
 
-// Pass schedule: stage counts per pass (summing to LOGN), resolved at compile time.
+// ---- pass schedule (stage counts per pass, summing to LOGN), resolved at compile time ----
 constexpr int plan_passes(int logn)
 {
-    return logn == 13 ? 4 : logn == 12 ? 3 : logn == 11 ? 3 : logn == 10 ? 3 : logn == 8 ? 2 : logn == 6 ? 2 : 0;
+    return logn == 13 ? 4 : logn == 12 ? 4 : logn == 11 ? 4 : logn == 10 ? 3 : logn == 8 ? 3 : logn == 6 ? 2 : 0;
 }
 constexpr int plan_k(int logn, int p)
 {
     switch (logn) {
     case 13: return p == 3 ? 4 : 3;               // 3,3,3,4
-    case 12: return 4;                            // 4,4,4
-    case 11: return p == 2 ? 3 : 4;               // 4,4,3
-    case 10: return p == 0 ? 4 : 3;               // 4,3,3   (parity tests only)
-    case 8:  return 4;                            // 4,4     (parity tests only)
+    case 12: return 3;                            // 3,3,3,3
+    case 11: return p == 3 ? 2 : 3;               // 3,3,3,2
+    case 10: return p == 2 ? 4 : 3;               // 3,3,4   (parity tests only)
+    case 8:  return p == 2 ? 2 : 3;               // 3,3,2   (parity tests only)
     case 6:  return 3;                            // 3,3     (parity tests only)
     default: return 0;
     }
@@ -115,28 +232,20 @@ constexpr int plan_s(int logn, int p)
     for (int i = 0; i < p; i++) s += plan_k(logn, i);
     return s;
 }
-constexpr int plan_max_k(int logn)
-{
-    int m = 0;
-    for (int i = 0; i < plan_passes(logn); i++) m = plan_k(logn, i) > m ? plan_k(logn, i) : m;
-    return m;
-}
 
 // Executes pass number PASS (in execution order) for "thread" tid of a T-thread workgroup.
 // The caller separates passes with __syncthreads() (device) or by looping tid (host emulation).
-template <int LOGN, bool INV, int PASS>
-HD void ntt_pass(u64 *lds, int tid, int T, const NttTable &tab)
+//   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
+//            then stores it coalesced);   inverse: pass 0 reads LDS (caller staged the limb there),
+//            the last pass writes the scaled result straight to global memory.
+template <int LOGN, bool INV, bool NARROW, int PASS>
+HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
 {
     constexpr int P = plan_passes(LOGN);
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
     constexpr int K = plan_k(LOGN, p);
     constexpr int S = plan_s(LOGN, p);
-    for (int w = tid; w < (1 << (LOGN - K)); w += T) {
-        if (INV) ntt_inv_pass<LOGN, K>(lds, w, S, tab.inv, tab.q);
-        else ntt_fwd_pass<LOGN, K>(lds, w, S, tab.fwd, tab.q);
-    }
+    constexpr int IN = (!INV && PASS == 0) ? IO_GLOBAL : IO_LDS;
+    constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, NARROW, IN, OUT>(lds, glob, w, tab);
 }
-
-// Final range fix-ups applied when the limb leaves LDS.
-HD u64 ntt_fwd_finish(u64 x, u64 q) { return csub(csub(x, q << 1), q); }            // [0,4q) -> [0,q)
-HD u64 ntt_inv_finish(u64 x, const NttTable &t) { return mul_shoup(x, t.ninv, t.ninv_q, t.q); }

@@ -152,7 +152,8 @@ def test_psu_params_validation_mirrors_reference(emu):
     assert rc(j) == -2
 
 
-@pytest.mark.parametrize("n,bits", [(64, 40), (256, 50), (1024, 56), (2048, 48), (4096, 36), (8192, 56), (8192, 60)])
+@pytest.mark.parametrize("n,bits", [(64, 40), (64, 60), (256, 50), (256, 60), (1024, 56), (1024, 60), (2048, 48), (2048, 60),
+                                    (4096, 36), (4096, 60), (8192, 56), (8192, 58), (8192, 60)])
 def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
     """the kernel's pass functions (ntt_core.h), stepped on the CPU, equal the oracle's NTT bit for bit"""
     logn = n.bit_length() - 1
