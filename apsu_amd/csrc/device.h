@@ -58,13 +58,15 @@ struct DevKey {
     ShoupConst inv_p[DMAXL];
 };
 
-// Generic multiply-accumulate job: out[2][L][n] = sum_{j<cnt} PW_j (.) PT_j   (NTT domain).
+// Multiply-accumulate job: for g < ng:  out[g][2][L][n] = sum_{j<cnt} PW_j (.) PT_{g,j}   (NTT domain).
+// All streams of a job share the ciphertext powers PW (same bundle index) and the term count.
+constexpr int MAC_G = 4;
 struct MacJob {
-    const u64 *pt;        // first plaintext; term j at pt + j*pt_stride ; limb l at + l*n
+    const u64 *pt[MAC_G]; // first plaintext of stream g; term j at + j*pt_stride ; limb l at + l*n
+    u64 *out[MAC_G];      // [2][L][n]
     const u64 *pw;        // first ciphertext; term j at pw + j*pw_stride ; poly p at + p*pw_poly_stride
-    u64 *out;             // [2][L][n]
-    u32 cnt;
-    u32 pt_stride, pw_stride, pw_poly_stride;   // in u64 words
+    u32 cnt, ng;
+    u32 pt_stride, pw_stride, pw_poly_stride, pad;   // in u64 words
 };
 
 // ---- launch wrappers (all asynchronous on `st`) --------------------------------------------

@@ -259,7 +259,39 @@ struct ProfScope {
     ~ProfScope() { e->prof_end(); }
 };
 #define PROF(kind, units) ProfScope prof_scope_(this, kind, units)
-static uint64_t mac_units(const std::vector<MacJob> &mj, size_t L) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * L; return u; }
+static uint64_t mac_units(const std::vector<MacJob> &mj, size_t L) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * L; return u; }
+
+// single-stream description of a multiply-accumulate; group_mac() packs streams that share the
+// ciphertext powers and the term count into MacJobs of up to MAC_G streams
+struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride; };
+static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
+{
+    std::vector<MacJob> jobs;
+    std::vector<char> used(ss.size(), 0);
+    // streams are generated bundle-major; match each unused stream with later ones of equal key
+    std::vector<size_t> order(ss.size());
+    for (size_t i = 0; i < ss.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        if (ss[a].pw != ss[b].pw) return ss[a].pw < ss[b].pw;
+        return ss[a].cnt < ss[b].cnt;
+    });
+    for (size_t x = 0; x < order.size();) {
+        const MacStream &f = ss[order[x]];
+        MacJob j{};
+        j.pw = f.pw; j.cnt = f.cnt; j.pt_stride = f.pt_stride; j.pw_stride = f.pw_stride; j.pw_poly_stride = f.pw_poly_stride;
+        u32 g = 0;
+        while (x < order.size() && g < (u32)MAC_G) {
+            const MacStream &s = ss[order[x]];
+            if (s.pw != f.pw || s.cnt != f.cnt || s.pt_stride != f.pt_stride || s.pw_stride != f.pw_stride ||
+                s.pw_poly_stride != f.pw_poly_stride) break;
+            j.pt[g] = s.pt; j.out[g] = s.out; g++; x++;
+        }
+        j.ng = g;
+        for (u32 r = g; r < (u32)MAC_G; r++) { j.pt[r] = j.pt[0]; j.out[r] = j.out[0]; }
+        jobs.push_back(j);
+    }
+    return jobs;
+}
 
 void Engine::check_level(int chain_idx) const
 {
@@ -908,18 +940,18 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 const int lvl = low;                                   // level of powers[1]
                 const size_t Lv = lvl + 1;
                 u64 *acc = ws((size_t)Bp * 2 * Lv * n);
-                std::vector<MacJob> mj;
+                std::vector<MacStream> ms;
                 std::vector<PlainJob> pj;
                 for (int x = 0; x < Bp; x++) {
                     const Bundle &b = *bundles[c0 + pl_ids[x]];
                     u64 *o = acc + (size_t)x * 2 * Lv * n;
-                    if (b.degree) mj.push_back(MacJob{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
+                    if (b.degree) ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
                                                        (u32)(Lv * n), low_term_stride, (u32)(Ll * n) });   // :140-149
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
                     pj.push_back(PlainJob{ o, b.a0.u() });                                               // :159
                 }
                 for (int x = 0; x < Bp; x++) pj.push_back(PlainJob{ acc + (size_t)x * 2 * Lv * n, mask_ptr(pl_ids[x]) });   // :162
-                { PROF(P_MAC, mac_units(mj, Lv)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lv)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
                 const PlainJob *pjd = upload_jobs(pj);
                 { PROF(P_OTHER, 0); launch_add_plain(dlevel(lvl), pjd, n, Bp, st_); }
@@ -948,18 +980,18 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     NI += nin[x];
                 }
                 u64 *inner = ws((size_t)NI * 2 * Ll * n);
-                std::vector<MacJob> mj;
+                std::vector<MacStream> ms;
                 for (int x = 0; x < Bs; x++) {
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
                     for (int i = 1; i <= nin[x]; i++) {
                         const u32 cnt = (u32)i < b.H ? l : b.r;
-                        mj.push_back(MacJob{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
+                        ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
                                              inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
                                              (u32)(Ll * n), low_term_stride, (u32)(Ll * n) });             // :258-264
                     }
                 }
-                { PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(inner, (size_t)NI * 2, low, true);                                                 // :268,297
                 u64 *innerh = inner;
                 for (int lv = low; lv > high; lv--) {                                                       // :269,298
@@ -990,16 +1022,16 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
 
                 // i = 0 block: every term is rounded on its own before the sum (note N1)            :314-324
                 u64 *term = ws((size_t)Bs * l * 2 * Ll * n);
-                mj.clear();
+                ms.clear();
                 for (int x = 0; x < Bs; x++) {
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
                     for (u32 j = 1; j <= l; j++)
-                        mj.push_back(MacJob{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                        ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
                                              term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
                                              (u32)(Ll * n) });
                 }
-                { PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
                 u64 *termh = term;
                 for (int lv = low; lv > high; lv--) {
@@ -1012,14 +1044,14 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 // coefficient-form plaintexts a_{i*h} times the high powers (:328-337): exact, so the
                 // products are summed in the NTT domain and transformed back once
                 u64 *cf = ws((size_t)Bs * 2 * Lh * n);
-                mj.clear();
+                ms.clear();
                 for (int x = 0; x < Bs; x++) {
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
-                    mj.push_back(MacJob{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
+                    ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
                                          (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n) });
                 }
-                { PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(cf, (size_t)Bs * 2, high, true);
                 { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, cf, 1, 2, n, Bs, st_); }
 

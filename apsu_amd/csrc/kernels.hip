@@ -568,39 +568,67 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 
 // ============================================================================ K3: dyadic multiply-accumulate
 // The inner loops of BatchedPlaintextPolyn::eval / eval_patstock
-// (bin_bundle.cpp:140-149, 250-265, 279-294): out = sum_j C^j (.) a_j in the NTT domain.
-// 128-bit lazy accumulation, one Barrett reduction per output coefficient.  Streams the
-// HBM-resident plaintexts once; the ciphertext powers are re-read from L2 / Infinity Cache.
+// (bin_bundle.cpp:140-149, 250-265, 279-294, 314-324, 328-337): out_g = sum_j C^j (.) a_{g,j} in the NTT
+// domain for up to MAC_G plaintext streams that share the same ciphertext powers (the inner
+// polynomials of the BinBundles of one bundle index).  Each lane owns two adjacent coefficients
+// (16-byte loads), keeps 128-bit lazy accumulators and does one Barrett reduction per output.
+// The HBM-resident plaintexts are streamed exactly once; every power load is shared by MAC_G streams.
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
-    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2;
     if (k >= n) return;
     const MacJob job = jobs[blockIdx.z];
     const int j = blockIdx.y;                                  // limb
+    const int L = lv->L;
     const Mod m = lv->q[j];
-    const u64 *pt = job.pt + (size_t)j * n + k;
     const u64 *p0 = job.pw + (size_t)j * n + k;
     const u64 *p1 = p0 + job.pw_poly_stride;
-    u128p a0{ 0, 0 }, a1{ 0, 0 };
-    // lazy budget: products < 2^(2*bits(q)); reduce every `chunk` terms so the sum stays < 2^128
+    const u64 *pt[MAC_G];
+    u128p a0[MAC_G][2], a1[MAC_G][2];
+#pragma unroll
+    for (int g = 0; g < MAC_G; g++) {
+        pt[g] = job.pt[g < job.ng ? g : 0] + (size_t)j * n + k;
+        a0[g][0] = a0[g][1] = a1[g][0] = a1[g][1] = u128p{ 0, 0 };
+    }
     for (u32 i = 0; i < job.cnt; i++) {
-        const u64 a = pt[(size_t)i * job.pt_stride];
-        mac128(a0, a, p0[(size_t)i * job.pw_stride]);
-        mac128(a1, a, p1[(size_t)i * job.pw_stride]);
-        if ((i & 31) == 31) {                                  // q < 2^61: 32 products < 2^127
-            a0 = u128p{ barrett128(a0, m), 0 };
-            a1 = u128p{ barrett128(a1, m), 0 };
+        const u64x2 c0 = *reinterpret_cast<const u64x2 *>(p0 + (size_t)i * job.pw_stride);
+        const u64x2 c1 = *reinterpret_cast<const u64x2 *>(p1 + (size_t)i * job.pw_stride);
+#pragma unroll
+        for (int g = 0; g < MAC_G; g++) {
+            if (g < job.ng) {
+                const u64x2 a = *reinterpret_cast<const u64x2 *>(pt[g] + (size_t)i * job.pt_stride);
+                mac128(a0[g][0], a[0], c0[0]);
+                mac128(a0[g][1], a[1], c0[1]);
+                mac128(a1[g][0], a[0], c1[0]);
+                mac128(a1[g][1], a[1], c1[1]);
+            }
+        }
+        if ((i & 31) == 31) {                                  // q < 2^61: 32 products + carry-in < 2^128
+#pragma unroll
+            for (int g = 0; g < MAC_G; g++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    a0[g][c] = u128p{ barrett128(a0[g][c], m), 0 };
+                    a1[g][c] = u128p{ barrett128(a1[g][c], m), 0 };
+                }
         }
     }
-    const int L = lv->L;
-    job.out[(size_t)j * n + k] = barrett128(a0, m);
-    job.out[((size_t)L + j) * n + k] = barrett128(a1, m);
+#pragma unroll
+    for (int g = 0; g < MAC_G; g++) {
+        if (g < job.ng) {
+            u64x2 r0, r1;
+            r0[0] = barrett128(a0[g][0], m); r0[1] = barrett128(a0[g][1], m);
+            r1[0] = barrett128(a1[g][0], m); r1[1] = barrett128(a1[g][1], m);
+            *reinterpret_cast<u64x2 *>(job.out[g] + (size_t)j * n + k) = r0;
+            *reinterpret_cast<u64x2 *>(job.out[g] + ((size_t)L + j) * n + k) = r1;
+        }
+    }
 }
 
 void launch_mac(const DevLevel *lv, int L, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
 {
     if (!njobs) return;
-    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n + EW_T - 1) / EW_T), (unsigned)L, (unsigned)njobs), dim3(EW_T), 0, st,
+    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)L, (unsigned)njobs), dim3(EW_T), 0, st,
                        lv, jobs, n);
     KERNEL_CHECK();
 }

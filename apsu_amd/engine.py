@@ -40,6 +40,30 @@ def lib_path():
     return os.path.join(_HERE, "libapsu_he_gpu.so")
 
 
+def _preload_shared_hip_runtime():
+    """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own libamdhip64
+    (same SONAME as /opt/rocm's); whichever is loaded first wins.  If this library came first, a later
+    `import torch` would bring a second runtime that sees no GPU ("No HIP GPUs are available"), and
+    device pointers could not be shared with torch tensors.  So when torch is installed but not yet
+    imported, load torch's copy first; the engine then binds to it through the SONAME."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Loads libapsu_he_gpu.so; raises (never falls back) if it has not been built."""
     global _LIB
@@ -49,6 +73,7 @@ def load_library():
             raise ApsuHeError(
                 "HIP extension %s is missing: build it with `make -C apsu_amd/csrc` "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+        _preload_shared_hip_runtime()
         _LIB = C.CDLL(path)
         _LIB.apsu_he_last_error.restype = C.c_char_p
     return _LIB
