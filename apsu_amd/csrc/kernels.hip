@@ -590,18 +590,27 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
         pt[g] = job.pt[g < job.ng ? g : 0] + (size_t)j * n + k;
         a0[g][0] = a0[g][1] = a1[g][0] = a1[g][1] = u128p{ 0, 0 };
     }
+    // streams beyond job.ng alias stream 0 (cache hits, results discarded): the loop body stays branch
+    // free so all six 16-byte loads of an iteration are in flight together, and the next iteration's
+    // loads are issued before this iteration's arithmetic (register double buffering).
+    u64x2 c0 = ldg16(p0);
+    u64x2 c1 = ldg16(p1);
+    u64x2 a[MAC_G];
+#pragma unroll
+    for (int g = 0; g < MAC_G; g++) a[g] = ldg16_nt(pt[g]);
     for (u32 i = 0; i < job.cnt; i++) {
-        const u64x2 c0 = *reinterpret_cast<const u64x2 *>(p0 + (size_t)i * job.pw_stride);
-        const u64x2 c1 = *reinterpret_cast<const u64x2 *>(p1 + (size_t)i * job.pw_stride);
+        const u32 nx = i + 1 < job.cnt ? i + 1 : i;
+        const u64x2 nc0 = ldg16(p0 + (size_t)nx * job.pw_stride);
+        const u64x2 nc1 = ldg16(p1 + (size_t)nx * job.pw_stride);
+        u64x2 na[MAC_G];
+#pragma unroll
+        for (int g = 0; g < MAC_G; g++) na[g] = ldg16_nt(pt[g] + (size_t)nx * job.pt_stride);
 #pragma unroll
         for (int g = 0; g < MAC_G; g++) {
-            if (g < job.ng) {
-                const u64x2 a = *reinterpret_cast<const u64x2 *>(pt[g] + (size_t)i * job.pt_stride);
-                mac128(a0[g][0], a[0], c0[0]);
-                mac128(a0[g][1], a[1], c0[1]);
-                mac128(a1[g][0], a[0], c1[0]);
-                mac128(a1[g][1], a[1], c1[1]);
-            }
+            mac128(a0[g][0], a[g][0], c0[0]);
+            mac128(a0[g][1], a[g][1], c0[1]);
+            mac128(a1[g][0], a[g][0], c1[0]);
+            mac128(a1[g][1], a[g][1], c1[1]);
         }
         if ((i & 31) == 31) {                                  // q < 2^61: 32 products + carry-in < 2^128
 #pragma unroll
@@ -612,6 +621,9 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
                     a1[g][c] = u128p{ barrett128(a1[g][c], m), 0 };
                 }
         }
+        c0 = nc0; c1 = nc1;
+#pragma unroll
+        for (int g = 0; g < MAC_G; g++) a[g] = na[g];
     }
 #pragma unroll
     for (int g = 0; g < MAC_G; g++) {

@@ -24,6 +24,25 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2), __may_alias__));
 typedef u64 u64x2 __attribute__((vector_size(16), __may_alias__));
 #endif
 
+// 16-byte loads that are known to hit global memory (pointers read from job descriptors lose their
+// address space and would otherwise compile to flat_load).  _nt = non-temporal (streamed-once data).
+HD u64x2 ldg16(const u64 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const u64x2 __attribute__((address_space(1))) *)(const void *)p;
+#else
+    return *reinterpret_cast<const u64x2 *>(p);
+#endif
+}
+HD u64x2 ldg16_nt(const u64 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load((const u64x2 __attribute__((address_space(1))) *)(const void *)p);
+#else
+    return *reinterpret_cast<const u64x2 *>(p);
+#endif
+}
+
 struct u128p { u64 lo, hi; };   // 128-bit value as a pair
 
 HD u64 mulhi64(u64 a, u64 b)

@@ -137,7 +137,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 if (COLS && g > 0) continue;   // column groups share the twiddle: handled below
                 int ti = (1 << (S + u)) + (((COLS ? block : block + g)) << u) + (j >> (K - u));
                 if (UNIFORM_TW) ti = UNIFORM_INT(ti);
-                const TwPair t = W[ti];
+                const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(W + ti));
+                const TwPair t{ tv[0], tv[1] };
 #pragma unroll
                 for (int gg = 0; gg < G; gg++) {
                     if (!COLS && gg != g) continue;
