@@ -13,7 +13,7 @@ using namespace apsu_he;
 struct apsu_he_ctx { std::unique_ptr<Engine> eng; };
 struct apsu_he_relin { std::unique_ptr<RelinKeys> rk; };
 struct apsu_he_bundle { std::unique_ptr<Bundle> b; };
-struct apsu_he_powers { std::unique_ptr<Powers> p; };
+struct apsu_he_powers { std::unique_ptr<Powers> p; Engine *eng = nullptr; };
 
 static thread_local std::string g_last_error;
 
@@ -174,12 +174,15 @@ int apsu_he_compute_powers(apsu_he_ctx *c, const uint32_t *bundle_indices, int n
     return guarded([&] {
         REQUIRE(c && bundle_indices && src && out, "null argument");
         auto p = new apsu_he_powers;
+        p->eng = c->eng.get();
         try { p->p = c->eng->compute_powers(bundle_indices, nb, src, on_device != 0, rk ? rk->rk.get() : nullptr); }
         catch (...) { delete p; throw; }
         *out = p;
     });
 }
-int apsu_he_powers_free(apsu_he_powers *p) { return guarded([&] { delete p; }); }
+/* buffers go back to the context's pool (the context must outlive its powers objects) */
+int apsu_he_powers_free(apsu_he_powers *p)
+{ return guarded([&] { if (p) { if (p->eng) p->eng->recycle_powers(std::move(p->p)); delete p; } }); }
 
 int apsu_he_powers_download(apsu_he_ctx *c, const apsu_he_powers *p, uint32_t bundle_idx, uint32_t power, uint64_t *out,
                             size_t capacity_words, int *chain_idx, int *is_ntt)
@@ -200,6 +203,7 @@ int apsu_he_powers_download(apsu_he_ctx *c, const apsu_he_powers *p, uint32_t bu
         else { REQUIRE(power % (ps + 1) == 0 && power / (ps + 1) <= pw.n_high, "power not available"); idx = power / (ps + 1) - 1; }
         const size_t words = (size_t)2 * (lvl + 1) * n;
         REQUIRE(capacity_words >= words, "output buffer too small");
+        c->eng->sync();
         const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)idx * pw.nb + b) * words;
         if (hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
         if (chain_idx) *chain_idx = lvl;

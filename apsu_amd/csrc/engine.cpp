@@ -230,16 +230,22 @@ void Engine::prof_begin(int kind, uint64_t units)
     }
     HIP_CHECK(hipEventRecord(r.a, st_));
     prof_recs_.push_back(r);
+    prof_open_ = true;
 }
 
 void Engine::prof_end()
 {
-    if (!prof_on_ || prof_recs_.empty()) return;
+    if (!prof_open_ || prof_recs_.empty()) return;
     HIP_CHECK(hipEventRecord(prof_recs_.back().b, st_));
+    prof_open_ = false;
 }
 
 void Engine::prof_collect()
 {
+    // a sync can happen inside an open scope (job-buffer growth): keep that record for later
+    ProfRec open_rec{};
+    const bool keep = prof_open_ && !prof_recs_.empty();
+    if (keep) { open_rec = prof_recs_.back(); prof_recs_.pop_back(); }
     for (auto &r : prof_recs_) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -251,6 +257,7 @@ void Engine::prof_collect()
         prof_pool_.push_back(r.b);
     }
     prof_recs_.clear();
+    if (keep) prof_recs_.push_back(open_rec);
 }
 
 struct ProfScope {
@@ -311,6 +318,7 @@ u64 *Engine::ws(size_t words)
 void Engine::ws_reset(size_t need)
 {
     arena_off_ = 0;
+    job_seq_ = job_seq_base_;
     if (need > arena_.bytes()) {
         sync();
         arena_.release();
@@ -322,9 +330,15 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
 {
     if (v.empty()) return nullptr;
     const size_t bytes = v.size() * sizeof(T);
-    u64 *d = ws((bytes + 7) / 8);
-    // job arrays go through a pinned staging area so the copy is truly asynchronous and the
-    // std::vector may die before the stream reaches it
+    if (job_seq_ >= job_slots_.size()) job_slots_.resize(job_seq_ + 1);
+    JobSlot &slot = job_slots_[job_seq_++];
+    if (slot.host.size() == bytes && std::memcmp(slot.host.data(), v.data(), bytes) == 0)
+        return reinterpret_cast<const T *>(slot.buf.p());                                             // unchanged since last call
+    if (slot.buf.bytes() < bytes) {
+        sync();                                   // the old buffer may still be read by queued kernels
+        slot.buf.alloc(bytes + bytes / 2);
+    }
+    // through a pinned staging area so the copy is truly asynchronous and the std::vector may die
     const size_t aligned = (bytes + 63) & ~(size_t)63;
     if (stage_off_ + aligned > stage_bytes_) {
         sync();                                   // everything staged so far has been consumed
@@ -335,11 +349,18 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
         }
         stage_off_ = 0;
     }
-    char *h = static_cast<char *>(stage_) + stage_off_;
-    std::memcpy(h, v.data(), bytes);
+    char *hp = static_cast<char *>(stage_) + stage_off_;
+    std::memcpy(hp, v.data(), bytes);
     stage_off_ += aligned;
-    HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st_));
-    return reinterpret_cast<const T *>(d);
+    HIP_CHECK(hipMemcpyAsync(slot.buf.p(), hp, bytes, hipMemcpyHostToDevice, st_));
+    slot.host.assign(reinterpret_cast<const unsigned char *>(v.data()), reinterpret_cast<const unsigned char *>(v.data()) + bytes);
+    return reinterpret_cast<const T *>(slot.buf.p());
+}
+
+void Engine::recycle_powers(std::unique_ptr<Powers> p)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (p && powers_pool_.size() < 4) powers_pool_.push_back(std::move(p));
 }
 
 // run `fn` with the arena, growing it and retrying when the bump allocator overflows
@@ -357,6 +378,7 @@ struct EngineAccess {
     template <class F> static void run(Engine *e, F &&fn) { with_arena(e, fn, &Engine::ws_reset); }
 };
 #define WITH_ARENA(...) EngineAccess::run(this, [&]() __VA_ARGS__)
+#define TIER1_SLOTS() job_seq_base_ = 512
 
 // ============================================================================ device building blocks
 void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
@@ -386,6 +408,7 @@ void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
 void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
     WITH_ARENA({
@@ -400,6 +423,7 @@ void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
 void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
     WITH_ARENA({
@@ -414,6 +438,7 @@ void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
 void Engine::multiply_plain_ntt(const u64 *ct, const u64 *pt_ntt, u64 *out, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
     WITH_ARENA({
@@ -436,6 +461,7 @@ static bool is_monomial(const u64 *pt, size_t count)
 void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
     if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
@@ -455,6 +481,7 @@ void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, i
 void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 *out, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
     if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
@@ -478,6 +505,7 @@ void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 
 void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
     WITH_ARENA({
@@ -493,6 +521,7 @@ void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
 void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
     if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
@@ -511,6 +540,7 @@ void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
 void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
     const int E = hlevel(chain_idx).L + hlevel(chain_idx).nB + 1;
@@ -537,6 +567,7 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
 void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     if (!hp_.using_keyswitching) throw std::logic_error("parameters do not support key switching");
     const size_t n = hp_.n, L = chain_idx + 1;
@@ -552,6 +583,7 @@ void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
 void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     check_level(chain_idx);
     if (chain_idx == 0) throw std::invalid_argument("end of modulus switching chain reached");
     const size_t n = hp_.n, L = chain_idx + 1;
@@ -567,6 +599,7 @@ void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
 void Engine::clear_irrelevant_bits(u64 *ct, int polys)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     const size_t w = (size_t)polys * hp_.n;
     WITH_ARENA({
         u64 *d = ws(w);
@@ -609,6 +642,7 @@ std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cach
                                               const u64 *const *coeff_ptrs, const unsigned char *is_ntt)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!n_coeffs) throw std::invalid_argument("batched_coeffs is empty");
     if (n_coeffs - 1 > psu_.table_params.max_items_per_bin) throw std::invalid_argument("degree exceeds max_items_per_bin");
@@ -706,6 +740,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
     const Sched &s = sched_;
     const size_t n = hp_.n;
+    job_seq_base_ = 0;                                       // job-cache slots 0..255: ComputePowers
     const int first = hp_.first_chain_idx, high = hp_.clamp_chain_idx(1), low = hp_.clamp_chain_idx(2);
     const uint32_t ps = psu_.query_params.ps_low_degree;
     const int low_target = ps ? low : high;                 // receiver_osn.cpp:459-487
@@ -713,18 +748,34 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     const size_t P = s.slot_power.size();
     const size_t slot_w = 3 * Lf * n;                       // (c0, c1, c2 scratch) per power and bundle index
 
-    auto pw = std::make_unique<Powers>();
+    const size_t Ll_ = low_target + 1, Lh_ = high + 1, Eh_ = hlevel(high).L + hlevel(high).nB + 1;
+    const size_t need_low = s.low_powers.size() * nb * 2 * Ll_ * n * sizeof(u64);
+    const size_t need_high = s.high_powers.size() * nb * 2 * Lh_ * n * sizeof(u64);
+    const size_t need_hext = s.high_powers.size() * nb * 2 * Eh_ * n * sizeof(u64);
+    std::unique_ptr<Powers> pw;
+    for (size_t i = 0; i < powers_pool_.size(); i++) {
+        Powers &c = *powers_pool_[i];
+        if (c.low.bytes() == need_low && c.high.bytes() == need_high && c.hext.bytes() == need_hext) {
+            pw = std::move(powers_pool_[i]);
+            powers_pool_.erase(powers_pool_.begin() + i);
+            break;
+        }
+    }
+    const bool recycled = (bool)pw;
+    if (!pw) pw = std::make_unique<Powers>();
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
     pw->low_level = low_target;
     pw->high_level = high;
     pw->n_low = (uint32_t)s.low_powers.size();
     pw->n_high = (uint32_t)s.high_powers.size();
-    const size_t Ll = low_target + 1, Lh = high + 1, Eh = hlevel(high).L + hlevel(high).nB + 1;
-    pw->low.alloc((size_t)pw->n_low * nb * 2 * Ll * n * sizeof(u64));
-    if (pw->n_high) {
-        pw->high.alloc((size_t)pw->n_high * nb * 2 * Lh * n * sizeof(u64));
-        pw->hext.alloc((size_t)pw->n_high * nb * 2 * Eh * n * sizeof(u64));
+    const size_t Lh = high + 1, Eh = hlevel(high).L + hlevel(high).nB + 1;
+    if (!recycled) {
+        pw->low.alloc(need_low);
+        if (pw->n_high) {
+            pw->high.alloc(need_high);
+            pw->hext.alloc(need_hext);
+        }
     }
 
     WITH_ARENA({
@@ -816,7 +867,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
             d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
         }
-        sync();
+        // device-resident inputs: no sync, consumers (eval_bundles, powers_download) are ordered on / synchronise
+        // with the engine's stream.  Host inputs: the caller's buffers must have been consumed before returning.
+        if (!on_device) sync();
     });
     return pw;
 }
@@ -826,6 +879,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
 std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed)
 {
     std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (degree > psu_.table_params.max_items_per_bin) throw std::invalid_argument("degree exceeds max_items_per_bin");
     auto b = std::make_unique<Bundle>();
@@ -877,6 +931,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (count <= 0) return;
     const size_t n = hp_.n;
+    job_seq_base_ = 256;                                     // job-cache slots 256..: eval_bundles
     const uint32_t ps = psu_.query_params.ps_low_degree, l = ps;
     const int high = pw.high_level, low = pw.low_level;
     const size_t Ll = low + 1, Lh = high + 1;

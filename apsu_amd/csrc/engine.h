@@ -156,6 +156,16 @@ private:
     size_t arena_off_ = 0;
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
+    // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the
+    // previous call of the same shape (workspace addresses are deterministic), so it is kept on the
+    // device and the copy is skipped when the content hash matches.
+    struct JobSlot { DevBuf buf; std::vector<unsigned char> host; };
+    std::vector<JobSlot> job_slots_;
+    size_t job_seq_ = 0, job_seq_base_ = 0;   // slots [base, ..) belong to the running top-level op
+    std::vector<std::unique_ptr<Powers>> powers_pool_;
+public:
+    void recycle_powers(std::unique_ptr<Powers> p);
+private:
     std::vector<DevBuf> retired_;     // arenas replaced while kernels may still reference them
 
     // PowersDag schedule (slot order = depth, parents first, power)
@@ -171,7 +181,7 @@ private:
 
     // profiling state
     struct ProfRec { hipEvent_t a, b; int kind; uint64_t units; };
-    bool prof_on_ = false;
+    bool prof_on_ = false, prof_open_ = false;
     std::vector<ProfRec> prof_recs_;
     std::vector<hipEvent_t> prof_pool_;
     ProfStats prof_{};
