@@ -66,7 +66,9 @@ struct MacJob {
     u64 *out[MAC_G];      // [2][L][n]
     const u64 *pw;        // first ciphertext; term j at pw + j*pw_stride ; poly p at + p*pw_poly_stride
     u32 cnt, ng;
-    u32 pt_stride, pw_stride, pw_poly_stride, pad;   // in u64 words
+    u32 pt_stride, pw_stride, pw_poly_stride;        // in u64 words
+    u32 out_poly_stride;  // words between the two output polynomials (L*n for a full ciphertext)
+    u32 limb0, pad;       // first limb handled (grid.y indexes limb0 .. limb0+L'-1); modulus = q[limb]
 };
 
 // ---- launch wrappers (all asynchronous on `st`) --------------------------------------------
@@ -81,6 +83,8 @@ void launch_add(const DevLevel *lv, u64 *acc, const u64 *x, int polys, size_t n,
 // acc[b] += sum_{i<terms} x[b][i]   (x: [batch][terms][polys][L][n]; acc: [batch] stride acc_stride words)
 void launch_add_many(const DevLevel *lv, u64 *acc, size_t acc_stride, const u64 *x, int terms, int polys, size_t n,
                      int batch, hipStream_t st);
+struct SumJob { const u64 *src; u64 *dst; int terms; int pad; };
+void launch_sum_jobs(const DevLevel *lv, int L, const SumJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
 struct PlainJob { u64 *ct; const u64 *pt; };        // ct: c0 limbs [L][n] ; pt: n coefficients mod t
 void launch_add_plain(const DevLevel *lv, const PlainJob *jobs, size_t n, int batch, hipStream_t st);
 void launch_lift(const DevLevel *lv, const u64 *pt, u64 *out, size_t n, int batch, const unsigned char *no_lift,
@@ -96,13 +100,13 @@ void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, siz
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
 // BEHZ
 // ct c at in + c*in_stride holds `polys` polys [L][n]; out packed [c][polys][E][n]
-void launch_behz_ext(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st);
 struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
 void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)
 struct FinishJob { const u64 *d; u64 *out; int terms; int pad; };
-void launch_behz_finish(const DevLevel *lv, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st);
+void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st);
 // key switching
 void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
                       hipStream_t st);
@@ -110,6 +114,10 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
                      hipStream_t st);
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
                        hipStream_t st);
-void launch_mac(const DevLevel *lv, int L, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
+// i = 0 block of eval_patstock when exactly one limb is dropped (bin_bundle.cpp:314-324, note N1):
+// acc[p][m] += (S[p][m] + terms*half - sum_t ((V[t][p] + half) mod q_last)) * q_last^-1  mod q_m
+struct I0Job { const u64 *s; const u64 *v; u64 *acc; int terms; int pad; };   // s:[2][L-1][n] v:[terms][2][n] acc:[2][L-1][n]
+void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st);
 
 } // namespace apsu_he

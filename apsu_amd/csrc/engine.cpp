@@ -270,7 +270,7 @@ static uint64_t mac_units(const std::vector<MacJob> &mj, size_t L) { uint64_t u 
 
 // single-stream description of a multiply-accumulate; group_mac() packs streams that share the
 // ciphertext powers and the term count into MacJobs of up to MAC_G streams
-struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride; };
+struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0; };
 static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
 {
     std::vector<MacJob> jobs;
@@ -280,17 +280,19 @@ static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
     for (size_t i = 0; i < ss.size(); i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
         if (ss[a].pw != ss[b].pw) return ss[a].pw < ss[b].pw;
+        if (ss[a].limb0 != ss[b].limb0) return ss[a].limb0 < ss[b].limb0;
         return ss[a].cnt < ss[b].cnt;
     });
     for (size_t x = 0; x < order.size();) {
         const MacStream &f = ss[order[x]];
         MacJob j{};
         j.pw = f.pw; j.cnt = f.cnt; j.pt_stride = f.pt_stride; j.pw_stride = f.pw_stride; j.pw_poly_stride = f.pw_poly_stride;
+        j.out_poly_stride = f.out_poly_stride; j.limb0 = f.limb0;
         u32 g = 0;
         while (x < order.size() && g < (u32)MAC_G) {
             const MacStream &s = ss[order[x]];
             if (s.pw != f.pw || s.cnt != f.cnt || s.pt_stride != f.pt_stride || s.pw_stride != f.pw_stride ||
-                s.pw_poly_stride != f.pw_poly_stride) break;
+                s.pw_poly_stride != f.pw_poly_stride || s.out_poly_stride != f.out_poly_stride || s.limb0 != f.limb0) break;
             j.pt[g] = s.pt; j.out[g] = s.out; g++; x++;
         }
         j.ng = g;
@@ -551,14 +553,14 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
         H2D(in, a, 2 * L * n);
         if (!square) H2D(in + 2 * L * n, b, 2 * L * n);
         u64 *ext = ws((size_t)nop * 2 * E * n);
-        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(chain_idx), in, L * n, 1, ext, n, nop * 2, st_); }
+        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, in, L * n, 1, ext, n, nop * 2, st_); }
         d_ntt(ext, (size_t)nop * 2 * E, map_ext(chain_idx), E, false);
         u64 *d = ws((size_t)3 * E * n), *o = ws(3 * L * n);
         std::vector<TensorJob> tj{ TensorJob{ ext, square ? ext : ext + (size_t)2 * E * n, d } };
         { PROF(P_TENSOR, 0); launch_tensor(dlevel(chain_idx), upload_jobs(tj), n, 1, st_); }
         d_ntt(d, (size_t)3 * E, map_ext(chain_idx), E, true);
         std::vector<FinishJob> fj{ FinishJob{ d, o, 1, 0 } };
-        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), upload_jobs(fj), false, n, 1, st_); }
+        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, upload_jobs(fj), false, n, 1, st_); }
         D2H(out3, o, 3 * L * n);
         sync();
     });
@@ -807,7 +809,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 const auto &pl = s.levels[d - 1];
                 const int npar = pl.sp - pl.s0;
                 if (npar > 0) {
-                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
+                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), hlevel(first).L, hlevel(first).nB, slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
                     d_ntt(ext_ptr(pl.s0, 0), (size_t)npar * nb * 2 * Ef, map_ext(first), (int)Ef, false);
                 }
                 const auto &cl = s.levels[d];
@@ -824,7 +826,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 }
                 { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }                 // :422/:424
                 d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext(first), (int)Ef, true);
-                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), upload_jobs(fj), false, n, (int)fj.size(), st_); }
+                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 if (hp_.using_keyswitching) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
             }
             arena_off_ = arena_mark;
@@ -864,7 +866,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         if (pw->n_high) {
             convert(s.high_powers, high, pw->high.u());
             // derived form used by eval_patstock's ct x ct products and coefficient-form plaintext products
-            { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
+            { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
             d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
         }
         // device-resident inputs: no sync, consumers (eval_bundles, powers_download) are ordered on / synchronise
@@ -1001,7 +1003,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const Bundle &b = *bundles[c0 + pl_ids[x]];
                     u64 *o = acc + (size_t)x * 2 * Lv * n;
                     if (b.degree) ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
-                                                       (u32)(Lv * n), low_term_stride, (u32)(Ll * n) });   // :140-149
+                                                          (u32)(Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0 });   // :140-149
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
                     pj.push_back(PlainJob{ o, b.a0.u() });                                               // :159
                 }
@@ -1042,8 +1044,8 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     for (int i = 1; i <= nin[x]; i++) {
                         const u32 cnt = (u32)i < b.H ? l : b.r;
                         ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
-                                             inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
-                                             (u32)(Ll * n), low_term_stride, (u32)(Ll * n) });             // :258-264
+                                                inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
+                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0 });   // :258-264
                     }
                 }
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
@@ -1056,45 +1058,89 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 }
                 // ct x ct with the high powers (:272,301): extend, NTT, tensor, INTT, finish (+ sum over i, :273,303)
                 u64 *ext = ws((size_t)NI * 2 * Eh * n);
-                { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+                { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                 d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
                 u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
                 u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
+                // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
+                // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
+                u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
                 std::vector<TensorJob> tj;
                 std::vector<FinishJob> fj;
+                std::vector<SumJob> sj;
                 for (int x = 0; x < Bs; x++) {
                     const int bs = bslot[c0 + ps_ids[x]];
                     for (int i = 1; i <= nin[x]; i++) {
                         const size_t job = (size_t)in_off[x] + i - 1;
                         tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
+                        fj.push_back(FinishJob{ dbuf + job * 3 * Eh * n, tbuf + job * 3 * Lh * n, 1, 0 });
                     }
-                    fj.push_back(FinishJob{ dbuf + (size_t)in_off[x] * 3 * Eh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                    sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                 }
                 { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
                 d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
-                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), upload_jobs(fj), false, n, Bs, st_); }
+                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
+                { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
                 if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
 
+                // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
+                // the sum (note N1).  With one dropped limb the sum of the rounded terms is
+                //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
+                // where the first sum is exact and may be taken in the NTT domain.  So only the LAST limb of each term
+                // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
+                const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
+                if (i0_fast) {
+                    u64 *ssum = ws((size_t)Bs * 2 * Lh * n);
+                    ms.clear();
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + ps_ids[x]];
+                        ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + ps_ids[x]]), ssum + (size_t)x * 2 * Lh * n, l,
+                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0 });
+                    }
+                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(low), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
+                    d_ntt_ct(ssum, (size_t)Bs * 2, high, true);
+                    if (low == high) {
+                        { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, ssum, 1, 2, n, Bs, st_); }
+                    } else {
+                        u64 *vlast = ws((size_t)Bs * l * 2 * n);
+                        ms.clear();
+                        for (int x = 0; x < Bs; x++) {
+                            const Bundle &b = *bundles[c0 + ps_ids[x]];
+                            const int bs = bslot[c0 + ps_ids[x]];
+                            for (u32 j = 1; j <= l; j++)
+                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                        vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
+                                                        (u32)(Ll * n), (u32)n, (u32)(Ll - 1) });
+                        }
+                        { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, 1)); launch_mac(dlevel(low), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
+                        d_ntt(vlast, (size_t)Bs * l * 2, map_ct() + (Ll - 1), 1, true);          // every limb polynomial is mod q_last
+                        std::vector<I0Job> ij;
+                        for (int x = 0; x < Bs; x++)
+                            ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, result + (size_t)x * 3 * Lh * n, (int)l, 0 });
+                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
+                    }
+                } else {
                 // i = 0 block: every term is rounded on its own before the sum (note N1)            :314-324
-                u64 *term = ws((size_t)Bs * l * 2 * Ll * n);
-                ms.clear();
-                for (int x = 0; x < Bs; x++) {
-                    const Bundle &b = *bundles[c0 + ps_ids[x]];
-                    const int bs = bslot[c0 + ps_ids[x]];
-                    for (u32 j = 1; j <= l; j++)
-                        ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                             term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
-                                             (u32)(Ll * n) });
+                    u64 *term = ws((size_t)Bs * l * 2 * Ll * n);
+                    ms.clear();
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + ps_ids[x]];
+                        const int bs = bslot[c0 + ps_ids[x]];
+                        for (u32 j = 1; j <= l; j++)
+                            ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                    term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
+                                                    (u32)(Ll * n), (u32)(Ll * n), 0 });
+                    }
+                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
+                    d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
+                    u64 *termh = term;
+                    for (int lv = low; lv > high; lv--) {
+                        u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
+                        { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
+                        termh = nxt;
+                    }
+                    { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
                 }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
-                d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
-                u64 *termh = term;
-                for (int lv = low; lv > high; lv--) {
-                    u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
-                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
-                    termh = nxt;
-                }
-                { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
 
                 // coefficient-form plaintexts a_{i*h} times the high powers (:328-337): exact, so the
                 // products are summed in the NTT domain and transformed back once
@@ -1104,7 +1150,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
                     ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
-                                         (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n) });
+                                            (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0 });
                 }
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(cf, (size_t)Bs * 2, high, true);

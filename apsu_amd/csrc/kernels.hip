@@ -160,6 +160,35 @@ void launch_add_many(const DevLevel *lv, u64 *acc, size_t acc_stride, const u64 
     KERNEL_CHECK();
 }
 
+// dst[polys][L][n] = sum over `terms` consecutive ciphertexts src[t][polys][L][n]  (exact modular sums)
+__global__ __launch_bounds__(EW_T) void k_sum_jobs(const DevLevel *__restrict__ lv, const SumJob *__restrict__ jobs, int polys, size_t n)
+{
+    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2;
+    if (k >= n) return;
+    const int L = lv->L;
+    const SumJob job = jobs[blockIdx.y / (polys * L)];
+    const int pl = blockIdx.y % (polys * L);              // (poly, limb) pair
+    const u64 q = lv->q[pl % L].q;
+    const size_t ctw = (size_t)polys * L * n;
+    const u64 *src = job.src + (size_t)pl * n + k;
+    u64 s0 = 0, s1 = 0;
+    for (int t = 0; t < job.terms; t++) {
+        const u64x2 v = ldg16(src + (size_t)t * ctw);
+        s0 = addmod(s0, v[0], q);
+        s1 = addmod(s1, v[1], q);
+    }
+    u64x2 r; r[0] = s0; r[1] = s1;
+    *reinterpret_cast<u64x2 *>(job.dst + (size_t)pl * n + k) = r;
+}
+
+void launch_sum_jobs(const DevLevel *lv, int L, const SumJob *jobs, int polys, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_sum_jobs, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)(njobs * polys * L)), dim3(EW_T), 0, st,
+                       lv, jobs, polys, n);
+    KERNEL_CHECK();
+}
+
 // K8: add_plain_inplace (bin_bundle.cpp:159,162,345,346): c0 += round(m*Q/t) in RNS  (App. B7)
 __global__ __launch_bounds__(EW_T) void k_add_plain(const DevLevel *__restrict__ lv, const PlainJob *__restrict__ jobs, size_t n)
 {
@@ -333,49 +362,60 @@ void launch_clear_bits(u64 *ct, size_t words, int bits, hipStream_t st)
 //
 // Step (1)+(2): q -> q u Bsk with Montgomery removal of the q-overflow (fastbconv_m_tilde + sm_mrq).
 // in: [batch] polynomials [L][n] at stride in_stride ; out: [batch][E][n] (q part copied, Bsk part computed)
+// TL / TNB > 0: compile-time limb counts (loops fully unrolled, constants fetched in bulk); 0 = generic.
+template <int TL, int TNB>
 __global__ __launch_bounds__(EW_T) void k_behz_ext(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
                                                    size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
-    const int L = lv->L, nBsk = lv->nBsk, E = lv->E;
+    const int L = TL ? TL : lv->L, nBsk = TL ? TNB + 1 : lv->nBsk, E = L + nBsk;
+    constexpr int LMAX = TL ? TL : DMAXL;
+    constexpr int BMAX = TL ? TNB + 1 : DMAXB;
     const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
     const u64 *src = in + c * in_stride + p * (size_t)L * n;
     u64 *dst = out + (size_t)blockIdx.y * E * n;
-    u64 xs[DMAXL];
+    u64 xs[LMAX];
     u32 mt_acc = 0;
 #pragma unroll
-    for (int j = 0; j < DMAXL; j++) {
-        if (j < L) {
-            const u64 x = src[j * n + k];
-            dst[j * n + k] = x;
+    for (int j = 0; j < LMAX; j++) {
+        if (TL || j < L) {
+            const u64 x = src[(size_t)j * n + k];
+            dst[(size_t)j * n + k] = x;
             xs[j] = mul_shoup(x, lv->ext_scale[j].w, lv->ext_scale[j].wq, lv->q[j].q);
             mt_acc += (u32)xs[j] * lv->q_to_mt[j];           // arithmetic mod 2^32 = m_tilde
         }
     }
     const u32 r32 = mt_acc * lv->neg_inv_q_mt;
-    for (int i = 0; i < nBsk; i++) {
-        const Mod m = lv->bsk[i];
-        u128p acc{ 0, 0 };
 #pragma unroll
-        for (int j = 0; j < DMAXL; j++)
-            if (j < L) mac128(acc, xs[j], lv->q_to_bsk[i][j]);
-        const u64 y = barrett128(acc, m);
-        // centred lift of r into Z_m (m_tilde is a power of two: ">=")
-        u64 r = r32;
-        if (r32 >= 0x80000000u) r += m.q - ((u64)1 << 32);
-        u128p v = mul128(r, lv->prod_q_bsk[i]);
-        add128(v, u128p{ y, 0 });
-        const u64 red = barrett128(v, m);
-        dst[(L + i) * n + k] = mul_shoup(red, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m.q);
+    for (int i = 0; i < BMAX; i++) {
+        if (TL || i < nBsk) {
+            const Mod m = lv->bsk[i];
+            u128p acc{ 0, 0 };
+#pragma unroll
+            for (int j = 0; j < LMAX; j++)
+                if (TL || j < L) mac128(acc, xs[j], lv->q_to_bsk[i][j]);
+            const u64 y = barrett128(acc, m);
+            // centred lift of r into Z_m (m_tilde is a power of two: ">=")
+            u64 r = r32;
+            if (r32 >= 0x80000000u) r += m.q - ((u64)1 << 32);
+            u128p v = mul128(r, lv->prod_q_bsk[i]);
+            add128(v, u128p{ y, 0 });
+            const u64 red = barrett128(v, m);
+            dst[(size_t)(L + i) * n + k] = mul_shoup(red, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m.q);
+        }
     }
 }
 
-void launch_behz_ext(const DevLevel *lv, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st)
 {
     if (!cts) return;
-    hipLaunchKernelGGL(k_behz_ext, ew_grid(n, cts * polys), dim3(EW_T), 0, st, lv, in, in_stride, polys, out, n);
+    const dim3 g = ew_grid(n, cts * polys), t(EW_T);
+#define EXT_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext<TL, TL>), g, t, 0, st, lv, in, in_stride, polys, out, n); } else
+    EXT_CASE(1) EXT_CASE(2) EXT_CASE(3) EXT_CASE(4)
+    { hipLaunchKernelGGL((k_behz_ext<0, 0>), g, t, 0, st, lv, in, in_stride, polys, out, n); }
+#undef EXT_CASE
     KERNEL_CHECK();
 }
 
@@ -407,75 +447,95 @@ void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batc
 
 // Steps (6)-(8) for one coefficient of one extended polynomial: multiply by t, fast_floor
 // (q u Bsk -> Bsk), fastbconv_sk (Bsk -> q).  d points at limb 0 of the polynomial, stride n.
+template <int TL, int TNB>
 __device__ __forceinline__ void behz_finish_coeff(const DevLevel *__restrict__ lv, const u64 *__restrict__ d, size_t n,
                                                   u64 *res /* [L] */)
 {
-    const int L = lv->L, nB = lv->nB, nBsk = lv->nBsk;
-    u64 xq[DMAXL];
+    const int L = TL ? TL : lv->L, nB = TL ? TNB : lv->nB, nBsk = nB + 1;
+    constexpr int LMAX = TL ? TL : DMAXL;
+    constexpr int BMAX = TL ? TNB + 1 : DMAXB;
+    u64 xq[LMAX];
 #pragma unroll
-    for (int j = 0; j < DMAXL; j++)
-        if (j < L) xq[j] = mul_shoup(d[j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
-    u64 ys[DMAXB];
+    for (int j = 0; j < LMAX; j++)
+        if (TL || j < L) xq[j] = mul_shoup(d[(size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    u64 ys[BMAX];
     u64 fl_sk = 0;
-    for (int i = 0; i < nBsk; i++) {
-        const Mod m = lv->bsk[i];
-        u128p acc{ 0, 0 };
 #pragma unroll
-        for (int j = 0; j < DMAXL; j++)
-            if (j < L) mac128(acc, xq[j], lv->q_to_bsk[i][j]);
-        const u64 conv = barrett128(acc, m);
-        const u64 xb = mul_shoup(d[(L + i) * n], lv->t_bsk[i].w, lv->t_bsk[i].wq, m.q);
-        const u64 fl = mul_shoup(xb + (m.q - conv), lv->inv_prod_q_bsk[i].w, lv->inv_prod_q_bsk[i].wq, m.q);
-        if (i < nB) ys[i] = mul_shoup(fl, lv->inv_punct_B[i].w, lv->inv_punct_B[i].wq, m.q);
-        else fl_sk = fl;
+    for (int i = 0; i < BMAX; i++) {
+        if (TL || i < nBsk) {
+            const Mod m = lv->bsk[i];
+            u128p acc{ 0, 0 };
+#pragma unroll
+            for (int j = 0; j < LMAX; j++)
+                if (TL || j < L) mac128(acc, xq[j], lv->q_to_bsk[i][j]);
+            const u64 conv = barrett128(acc, m);
+            const u64 xb = mul_shoup(d[(size_t)(L + i) * n], lv->t_bsk[i].w, lv->t_bsk[i].wq, m.q);
+            const u64 fl = mul_shoup(xb + (m.q - conv), lv->inv_prod_q_bsk[i].w, lv->inv_prod_q_bsk[i].wq, m.q);
+            if (i < nB) ys[i] = mul_shoup(fl, lv->inv_punct_B[i].w, lv->inv_punct_B[i].wq, m.q);
+            else fl_sk = fl;
+        }
     }
     const Mod msk = lv->bsk[nB];
     u128p acc{ 0, 0 };
-    for (int i = 0; i < nB; i++) mac128(acc, ys[i], lv->B_to_msk[i]);
+#pragma unroll
+    for (int i = 0; i < BMAX - 1; i++)
+        if (TL || i < nB) mac128(acc, ys[i], lv->B_to_msk[i]);
     const u64 z_sk = barrett128(acc, msk);
     const u64 alpha = mul_shoup(z_sk + (msk.q - fl_sk), lv->inv_prod_B_msk.w, lv->inv_prod_B_msk.wq, msk.q);
     const bool neg = alpha > lv->msk_half;                     // alpha represents a negative value
     const u64 a_abs = neg ? msk.q - alpha : alpha;
-    for (int j = 0; j < L; j++) {
-        u128p z{ 0, 0 };
-        for (int i = 0; i < nB; i++) mac128(z, ys[i], lv->B_to_q[j][i]);
-        mac128(z, a_abs, neg ? lv->prod_B_q[j] : lv->neg_prod_B_q[j]);
-        res[j] = barrett128(z, lv->q[j]);
+#pragma unroll
+    for (int j = 0; j < LMAX; j++) {
+        if (TL || j < L) {
+            u128p z{ 0, 0 };
+#pragma unroll
+            for (int i = 0; i < BMAX - 1; i++)
+                if (TL || i < nB) mac128(z, ys[i], lv->B_to_q[j][i]);
+            mac128(z, a_abs, neg ? lv->prod_B_q[j] : lv->neg_prod_B_q[j]);
+            res[j] = barrett128(z, lv->q[j]);
+        }
     }
 }
 
 // One job = one output polynomial triple: out[3][L][n] (+)= sum over `terms` consecutive extended
 // products d[term][3][E][n] (coefficient form).  The per-term rounding is kept (SURVEY note N1).
+template <int TL, int TNB>
 __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict__ lv, const FinishJob *__restrict__ jobs,
                                                       int accumulate, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
-    const int L = lv->L, E = lv->E;
+    const int L = TL ? TL : lv->L, E = TL ? 2 * TL + 1 + (TNB - TL) : lv->E;
+    constexpr int LMAX = TL ? TL : DMAXL;
     const FinishJob job = jobs[blockIdx.y / 3];
     const size_t p = blockIdx.y % 3;
-    u64 sum[DMAXL];
+    u64 sum[LMAX];
     u64 *o = job.out + p * (size_t)L * n + k;
 #pragma unroll
-    for (int j = 0; j < DMAXL; j++)
-        if (j < L) sum[j] = accumulate ? o[(size_t)j * n] : 0;
+    for (int j = 0; j < LMAX; j++)
+        if (TL || j < L) sum[j] = accumulate ? o[(size_t)j * n] : 0;
     for (int i = 0; i < job.terms; i++) {
         const u64 *dp = job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k;
-        u64 res[DMAXL];
-        behz_finish_coeff(lv, dp, n, res);
+        u64 res[LMAX];
+        behz_finish_coeff<TL, TNB>(lv, dp, n, res);
 #pragma unroll
-        for (int j = 0; j < DMAXL; j++)
-            if (j < L) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
+        for (int j = 0; j < LMAX; j++)
+            if (TL || j < L) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
     }
 #pragma unroll
-    for (int j = 0; j < DMAXL; j++)
-        if (j < L) o[(size_t)j * n] = sum[j];
+    for (int j = 0; j < LMAX; j++)
+        if (TL || j < L) o[(size_t)j * n] = sum[j];
 }
 
-void launch_behz_finish(const DevLevel *lv, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st)
+void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st)
 {
     if (!njobs) return;
-    hipLaunchKernelGGL(k_behz_finish, ew_grid(n, njobs * 3), dim3(EW_T), 0, st, lv, jobs, accumulate ? 1 : 0, n);
+    const dim3 g = ew_grid(n, njobs * 3), t(EW_T);
+    const int acc = accumulate ? 1 : 0;
+#define FIN_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_finish<TL, TL>), g, t, 0, st, lv, jobs, acc, n); } else
+    FIN_CASE(1) FIN_CASE(2) FIN_CASE(3) FIN_CASE(4)
+    { hipLaunchKernelGGL((k_behz_finish<0, 0>), g, t, 0, st, lv, jobs, acc, n); }
+#undef FIN_CASE
     KERNEL_CHECK();
 }
 
@@ -578,8 +638,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2;
     if (k >= n) return;
     const MacJob job = jobs[blockIdx.z];
-    const int j = blockIdx.y;                                  // limb
-    const int L = lv->L;
+    const int j = blockIdx.y + job.limb0;                      // limb
     const Mod m = lv->q[j];
     const u64 *p0 = job.pw + (size_t)j * n + k;
     const u64 *p1 = p0 + job.pw_poly_stride;
@@ -631,17 +690,50 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
             u64x2 r0, r1;
             r0[0] = barrett128(a0[g][0], m); r0[1] = barrett128(a0[g][1], m);
             r1[0] = barrett128(a1[g][0], m); r1[1] = barrett128(a1[g][1], m);
-            *reinterpret_cast<u64x2 *>(job.out[g] + (size_t)j * n + k) = r0;
-            *reinterpret_cast<u64x2 *>(job.out[g] + ((size_t)L + j) * n + k) = r1;
+            u64 *o = job.out[g] + (size_t)blockIdx.y * n + k;
+            *reinterpret_cast<u64x2 *>(o) = r0;
+            *reinterpret_cast<u64x2 *>(o + job.out_poly_stride) = r1;
         }
     }
 }
 
-void launch_mac(const DevLevel *lv, int L, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs || !nlimbs) return;
+    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)njobs), dim3(EW_T), 0, st,
+                       lv, jobs, n);
+    KERNEL_CHECK();
+}
+
+// Sum of `terms` individually rounded drop-last-limb results, computed from the exact sum S of the kept
+// limbs and the per-term last limbs V (all coefficient form):  SURVEY note N1 / DESIGN.md §4.
+__global__ __launch_bounds__(EW_T) void k_i0_finish(const DevLevel *__restrict__ lv, const I0Job *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const I0Job job = jobs[blockIdx.y >> 1];
+    const int p = blockIdx.y & 1;
+    const int L = lv->L;                                        // level BEFORE the drop
+    const u64 ql = lv->q[L - 1].q, half = lv->half;
+    u64 R = 0;                                                  // integer sum of (v + half) mod q_last; terms*q_last < 2^64 (host-checked)
+    const u64 *v = job.v + (size_t)p * n + k;
+    for (int t = 0; t < job.terms; t++) R += addmod(v[(size_t)t * 2 * n], half, ql);
+    for (int m = 0; m + 1 < L; m++) {
+        const Mod mq = lv->q[m];
+        // terms * (half mod q_m) - (R mod q_m)
+        const u64 th = barrett128(mul128((u64)job.terms, lv->half_mod[m]), mq);
+        const u64 corr = submod(th, barrett64(R, mq), mq.q);
+        const size_t o = ((size_t)p * (L - 1) + m) * n + k;
+        const u64 val = addmod(job.s[o], corr, mq.q);
+        const u64 r = mul_shoup(val, lv->inv_q_last[m].w, lv->inv_q_last[m].wq, mq.q);
+        job.acc[((size_t)p * (L - 1) + m) * n + k] = addmod(job.acc[((size_t)p * (L - 1) + m) * n + k], r, mq.q);
+    }
+}
+
+void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st)
 {
     if (!njobs) return;
-    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)L, (unsigned)njobs), dim3(EW_T), 0, st,
-                       lv, jobs, n);
+    hipLaunchKernelGGL(k_i0_finish, ew_grid(n, njobs * 2), dim3(EW_T), 0, st, lv_low, jobs, n);
     KERNEL_CHECK();
 }
 

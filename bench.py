@@ -74,12 +74,20 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # rehearsal on a one-GPU box: APSU_BENCH_BACKEND=gloo runs every rank on GPU 0 and gathers through host
+    # memory; the driver's multi-GPU runs use the default ("nccl" == RCCL over xGMI, one GPU per rank)
+    backend = os.environ.get("APSU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm (xGMI)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm (xGMI)
+        else:
+            dist.init_process_group(backend)
 
     with open(os.path.join(ROOT, "tests", "params", args.config + ".json")) as f:
         params_json = f.read()
@@ -120,7 +128,8 @@ def main():
     mask_ptrs = [mask_dev.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine]
     max_local, _rows = gather_slots(assign)
     out_dev = torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev)
-    gathered = torch.zeros((world * max_local, 2, n), dtype=torch.int64, device=dev) if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.zeros((world * max_local, 2, n), dtype=torch.int64, device=gdev) if world > 1 else None
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
@@ -128,8 +137,8 @@ def main():
         pw = ctx.compute_powers(my_indices, src_ptrs, rk, on_device=True) if my_indices else None
         if bundles:
             ctx.eval_bundles(bundles, pw, rk, mask_ptrs, out=out_dev.data_ptr(), masks_on_device=True, out_on_device=True)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out_dev)           # the path's only collective
+        if world > 1:                                                # the path's only collective
+            dist.all_gather_into_tensor(gathered, out_dev if backend == "nccl" else out_dev.cpu())
         return pw
 
     def fence():
@@ -155,7 +164,7 @@ def main():
     ms_local = elapsed * 1e3 / max(1, args.steps)
     ms_step = ms_local
     if world > 1:
-        tt = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+        tt = torch.tensor([ms_local], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ms_step = float(tt.item())
 
@@ -221,6 +230,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host,
                                               unit_pos, out_dev, n, t)
+    if rank == 0 and world > 1:
+        g = gathered.cpu()
+        mine_ok = bool((g[:len(mine)] == out_dev[:len(mine)].cpu()).all())
+        filled = all(bool(g[row].any()) for row in _rows.values())
+        result["gather_check"] = {"rank0_rows_match": mine_ok, "all_binbundle_rows_filled": filled, "rows": len(_rows)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

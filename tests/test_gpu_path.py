@@ -53,6 +53,13 @@ def test_toy_two_limb_key_level():
                                  felts=7), {0: [5, 4, 2]})
 
 
+def test_toy_wide_primes_many_low_powers_fallback_path():
+    # 60-bit coefficient primes with 16 low powers: (l+1)*q_last >= 2^64, so the i = 0 block cannot use the
+    # summed-last-limb shortcut and takes the per-term INTT + drop-limb path
+    run_scenario(common.toy_json(coeff_bits=(60, 60, 60, 40), plain_bits=17, ps_low=16, max_items=40, query_powers=(1, 17)),
+                 {0: [40, 35], 1: [17]})
+
+
 def test_config_100K_1():
     run_scenario(common.param_json("100K-1"), {0: [19, 7, 1]})
 
