@@ -224,7 +224,7 @@ int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, i
 }
 
 int apsu_he_profile_enable(apsu_he_ctx *c, int on)
-{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->profile_enable(on != 0); }); }
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->profile_enable(on); }); }
 
 int apsu_he_profile_read(apsu_he_ctx *c, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset)
 {

@@ -60,14 +60,16 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
 
     const size_t n = hp_.n;
     const int nmod = (int)hp_.ntt.size();
-    // twiddles: per modulus [fwd n][inv n] TwPair
+    // twiddles: per modulus [fwd n][inv n][dit n][scale n] TwPair
     {
-        std::vector<TwPair> tw((size_t)nmod * 2 * n);
+        std::vector<TwPair> tw((size_t)nmod * 4 * n);
         for (int m = 0; m < nmod; m++) {
             const NttTablesHost &t = hp_.ntt[m];
             for (size_t k = 0; k < n; k++) {
-                tw[((size_t)m * 2 + 0) * n + k] = TwPair{ t.fwd[k], t.fwd_q[k] };
-                tw[((size_t)m * 2 + 1) * n + k] = TwPair{ t.inv[k], t.inv_q[k] };
+                tw[((size_t)m * 4 + 0) * n + k] = TwPair{ t.fwd[k], t.fwd_q[k] };
+                tw[((size_t)m * 4 + 1) * n + k] = TwPair{ t.inv[k], t.inv_q[k] };
+                tw[((size_t)m * 4 + 2) * n + k] = TwPair{ t.dit[k], t.dit_q[k] };
+                tw[((size_t)m * 4 + 3) * n + k] = TwPair{ t.scale[k], t.scale_q[k] };
             }
         }
         d_tw_.alloc(tw.size() * sizeof(TwPair));
@@ -81,8 +83,10 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
             tabs[m].pad = 0;
-            tabs[m].fwd = base + ((size_t)m * 2 + 0) * n;
-            tabs[m].inv = base + ((size_t)m * 2 + 1) * n;
+            tabs[m].fwd = base + ((size_t)m * 4 + 0) * n;
+            tabs[m].inv = base + ((size_t)m * 4 + 1) * n;
+            tabs[m].dit = base + ((size_t)m * 4 + 2) * n;
+            tabs[m].scale = base + ((size_t)m * 4 + 3) * n;
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
@@ -203,12 +207,13 @@ void Engine::sync()
 }
 
 // ---- profiling: one HIP event pair per launch on the engine's stream, resolved at the next sync
-void Engine::profile_enable(bool on)
+void Engine::profile_enable(int mode)
 {
     std::lock_guard<std::mutex> g(mu_);
     HIP_CHECK(hipStreamSynchronize(st_));
     prof_collect();
-    prof_on_ = on;
+    prof_on_ = mode != 0;
+    prof_ntt_only_ = mode == 2;
 }
 
 void Engine::profile_read(ProfStats *out, bool reset)
@@ -222,7 +227,7 @@ void Engine::profile_read(ProfStats *out, bool reset)
 
 void Engine::prof_begin(int kind, uint64_t units)
 {
-    if (!prof_on_) return;
+    if (!prof_on_ || (prof_ntt_only_ && kind > P_NTT_INV)) return;
     ProfRec r{ nullptr, nullptr, kind, units };
     for (hipEvent_t *e : { &r.a, &r.b }) {
         if (!prof_pool_.empty()) { *e = prof_pool_.back(); prof_pool_.pop_back(); }

@@ -118,7 +118,7 @@ public:
     // ---------------- per-kernel timing with HIP events on the engine's stream (bench.py roofline)
     enum ProfKind { P_NTT_FWD = 0, P_NTT_INV, P_MAC, P_BEHZ_EXT, P_TENSOR, P_BEHZ_FINISH, P_KEYSWITCH, P_MODSWITCH, P_OTHER, P_COUNT };
     struct ProfStats { double ms[P_COUNT]; uint64_t launches[P_COUNT]; uint64_t units[P_COUNT]; };
-    void profile_enable(bool on);
+    void profile_enable(int mode);      // 0 off, 1 every kernel class, 2 NTT launches only (cheapest)
     void profile_read(ProfStats *out, bool reset);
 
 private:
@@ -181,7 +181,7 @@ private:
 
     // profiling state
     struct ProfRec { hipEvent_t a, b; int kind; uint64_t units; };
-    bool prof_on_ = false, prof_open_ = false;
+    bool prof_on_ = false, prof_open_ = false, prof_ntt_only_ = false;
     std::vector<ProfRec> prof_recs_;
     std::vector<hipEvent_t> prof_pool_;
     ProfStats prof_{};

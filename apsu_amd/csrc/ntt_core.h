@@ -36,6 +36,10 @@ struct NttTable {
     u64 r1;                            // floor(2^64 / q): single-word Barrett ratio
     const TwPair *fwd;
     const TwPair *inv;
+    // narrow moduli only: the inverse runs as a decimation-in-time cyclic transform with the psi^-j
+    // twist and n^-1 applied at the end (no conditional subtractions, same butterfly as the forward):
+    const TwPair *dit;                 // dit[g + j] = psi^(-j*n/g), j < g, g = 1,2,4,..,n/2
+    const TwPair *scale;               // scale[j] = n^-1 * psi^-j
     int narrow;                        // (4*logn+1)*q < 2^64
     int pad;
 };
@@ -135,6 +139,23 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (COLS && g > 0) continue;   // column groups share the twiddle: handled below
+                if (INV && NARROW) {
+                    // decimation-in-time butterfly of the cyclic inverse: twiddle depends on the position inside
+                    // the block (row low bits and column), not on the block
+#pragma unroll
+                    for (int gg = 0; gg < G; gg++) {
+                        if (!COLS && gg != g) continue;
+                        const int jj = COLS ? (((j & (bit - 1)) << LOWBITS) | (c0 + gg)) : (j & (bit - 1));
+                        const int gap = COLS ? (bit << LOWBITS) : bit;
+                        const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
+                        u64 &x = r[gg][j], &y = r[gg][j | bit];
+                        const u64 v = mul_lazy4(y, tv[0], tv[1], nq);
+                        const u64 a = x;
+                        x = a + v;
+                        y = a - v + q4;
+                    }
+                    continue;
+                }
                 int ti = (1 << (S + u)) + (((COLS ? block : block + g)) << u) + (j >> (K - u));
                 if (UNIFORM_TW) ti = UNIFORM_INT(ti);
                 const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(W + ti));
@@ -164,7 +185,10 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 u64 v = r[g][j];
-                if (INV) v = mul_shoup(v, tab.ninv, tab.ninv_q, q);
+                if (INV && NARROW) {
+                    const u64x2 sv = ldg16(reinterpret_cast<const u64 *>(tab.scale + idx(g, j)));
+                    v = mul_shoup(v, sv[0], sv[1], q);
+                } else if (INV) v = mul_shoup(v, tab.ninv, tab.ninv_q, q);
                 else if (NARROW) { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }
                 else v = csub(csub(csub(v, q4), q << 1), q);
                 r[g][j] = v;

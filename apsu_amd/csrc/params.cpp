@@ -382,6 +382,23 @@ NttTablesHost make_ntt_tables(u64 q, size_t n, int logn)
     }
     t.ninv = t.mod.inv((u64)n % q);
     t.ninv_q = t.mod.shoup(t.ninv);
+    // tables of the decimation-in-time inverse (used for narrow moduli): powers of psi^-1 by index
+    std::vector<u64> ipow(n);
+    ipow[0] = 1;
+    for (size_t i = 1; i < n; i++) ipow[i] = t.mod.mul(ipow[i - 1], ipsi);
+    t.dit.assign(n, 1); t.dit_q.assign(n, t.mod.shoup(1));
+    t.scale.resize(n); t.scale_q.resize(n);
+    for (size_t g = 1; g < n; g <<= 1)
+        for (size_t j = 0; j < g; j++) {
+            u64 w = ipow[(j * (n / g)) % n];                 // psi^(-j*n/g), exponent < n
+            t.dit[g + j] = w;
+            t.dit_q[g + j] = t.mod.shoup(w);
+        }
+    for (size_t j = 0; j < n; j++) {
+        u64 s = t.mod.mul(t.ninv, ipow[j]);
+        t.scale[j] = s;
+        t.scale_q[j] = t.mod.shoup(s);
+    }
     return t;
 }
 

@@ -65,6 +65,8 @@ struct NttTablesHost {                  // one modulus
     u64 psi = 0;
     std::vector<u64> fwd, fwd_q;        // fwd[k] = psi^brv(k) and Shoup quotient
     std::vector<u64> inv, inv_q;        // inv[k] = psi^-brv(k)
+    std::vector<u64> dit, dit_q;        // dit[g + j] = psi^(-j*n/g)   (decimation-in-time cyclic inverse)
+    std::vector<u64> scale, scale_q;    // scale[j] = n^-1 * psi^-j
     u64 ninv = 0, ninv_q = 0;
 };
 

@@ -209,8 +209,9 @@ class HeContext:
     PROFILE_CLASSES = ("ntt_fwd", "ntt_inv", "dyadic_mac", "behz_ext", "behz_tensor", "behz_finish", "keyswitch",
                        "modswitch", "other")
 
-    def profile_enable(self, on=True):
-        _check(load_library().apsu_he_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, mode=1):
+        """0/False off, 1/True every kernel class, 2 NTT launches only (least intrusive)"""
+        _check(load_library().apsu_he_profile_enable(self.h, int(mode)))
 
     def profile_read(self, reset=True):
         """-> {class: (ms, launches, units)} of device time measured with HIP events on the engine's stream."""

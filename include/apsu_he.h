@@ -148,7 +148,7 @@ int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles,
  * Classes (index): 0 ntt_fwd, 1 ntt_inv, 2 dyadic_mac, 3 behz_ext, 4 behz_tensor, 5 behz_finish,
  * 6 keyswitch, 7 modswitch, 8 other.  units: limb polynomials for 0/1, plaintext limb-terms for 2. */
 #define APSU_HE_PROFILE_CLASSES 9
-int apsu_he_profile_enable(apsu_he_ctx *ctx, int on);
+int apsu_he_profile_enable(apsu_he_ctx *ctx, int mode);   /* 0 off, 1 every class, 2 NTT launches only */
 int apsu_he_profile_read(apsu_he_ctx *ctx, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset);
 
 #ifdef __cplusplus

@@ -157,7 +157,7 @@ def test_device_resident_io_and_profile_hooks():
     src_d = torch.from_numpy(src.view(np.int64)).cuda()
     w = src[0].size
     ptrs = [[src_d.data_ptr() + i * w * 8 for i in range(len(S.sources))]]
-    G.profile_enable(True)
+    G.profile_enable(1)
     pw_h = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
     pw_d = G.compute_powers([0], ptrs, rk, on_device=True)
     gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]

@@ -38,7 +38,7 @@ def run(n, bits, label, gib=1.0):
     ct[:, :, 0] += np.arange(polys, dtype=np.uint64)[:, None] % np.uint64(1000)
     ref0 = ct[0].copy()
     G.transform_to_ntt_inplace(ct, 2); G.transform_from_ntt_inplace(ct, 2)     # warm-up (first touch of the arena)
-    G.profile_enable(True); G.profile_read()
+    G.profile_enable(2); G.profile_read()
     for it in range(3):
         G.transform_to_ntt_inplace(ct, 2)
         G.transform_from_ntt_inplace(ct, 2)
