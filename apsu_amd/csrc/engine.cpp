@@ -60,16 +60,15 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
 
     const size_t n = hp_.n;
     const int nmod = (int)hp_.ntt.size();
-    // twiddles: per modulus [fwd n][inv n][dit n][scale n] TwPair
+    // twiddles: per modulus [fwd n][dit n][scale n] TwPair
     {
-        std::vector<TwPair> tw((size_t)nmod * 4 * n);
+        std::vector<TwPair> tw((size_t)nmod * 3 * n);
         for (int m = 0; m < nmod; m++) {
             const NttTablesHost &t = hp_.ntt[m];
             for (size_t k = 0; k < n; k++) {
-                tw[((size_t)m * 4 + 0) * n + k] = TwPair{ t.fwd[k], t.fwd_q[k] };
-                tw[((size_t)m * 4 + 1) * n + k] = TwPair{ t.inv[k], t.inv_q[k] };
-                tw[((size_t)m * 4 + 2) * n + k] = TwPair{ t.dit[k], t.dit_q[k] };
-                tw[((size_t)m * 4 + 3) * n + k] = TwPair{ t.scale[k], t.scale_q[k] };
+                tw[((size_t)m * 3 + 0) * n + k] = TwPair{ t.fwd[k], t.fwd_q[k] };
+                tw[((size_t)m * 3 + 1) * n + k] = TwPair{ t.dit[k], t.dit_q[k] };
+                tw[((size_t)m * 3 + 2) * n + k] = TwPair{ t.scale[k], t.scale_q[k] };
             }
         }
         d_tw_.alloc(tw.size() * sizeof(TwPair));
@@ -83,10 +82,9 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
             tabs[m].pad = 0;
-            tabs[m].fwd = base + ((size_t)m * 4 + 0) * n;
-            tabs[m].inv = base + ((size_t)m * 4 + 1) * n;
-            tabs[m].dit = base + ((size_t)m * 4 + 2) * n;
-            tabs[m].scale = base + ((size_t)m * 4 + 3) * n;
+            tabs[m].fwd = base + ((size_t)m * 3 + 0) * n;
+            tabs[m].dit = base + ((size_t)m * 3 + 1) * n;
+            tabs[m].scale = base + ((size_t)m * 3 + 2) * n;
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));

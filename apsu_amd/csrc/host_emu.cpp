@@ -55,12 +55,12 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
         // plain modulus irrelevant for the tables; pick any value < q
         hp = HeParams::Create(n, { q }, 65537 < q ? 65537 : 3);
         const NttTablesHost &t = hp.ntt[0];
-        std::vector<TwPair> fwd(n), inv(n), dit(n), sc(n);
+        std::vector<TwPair> fwd(n), dit(n), sc(n);
         for (size_t k = 0; k < n; k++) {
-            fwd[k] = { t.fwd[k], t.fwd_q[k] }; inv[k] = { t.inv[k], t.inv_q[k] };
+            fwd[k] = { t.fwd[k], t.fwd_q[k] };
             dit[k] = { t.dit[k], t.dit_q[k] }; sc[k] = { t.scale[k], t.scale_q[k] };
         }
-        NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), inv.data(), dit.data(), sc.data(),
+        NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), dit.data(), sc.data(),
                       ntt_is_narrow(q, logn) ? 1 : 0, 0 };
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
         switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }

@@ -20,8 +20,10 @@
 //   narrow moduli ((4*log2(n)+1)*q < 2^64, e.g. the 48..58-bit coefficient primes): the forward
 //     transform needs NO conditional subtraction at all (values grow by < 4q per stage) and ends with
 //     one Barrett reduction per coefficient;
-//   wide moduli (the 61-bit BEHZ primes): values live in [0,8q), one conditional subtraction per
-//     butterfly;  inverse (any modulus): values in [0,4q), one conditional subtraction per butterfly.
+//   wide moduli (the 61-bit BEHZ primes): values live in [0,8q), one conditional subtraction per butterfly.
+// The inverse is computed as a decimation-in-time CYCLIC inverse transform (bit-reversed input, natural
+// output, twiddles psi^(-j*n/g)) followed by the twist n^-1 * psi^-j, so it uses the very same butterfly
+// (x + w*y, x - w*y) and range discipline as the forward transform.
 // All of this is invisible in the results: outputs are canonical residues.
 // The pass functions are __host__ __device__ so tests can emulate a workgroup on the CPU.
 #pragma once
@@ -29,15 +31,14 @@
 
 struct TwPair { u64 w, wq; };          // twiddle and its Shoup quotient, 16 B -> one dwordx4 load
 
-// Per-modulus device tables.  fwd[k] = psi^brv(k), inv[k] = psi^-brv(k)  (k = m + i).
+// Per-modulus device tables.  fwd[k] = psi^brv(k)  (k = m + i).
 struct NttTable {
     u64 q;
     u64 ninv, ninv_q;                  // n^-1 mod q and its Shoup quotient
     u64 r1;                            // floor(2^64 / q): single-word Barrett ratio
     const TwPair *fwd;
-    const TwPair *inv;
-    // narrow moduli only: the inverse runs as a decimation-in-time cyclic transform with the psi^-j
-    // twist and n^-1 applied at the end (no conditional subtractions, same butterfly as the forward):
+    // the inverse runs as a decimation-in-time cyclic transform with the psi^-j twist and n^-1 applied at
+    // the end: same butterfly as the forward (no conditional subtractions for narrow moduli):
     const TwPair *dit;                 // dit[g + j] = psi^(-j*n/g), j < g, g = 1,2,4,..,n/2
     const TwPair *scale;               // scale[j] = n^-1 * psi^-j
     int narrow;                        // (4*logn+1)*q < 2^64
@@ -72,7 +73,7 @@ HD u64 mul_lazy4(u64 x, u64 w, u64 wq, u64 nq)
 enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
 
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
-//   forward: Cooley-Tukey, stages ascending; inverse: Gentleman-Sande, stages descending.
+//   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
 template <int LOGN, int S, int K, bool INV, bool NARROW, int IN, int OUT>
 HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
@@ -83,7 +84,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
     constexpr bool COLS = (1 << LOWBITS) >= G; // groups = adjacent columns (else adjacent blocks)
     constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;      // column groups per block
     constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);      // every lane of a wave shares the twiddles
-    const TwPair *__restrict__ W = INV ? tab.inv : tab.fwd;
+    const TwPair *__restrict__ W = tab.fwd;
     const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2;
 
     int block, c0;
@@ -139,7 +140,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (COLS && g > 0) continue;   // column groups share the twiddle: handled below
-                if (INV && NARROW) {
+                if (INV) {
                     // decimation-in-time butterfly of the cyclic inverse: twiddle depends on the position inside
                     // the block (row low bits and column), not on the block
 #pragma unroll
@@ -150,7 +151,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                         const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         const u64 v = mul_lazy4(y, tv[0], tv[1], nq);
-                        const u64 a = x;
+                        const u64 a = NARROW ? x : csub(x, q4);
                         x = a + v;
                         y = a - v + q4;
                     }
@@ -164,16 +165,10 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 for (int gg = 0; gg < G; gg++) {
                     if (!COLS && gg != g) continue;
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
-                    if (!INV) {
-                        const u64 v = mul_lazy4(y, t.w, t.wq, nq);
-                        const u64 a = NARROW ? x : csub(x, q4);
-                        x = a + v;
-                        y = a - v + q4;
-                    } else {
-                        const u64 a = x, b = y;
-                        x = csub(a + b, q4);
-                        y = mul_lazy4(a - b + q4, t.w, t.wq, nq);
-                    }
+                    const u64 v = mul_lazy4(y, t.w, t.wq, nq);
+                    const u64 a = NARROW ? x : csub(x, q4);
+                    x = a + v;
+                    y = a - v + q4;
                 }
             }
         }
@@ -185,11 +180,10 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 u64 v = r[g][j];
-                if (INV && NARROW) {
+                if (INV) {
                     const u64x2 sv = ldg16(reinterpret_cast<const u64 *>(tab.scale + idx(g, j)));
                     v = mul_shoup(v, sv[0], sv[1], q);
-                } else if (INV) v = mul_shoup(v, tab.ninv, tab.ninv_q, q);
-                else if (NARROW) { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }
+                } else if (NARROW) { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }
                 else v = csub(csub(csub(v, q4), q << 1), q);
                 r[g][j] = v;
             }
