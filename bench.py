@@ -92,6 +92,18 @@ def main():
     with open(os.path.join(ROOT, "tests", "params", args.config + ".json")) as f:
         params_json = f.read()
     ctx = apsu_amd.HeContext(params_json, device=local_rank)
+    proc_ntt = {"ms": 0.0, "launches": 0, "limbs": 0}           # every k_ntt launch of this process (rocprof cross-check)
+
+    def take_profile():
+        p = ctx.profile_read(reset=True)
+        for k in ("ntt_fwd", "ntt_inv"):
+            proc_ntt["ms"] += p[k][0]
+            proc_ntt["launches"] += p[k][1]
+            proc_ntt["limbs"] += p[k][2]
+        return p
+
+    if not args.no_profile:
+        ctx.profile_enable(2)                      # HIP events around the NTT launches only (the roofline kernel)
     n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
     Lf = first + 1
     wl = WORKLOADS[args.config]
@@ -150,8 +162,7 @@ def main():
         step()
     fence()
     if not args.no_profile:
-        ctx.profile_enable(2)                      # HIP events around the NTT launches only (the roofline kernel)
-        ctx.profile_read(reset=True)
+        take_profile()                             # setup + warm-up launches go to the process totals only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -159,14 +170,14 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = prof_all = None
     if not args.no_profile:
-        prof = ctx.profile_read(reset=True)
+        prof = take_profile()
         # per-kernel-class breakdown from two extra, untimed steps with events around every launch
         ctx.profile_enable(1)
         for _ in range(2):
             step()
         fence()
-        prof_all = ctx.profile_read(reset=True)
-        ctx.profile_enable(0)
+        prof_all = take_profile()
+        ctx.profile_enable(2)
     ms_local = elapsed * 1e3 / max(1, args.steps)
     ms_step = ms_local
     if world > 1:
@@ -217,12 +228,9 @@ def main():
             big = np.zeros((polys, Lf, n), dtype=np.uint64)
             big[:] = src_host[0, 0, 0]                                  # valid residues
             # tier-1 call moves data over PCIe; time only the kernel via the event profile
-            ctx.profile_enable(2)
-            ctx.profile_read(reset=True)
             ctx.transform_to_ntt_inplace(big, first)
             ctx.transform_from_ntt_inplace(big, first)
-            p2 = ctx.profile_read(reset=True)
-            ctx.profile_enable(0)
+            p2 = take_profile()
             ms = p2["ntt_fwd"][0] + p2["ntt_inv"][0]
             by = (p2["ntt_fwd"][2] + p2["ntt_inv"][2]) * 16 * n
             result["ntt_stream"] = {"limbs": polys * Lf, "bytes": int(by), "GBps": round(by / (ms * 1e-3) / 1e9, 1),
@@ -231,6 +239,20 @@ def main():
             del big
         except Exception as e:                                          # never lose the main line
             result["ntt_stream"] = {"error": str(e)}
+
+    if not args.no_profile and "roofline" in result:
+        ctx.profile_enable(0)
+        result["roofline"]["process_avg_launch_us"] = round(proc_ntt["ms"] * 1e3 / max(1, proc_ntt["launches"]), 2)
+        result["roofline"]["process_launches"] = proc_ntt["launches"]
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_ntt_traffic.json")) as f:
+                tr = json.load(f)
+            if tr.get("n") == n:
+                per_launch = result["roofline"]["limb_transforms_per_step"] / max(1e-9, result["roofline"]["launches_per_step"])
+                result["roofline"]["traffic"] = int(tr["hbm_bytes_per_limb"] * per_launch)
+                result["roofline"]["traffic_source"] = "profiles/r01_ntt_traffic.json (rocprofv3 PMC passes, FETCH_SIZE x2 corrected)"
+        except OSError:
+            pass
 
     # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
