@@ -164,6 +164,27 @@ int apsu_he_db_random_bundle(apsu_he_ctx *c, uint32_t bundle_idx, uint32_t cache
         *out = b;
     });
 }
+int apsu_he_db_build_bundle(apsu_he_ctx *c, uint32_t bundle_idx, uint32_t cache_idx, const uint64_t *roots, const uint32_t *counts,
+                            uint32_t bins, uint32_t stride, apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && counts && out && (roots || !bins), "null argument");
+        auto b = new apsu_he_bundle;
+        try { b->b = c->eng->build_bundle(bundle_idx, cache_idx, roots, counts, bins, stride); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
+int apsu_he_bundle_download(apsu_he_ctx *c, const apsu_he_bundle *b, uint32_t degree, uint64_t *out, size_t capacity_words,
+                            size_t *words, int *kind)
+{
+    return guarded([&] {
+        REQUIRE(c && b && out, "null argument");
+        size_t w = c->eng->download_coeff(*b->b, degree, out, capacity_words, kind);
+        if (words) *words = w;
+    });
+}
+int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree)
+{ return guarded([&] { REQUIRE(b && degree, "null argument"); *degree = b->b->degree; }); }
 int apsu_he_bundle_free(apsu_he_bundle *b) { return guarded([&] { delete b; }); }
 int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes)
 { return guarded([&] { REQUIRE(b && db_bytes, "null argument"); *db_bytes = b->b->db_bytes(); }); }

@@ -98,6 +98,11 @@ void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st
 // drop last limb of `polys` polynomials per job: src [polys][L][n] -> dst [polys][L-1][n]
 void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
+// N1: BinBundle build (polyn_with_roots per bin, BatchEncoder scatter, monomial detection)
+void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
+                             hipStream_t st);
+void launch_scatter_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st);
+void launch_flag_monomial(const u64 *pt, size_t n, int batch, unsigned char *flag, hipStream_t st);
 // BEHZ
 // ct c at in + c*in_stride holds `polys` polys [L][n]; out packed [c][polys][E][n]
 void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,

@@ -158,8 +158,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             HIP_CHECK(hipMemcpy(b.p(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
         };
         up(d_map_ext_, map_ext); up(d_map_ks_, map_ks); up(d_map_ksacc_, map_ksacc);
-        std::vector<int> ident(DMAXL + 1);
-        for (int i = 0; i <= DMAXL; i++) ident[i] = i;
+        std::vector<int> ident(DMAXL + DMAXB + 4);                     // identity over every modulus id (incl. plain modulus)
+        for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
         up(d_map_ct_, ident);
     }
     // key-switching constants
@@ -178,6 +178,10 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         }
         d_key_.alloc(sizeof(DevKey));
         HIP_CHECK(hipMemcpy(d_key_.p(), &k, sizeof(DevKey), hipMemcpyHostToDevice));
+    }
+    if (hp_.batching) {
+        d_slot_map_.alloc(hp_.slot_map.size() * sizeof(uint32_t));
+        HIP_CHECK(hipMemcpy(d_slot_map_.p(), hp_.slot_map.data(), hp_.slot_map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (has_psu_) {
         auto targets = create_powers_set(psu_.query_params.ps_low_degree, psu_.table_params.max_items_per_bin);
@@ -880,7 +884,44 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
 }
 
 
-// ============================================================================ tier 2: synthetic DB
+// ============================================================================ tier 2: BinBundle construction
+// raw = the batched polynomial's coefficient-form plaintexts [degree+1][n] mod t on the device.  Applies the
+// layout rule of the BatchedPlaintextPolyn ctor (bin_bundle.cpp:385-420): NTT-form coefficients are lifted
+// and transformed at pt_level; coefficient-form a_{i*h} are pre-lifted (honouring SEAL's monomial
+// shortcut of multiply_plain) and pre-NTT'd at the high level; a_0 stays raw.
+void Engine::finish_bundle(Bundle &b, const u64 *raw)
+{
+    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1, degree = b.degree;
+    const size_t n = hp_.n, Lpt = b.pt_level + 1;
+    const int high = hp_.clamp_chain_idx(1);
+    const size_t Lh = high + 1;
+    b.ntt.alloc(b.ntt_count * Lpt * n * sizeof(u64));
+    b.a0.alloc(n * sizeof(u64));
+    const size_t H = b.use_ps ? b.H : 0;
+    if (H) b.lifted.alloc(H * Lh * n * sizeof(u64));
+    D2D(b.a0.u(), raw, n);
+    unsigned char *flags = reinterpret_cast<unsigned char *>(ws((degree + 1 + 7) / 8 + 1));
+    launch_flag_monomial(raw, n, (int)degree + 1, flags, st_);
+    size_t slot = 0, hi = 0;
+    uint32_t d = 1;
+    while (d <= degree) {
+        const bool is_ntt = (!ps && d != 0) || (ps && (d % h) != 0);
+        uint32_t e = d;
+        while (e + 1 <= degree && (((!ps) || ((e + 1) % h) != 0) == is_ntt)) e++;
+        const size_t run = e - d + 1;
+        if (is_ntt) {
+            launch_lift(dlevel(b.pt_level), raw + (size_t)d * n, b.ntt.u() + slot * Lpt * n, n, (int)run, nullptr, st_);
+            slot += run;
+        } else if (H) {
+            launch_lift(dlevel(high), raw + (size_t)d * n, b.lifted.u() + hi * Lh * n, n, (int)run, flags + d, st_);
+            hi += run;
+        }
+        d = e + 1;
+    }
+    d_ntt_ct(b.ntt.u(), b.ntt_count, b.pt_level, false);
+    if (H) d_ntt_ct(b.lifted.u(), H, high, false);
+}
+
 std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed)
 {
     std::lock_guard<std::mutex> g(mu_);
@@ -891,41 +932,83 @@ std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cach
     b->bundle_idx = bundle_idx;
     b->cache_idx = cache_idx;
     bundle_shape(psu_, hp_, degree, *b);
-    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
-    const size_t n = hp_.n, Lpt = b->pt_level + 1;
-    const int high = hp_.clamp_chain_idx(1);
-    const size_t Lh = high + 1;
-    b->ntt.alloc(b->ntt_count * Lpt * n * sizeof(u64));
-    b->a0.alloc(n * sizeof(u64));
-    const size_t H = b->use_ps ? b->H : 0;
-    if (H) b->lifted.alloc(H * Lh * n * sizeof(u64));
-    // coefficient d of the batched polynomial = splitmix64 stream at offset d*n (mod t), coefficient form.
-    // The whole polynomial is generated in one launch, then lifted + NTT'd in runs of consecutive degrees.
+    const size_t n = hp_.n;
+    // coefficient d, index k of the batched polynomial = splitmix64 stream at offset d*n + k (mod t), coefficient form
     WITH_ARENA({
         u64 *raw = ws((size_t)(degree + 1) * n);
         launch_fill_random(raw, (size_t)(degree + 1) * n, seed, hp_.t, st_);
-        D2D(b->a0.u(), raw, n);
-        size_t slot = 0, hi = 0;
-        uint32_t d = 1;
-        while (d <= degree) {
-            const bool is_ntt = (!ps && d != 0) || (ps && (d % h) != 0);
-            uint32_t e = d;
-            while (e + 1 <= degree && (((!ps) || ((e + 1) % h) != 0) == is_ntt)) e++;
-            const size_t run = e - d + 1;
-            if (is_ntt) {
-                launch_lift(dlevel(b->pt_level), raw + (size_t)d * n, b->ntt.u() + slot * Lpt * n, n, (int)run, nullptr, st_);
-                slot += run;
-            } else if (H) {
-                launch_lift(dlevel(high), raw + (size_t)d * n, b->lifted.u() + hi * Lh * n, n, (int)run, nullptr, st_);
-                hi += run;
-            }
-            d = e + 1;
-        }
-        d_ntt_ct(b->ntt.u(), b->ntt_count, b->pt_level, false);
-        if (H) d_ntt_ct(b->lifted.u(), H, high, false);
+        finish_bundle(*b, raw);
         sync();
     });
     return b;
+}
+
+std::unique_ptr<Bundle> Engine::build_bundle(uint32_t bundle_idx, uint32_t cache_idx, const u64 *roots, const uint32_t *counts,
+                                             uint32_t bins, uint32_t stride)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    TIER1_SLOTS();
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
+    const size_t n = hp_.n;
+    if (bins > n) throw std::invalid_argument("more bins than batching slots");
+    if (bundle_idx >= psu_.bundle_idx_count) throw std::invalid_argument("bundle_idx out of range");
+    uint32_t degree = 0;
+    for (uint32_t s = 0; s < bins; s++) {
+        if (counts[s] > stride) throw std::invalid_argument("bin count exceeds stride");
+        degree = std::max(degree, counts[s]);
+    }
+    // a bin may hold at most max_items_per_bin - 1 items (receiver_db.cpp:388-389: insertion requires size < max)
+    if (degree > psu_.table_params.max_items_per_bin) throw std::invalid_argument("bin size exceeds max_items_per_bin");
+    for (uint32_t s = 0; s < bins; s++)
+        for (uint32_t r = 0; r < counts[s]; r++)
+            if (roots[(size_t)s * stride + r] >= hp_.t) throw std::invalid_argument("field element is not reduced modulo plain_modulus");
+    auto b = std::make_unique<Bundle>();
+    b->bundle_idx = bundle_idx;
+    b->cache_idx = cache_idx;
+    bundle_shape(psu_, hp_, degree, *b);
+    const int tid = hp_.plain_id();
+    WITH_ARENA({
+        u64 *droots = ws((size_t)bins * stride + 1);
+        uint32_t *dcounts = reinterpret_cast<uint32_t *>(ws((bins + 1) / 2 + 1));
+        if (bins) {
+            H2D(droots, roots, (size_t)bins * stride);
+            HIP_CHECK(hipMemcpyAsync(dcounts, counts, bins * sizeof(uint32_t), hipMemcpyHostToDevice, st_));
+        }
+        u64 *poly = ws((size_t)(degree + 1) * n);                  // [d][slot] slot values of the batched polynomial
+        launch_polyn_with_roots(droots, dcounts, bins, stride, degree, make_mod(hp_.t), poly, n, st_);
+        // BatchEncoder::encode (bin_bundle.cpp:409): slot permutation, then inverse negacyclic NTT mod t
+        u64 *raw = ws((size_t)(degree + 1) * n);
+        launch_scatter_slots(poly, reinterpret_cast<const uint32_t *>(d_slot_map_.p()), raw, n, (int)degree + 1, st_);
+        d_ntt(raw, degree + 1, map_ct() + tid, 1, true);
+        finish_bundle(*b, raw);
+        sync();
+    });
+    return b;
+}
+
+size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    sync();
+    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
+    const size_t n = hp_.n;
+    if (d > b.degree) throw std::invalid_argument("degree out of range");
+    const u64 *src;
+    size_t words;
+    int k;
+    const bool is_ntt = (!ps && d != 0) || (ps && (d % h) != 0);
+    if (d == 0) { src = b.a0.u(); words = n; k = 0; }
+    else if (is_ntt) { src = b.ntt.u() + (size_t)(d - (ps ? d / h : 0) - 1) * (b.pt_level + 1) * n; words = (size_t)(b.pt_level + 1) * n; k = 1; }
+    else {
+        if (!b.use_ps) throw std::invalid_argument("coefficient is not stored for this bundle");
+        const size_t Lh = hp_.clamp_chain_idx(1) + 1;
+        src = b.lifted.u() + (size_t)(d / h - 1) * Lh * n; words = Lh * n; k = 2;
+    }
+    if (capacity < words) throw std::invalid_argument("output buffer too small");
+    HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
+    if (kind) *kind = k;
+    return words;
 }
 
 // ============================================================================ tier 2: BinBundle evaluation

@@ -104,6 +104,13 @@ public:
     // Synthetic-DB helper for benchmarks: fills a bundle of the given degree with uniformly random
     // plaintext coefficients generated and transformed on the GPU (no host data).
     std::unique_ptr<Bundle> random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed);
+    // N1: BinBundle::regen_polyns + regen_plaintexts + BatchedPlaintextPolyn ctor on the GPU
+    // (bin_bundle.cpp:366-430,934-1026): roots[bin * stride + r], r < counts[bin], are the field elements of a bin.
+    std::unique_ptr<Bundle> build_bundle(uint32_t bundle_idx, uint32_t cache_idx, const u64 *roots, const uint32_t *counts,
+                                         uint32_t bins, uint32_t stride);
+    // test hook: stored form of coefficient d.  kind: 0 = raw mod t (d = 0), 1 = NTT form at pt_level,
+    // 2 = pre-lifted + NTT at the high level (coefficient-form a_{i*h}); returns words written
+    size_t download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind);
     // src[b * n_sources + s]: source power s (ascending power order) of bundle index bundle_indices[b],
     // size-2 coefficient-form ct at the first data level.  on_device: pointers are device pointers.
     std::unique_ptr<Powers> compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
@@ -178,6 +185,8 @@ private:
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_;
     void build_schedule();
+    void finish_bundle(Bundle &b, const u64 *raw);     // raw: [degree+1][n] coefficient-form plaintexts mod t (device)
+    DevBuf d_slot_map_;
 
     // profiling state
     struct ProfRec { hipEvent_t a, b; int kind; uint64_t units; };

@@ -342,6 +342,76 @@ void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t
     KERNEL_CHECK();
 }
 
+// ============================================================================ N1: BinBundle build on the GPU
+// polyn_with_roots (common/apsu/util/interpolate.cpp:27-80) for every bin of a BinBundle: one thread per
+// bin multiplies (x - a) into its monic polynomial, coefficients kept column-wise ([degree][slot], so the
+// accesses of a wave are coalesced).  Bins beyond `bins` and degrees beyond a bin's count hold 0
+// (BatchedPlaintextPolyn ctor, bin_bundle.cpp:395-405).
+__global__ __launch_bounds__(EW_T) void k_polyn_with_roots(const u64 *__restrict__ roots, const u32 *__restrict__ counts,
+                                                           u32 bins, u32 stride, u32 max_deg, Mod t, u64 *__restrict__ poly, size_t n)
+{
+    const size_t s = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (s >= n) return;
+    u64 *P = poly + s;                                          // P[d * n]
+    for (u32 d = 0; d <= max_deg; d++) P[(size_t)d * n] = 0;
+    if (s >= bins) return;
+    const u32 cnt = counts[s];
+    P[0] = 1;
+    for (u32 r = 0; r < cnt; r++) {
+        const u64 a = roots[(size_t)s * stride + r];
+        const u64 neg_a = a ? t.q - a : 0;
+        // P'[i] = P[i-1] + (-a) * P[i], right to left; P'[0] = (-a) * P[0]
+        for (u32 i = r + 1; i > 0; i--)
+            P[(size_t)i * n] = addmod(mulmod(P[(size_t)i * n], neg_a, t), P[(size_t)(i - 1) * n], t.q);
+        P[0] = mulmod(P[0], neg_a, t);
+    }
+}
+
+void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
+                             hipStream_t st)
+{
+    hipLaunchKernelGGL(k_polyn_with_roots, dim3((unsigned)((n + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, roots, counts, bins, stride,
+                       max_deg, t, poly, n);
+    KERNEL_CHECK();
+}
+
+// BatchEncoder::encode, first half (App. B4): out[b][slot_map[i]] = in[b][i]; the inverse NTT mod t follows
+__global__ __launch_bounds__(EW_T) void k_scatter_slots(const u64 *__restrict__ in, const u32 *__restrict__ slot_map,
+                                                        u64 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (i >= n) return;
+    const size_t b = blockIdx.y;
+    out[b * n + slot_map[i]] = in[b * n + i];
+}
+
+void launch_scatter_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st)
+{
+    if (!batch) return;
+    hipLaunchKernelGGL(k_scatter_slots, ew_grid(n, batch), dim3(EW_T), 0, st, in, slot_map, out, n);
+    KERNEL_CHECK();
+}
+
+// flag[b] = 1 iff plaintext b has exactly one non-zero coefficient (SEAL's monomial shortcut in multiply_plain)
+__global__ __launch_bounds__(EW_T) void k_flag_monomial(const u64 *__restrict__ pt, size_t n, unsigned char *__restrict__ flag)
+{
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    unsigned int local = 0;
+    for (size_t k = threadIdx.x; k < n; k += EW_T) local += pt[(size_t)blockIdx.x * n + k] != 0;
+    atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) flag[blockIdx.x] = cnt == 1 ? 1 : 0;
+}
+
+void launch_flag_monomial(const u64 *pt, size_t n, int batch, unsigned char *flag, hipStream_t st)
+{
+    if (!batch) return;
+    hipLaunchKernelGGL(k_flag_monomial, dim3((unsigned)batch), dim3(EW_T), 0, st, pt, n, flag);
+    KERNEL_CHECK();
+}
+
 // K9: try_clear_irrelevant_bits (bin_bundle.cpp:67-97)
 __global__ __launch_bounds__(EW_T) void k_clear_bits(u64 *__restrict__ ct, size_t words, u64 mask)
 {

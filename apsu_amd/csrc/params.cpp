@@ -517,6 +517,20 @@ HeParams HeParams::Create(size_t n, const std::vector<u64> &coeff_modulus, u64 p
     hp.aux_primes = get_primes(2 * (u64)n, 61, (size_t)maxL + 3);
     for (u64 q : hp.key_q) hp.ntt.push_back(make_ntt_tables(q, n, hp.logn));
     for (u64 q : hp.aux_primes) hp.ntt.push_back(make_ntt_tables(q, n, hp.logn));
+    if (plain_modulus > 1 && (plain_modulus - 1) % (2 * (u64)n) == 0 && is_prime_u64(plain_modulus)) {
+        // BatchEncoder tables [SEAL-recall batchencoder.cpp]: NTT mod t and matrix_reps_index_map (generator 3)
+        hp.batching = true;
+        hp.ntt.push_back(make_ntt_tables(plain_modulus, n, hp.logn));
+        hp.slot_map.resize(n);
+        const u64 m = 2 * (u64)n;
+        u64 pos = 1;
+        const size_t row = n >> 1;
+        for (size_t i = 0; i < row; i++) {
+            hp.slot_map[i] = bit_reverse((u32)((pos - 1) >> 1), hp.logn);
+            hp.slot_map[row | i] = bit_reverse((u32)((m - pos - 1) >> 1), hp.logn);
+            pos = (pos * 3) & (m - 1);
+        }
+    }
     for (int c = 0; c <= hp.first_chain_idx; c++) hp.level.push_back(make_level(hp, c + 1));
     if (hp.K > 1) {
         u64 p = hp.key_q[hp.K - 1];

@@ -111,6 +111,10 @@ struct HeParams {
     std::vector<LevelConstants> level;  // indexed by chain_idx, 0..first_chain_idx
     std::vector<u64> inv_p_mod_q;       // special prime^-1 mod q_j  (B10)
     int irrelevant_bit_count = 0;       // bin_bundle.cpp:67-97
+    // BatchEncoder (App. B4), only when t = 1 (mod 2n): modulus id plain_id() in `ntt`, slot -> coefficient map
+    bool batching = false;
+    std::vector<uint32_t> slot_map;     // matrix_reps_index_map
+    int plain_id() const { return K + (int)aux_primes.size(); }
 
     static HeParams Create(size_t n, const std::vector<u64> &coeff_modulus, u64 plain_modulus);
     static HeParams FromPSUParams(const PSUParams &p);

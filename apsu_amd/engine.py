@@ -289,6 +289,31 @@ class HeContext:
                                                        C.byref(h)))
         return Bundle(self, h, bundle_idx, cache_idx, len(keep) - 1)
 
+    def build_bundle(self, bundle_idx, cache_idx, bins):
+        """BinBundle::regen_cache on the GPU.  bins: list (one per bin / slot) of lists of field elements."""
+        nb = len(bins)
+        stride = max([len(b) for b in bins] + [1])
+        roots = np.zeros((max(nb, 1), stride), dtype=np.uint64)
+        counts = np.zeros(max(nb, 1), dtype=np.uint32)
+        for i, b in enumerate(bins):
+            counts[i] = len(b)
+            roots[i, :len(b)] = b
+        h = C.c_void_p()
+        _check(load_library().apsu_he_db_build_bundle(self.h, bundle_idx, cache_idx, _p(roots), C.c_void_p(counts.ctypes.data),
+                                                      nb, stride, C.byref(h)))
+        deg = C.c_uint32()
+        _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
+        return Bundle(self, h, bundle_idx, cache_idx, deg.value)
+
+    def bundle_coeff(self, bundle, degree):
+        """test hook -> (array, kind): kind 0 raw mod t, 1 NTT form [L][n], 2 pre-lifted NTT at the high level"""
+        buf = np.empty((self.first_chain_idx + 1) * self.n, dtype=np.uint64)
+        words, kind = C.c_size_t(), C.c_int()
+        _check(load_library().apsu_he_bundle_download(self.h, bundle.h, degree, _p(buf), C.c_size_t(buf.size), C.byref(words),
+                                                      C.byref(kind)))
+        w = words.value
+        return (buf[:w].copy() if kind.value == 0 else buf[:w].reshape(-1, self.n).copy()), kind.value
+
     def random_bundle(self, bundle_idx, cache_idx, degree, seed):
         h = C.c_void_p()
         _check(load_library().apsu_he_db_random_bundle(self.h, bundle_idx, cache_idx, degree, C.c_uint64(seed), C.byref(h)))

@@ -122,6 +122,18 @@ int apsu_he_db_upload_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cac
  * form, mod t) = splitmix64_mix(seed + (d*n + k + 1) * 0x9e3779b97f4a7c15) % t; generated on the GPU. */
 int apsu_he_db_random_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, uint64_t seed,
                              apsu_he_bundle **out);
+/* "next" row N1: BinBundle::regen_polyns + regen_plaintexts on the GPU
+ * (bin_bundle.cpp:934-1026 -> polyn_with_roots, common/apsu/util/interpolate.cpp:63-80 -> BatchedPlaintextPolyn
+ * ctor bin_bundle.cpp:366-430: BatchEncoder::encode, transform_to_ntt).  roots[bin*stride + r], r < counts[bin],
+ * are the field elements (mod plain_modulus) stored in bin `bin`; bins <= poly_modulus_degree; empty bins give the
+ * polynomial 1.  The result is identical to uploading the reference-built cache with apsu_he_db_upload_bundle. */
+int apsu_he_db_build_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cache_idx, const uint64_t *roots,
+                            const uint32_t *counts, uint32_t bins, uint32_t stride, apsu_he_bundle **out);
+/* test hooks: degree of the batched polynomial; stored form of coefficient `degree`
+ * (kind 0: raw mod t [n]; 1: NTT form [(plain_level+1)*n]; 2: pre-lifted + NTT at the high level [(high+1)*n]) */
+int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);
+int apsu_he_bundle_download(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint32_t degree, uint64_t *out, size_t capacity_words,
+                            size_t *words, int *kind);
 int apsu_he_bundle_free(apsu_he_bundle *b);
 int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes);
 /* Receiver::ComputePowers for n_bundle_idx bundle indices at once (receiver_osn.cpp:320-328,395-488).

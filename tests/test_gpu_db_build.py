@@ -1,0 +1,140 @@
+"""GPU tier: the "next" row N1 — BinBundle::regen_polyns / regen_plaintexts / BatchedPlaintextPolyn
+ctor on the GPU (apsu_he_db_build_bundle) against the oracle's polyn_with_roots + BatchEncoder + lift/NTT,
+coefficient by coefficient and end to end through eval."""
+import numpy as np
+import pytest
+
+import apsu_amd
+import common
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_build(C, ps_low, bins):
+    """reference semantics: per-bin monic polynomial with the bin's items as roots (interpolate.cpp:63-80),
+    coefficient d of every bin batched into one plaintext (bin_bundle.cpp:395-430)"""
+    n = C.n
+    deg = max([len(b) for b in bins] + [0])
+    A = np.zeros((deg + 1, n), dtype=np.uint64)
+    for s, b in enumerate(bins):
+        p = C.polyn_with_roots(np.array(b, dtype=np.uint64)) if len(b) else np.array([1], dtype=np.uint64)
+        A[:len(p), s] = p
+    pci = C.plain_chain_idx(ps_low)
+    coeffs, flags = [], []
+    for d in range(deg + 1):
+        enc = C.encode(A[d])
+        ntt = ref.coeff_is_ntt(ps_low, d)
+        coeffs.append(C.plain_lift_ntt(enc, pci) if ntt else enc)
+        flags.append(ntt)
+    return A, coeffs, flags
+
+
+def check_build(js, bins, bundle_idx=0):
+    p = ref.load_params(js)
+    C = ref.RefContext.from_params(p)
+    ps = p["ps_low_degree"]
+    A, coeffs, flags = oracle_build(C, ps, bins)
+    G = apsu_amd.HeContext(js)
+    gb = G.build_bundle(bundle_idx, 0, bins)
+    deg = len(coeffs) - 1
+    assert gb.degree == deg
+    use_ps = ps > 1 and ps < deg
+    high = C.clamp(1)
+    for d in range(deg + 1):
+        if d > 0 and not flags[d] and not use_ps:
+            continue
+        got, kind = G.bundle_coeff(gb, d)
+        if d == 0:
+            assert kind == 0 and (got == coeffs[0]).all()
+        elif flags[d]:
+            assert kind == 1 and (got == coeffs[d]).all(), "NTT-form coefficient %d" % d
+        else:
+            # what multiply_plain (bin_bundle.cpp:334) derives from the coefficient-form plaintext at the high level
+            nz = np.count_nonzero(coeffs[d])
+            exp = C.plain_lift_ntt(coeffs[d], high)
+            if nz == 1:                                   # monomial shortcut: no lift
+                raw = np.tile(coeffs[d], (high + 1, 1))
+                exp = raw.reshape(1, high + 1, C.n).copy()
+                C.transform_to_ntt(exp, high)
+                exp = exp[0]
+            assert kind == 2 and (got == exp).all(), "coefficient-form coefficient %d" % d
+    return C, G, gb, A, coeffs, flags
+
+
+def rand_bins(rng, t, n_bins, max_count, full_frac=0.3):
+    bins = []
+    for s in range(n_bins):
+        c = max_count if rng.random() < full_frac else int(rng.integers(0, max_count + 1))
+        bins.append([int(v) for v in rng.choice(t - 1, size=c, replace=False) + 1])
+    return bins
+
+
+def test_build_toy_ragged_bins():
+    rng = np.random.default_rng(5)
+    js = common.toy_json()
+    t = ref.RefContext.from_params(ref.load_params(js)).t
+    bins = rand_bins(rng, t, 60, 10)                      # 60 of 64 slots are bins, 4 stay unused
+    bins[3] = []                                          # empty bin -> polynomial 1
+    bins[7] = [0]                                         # root 0
+    check_build(js, bins)
+
+
+def test_build_all_bins_same_size_monomial_leading_coefficient():
+    # every slot holds exactly h = 4 items: a_4 is the all-ones vector -> constant plaintext (monomial)
+    rng = np.random.default_rng(6)
+    js = common.toy_json()
+    t = ref.RefContext.from_params(ref.load_params(js)).t
+    bins = [[int(v) for v in rng.choice(t - 1, size=4, replace=False) + 1] for _ in range(64)]
+    bins2 = [b + [int(rng.integers(1, t))] * 0 for b in bins]
+    check_build(js, bins2)
+    # degree 8 = 2h: a_8 all ones again, a_4 generic
+    bins3 = [[int(v) for v in rng.choice(t - 1, size=8, replace=False) + 1] for _ in range(64)]
+    check_build(js, bins3)
+
+
+def test_build_without_paterson_stockmeyer():
+    rng = np.random.default_rng(7)
+    js = common.toy_json(ps_low=0, max_items=6, query_powers=(1, 2, 3, 5))
+    t = ref.RefContext.from_params(ref.load_params(js)).t
+    check_build(js, rand_bins(rng, t, 64, 6))
+
+
+def test_build_1M_params_and_evaluate():
+    """GPU-built BinBundle evaluates to the same ciphertext as the oracle-built one, and members decrypt to the mask"""
+    rng = np.random.default_rng(8)
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: []})
+    C = S.C
+    n_bins = S.p["items_per_bundle"] * S.p["felts_per_item"]
+    bins = rand_bins(rng, C.t, n_bins, 60, full_frac=0.1)
+    for s in range(0, n_bins, 2):                         # make the query value a member of every other bin
+        if bins[s]:
+            bins[s][0] = int(S.x[0][s])
+    C2, G, gb, A, coeffs, flags = check_build(js, bins)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    mask_vals = ref.fill_uniform(9, C.t, C.n)
+    mask = C.encode(mask_vals)
+    out = G.eval_bundles([gb], pw, rk, [mask])
+    opw = common.oracle_powers(S)
+    bundle = dict(bundle_idx=0, cache_idx=0, degree=len(coeffs) - 1, A=A, coeffs=coeffs, flags=flags, mask_vals=mask_vals, mask=mask)
+    assert (out[0] == common.oracle_eval(S, opw, bundle)).all()
+    ok, budget = common.check_semantics(S, bundle, out[0])
+    assert ok and budget > 0
+    got = C.decode(C.decrypt(S.sk, out[0], 0)[0])
+    members = [s for s in range(0, n_bins, 2) if bins[s]]
+    assert (got[members] == mask_vals[members]).all()
+    G.close()
+
+
+def test_build_rejects_bad_input():
+    js = common.toy_json()
+    G = apsu_amd.HeContext(js)
+    with pytest.raises(ValueError):
+        G.build_bundle(0, 0, [[1, 2]] * 65)               # more bins than slots
+    with pytest.raises(ValueError):
+        G.build_bundle(0, 0, [[G.t]])                     # unreduced field element
+    with pytest.raises(ValueError):
+        G.build_bundle(0, 0, [list(range(1, 14))])        # bin larger than max_items_per_bin
+    G.close()
