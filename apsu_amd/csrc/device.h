@@ -47,6 +47,14 @@ struct DevLevel {
     ShoupConst inv_prod_B_msk;
     u64 prod_B_q[DMAXL], neg_prod_B_q[DMAXL];
     u64 msk_half;
+    // the same matrices as Shoup constants for the fully unrolled kernels (L = nB <= 3): every product is a
+    // lazy Shoup product (< 2m), sums stay below 8m < 2^64 and are reduced once
+    ShoupConst s_q_to_bsk[DMAXB][DMAXL];
+    ShoupConst s_prod_q_bsk[DMAXB];
+    ShoupConst s_fl[DMAXB];                     // i < nB: (Q^-1 * (B/b_i)^-1) mod b_i ; i = nB: Q^-1 mod m_sk
+    ShoupConst s_B_to_q[DMAXL][DMAXB];
+    ShoupConst s_B_to_msk[DMAXB];
+    ShoupConst s_prod_B_q[DMAXL], s_neg_prod_B_q[DMAXL];
 };
 
 // Key-switching constants (App. B10); moduli indexed by key limb.

@@ -123,7 +123,9 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 d.t_inv_punct_q[j] = shoup_const(mj.mul(hp_.t % qj, h.inv_punct_q[j]), qj);
                 d.prod_B_q[j] = h.prod_B_mod_q[j];
                 d.neg_prod_B_q[j] = (qj - h.prod_B_mod_q[j]) % qj;
-                for (int i = 0; i < nB; i++) d.B_to_q[j][i] = h.B_to_q[j][i];
+                d.s_prod_B_q[j] = shoup_const(d.prod_B_q[j], qj);
+                d.s_neg_prod_B_q[j] = shoup_const(d.neg_prod_B_q[j], qj);
+                for (int i = 0; i < nB; i++) { d.B_to_q[j][i] = h.B_to_q[j][i]; d.s_B_to_q[j][i] = shoup_const(h.B_to_q[j][i], qj); }
                 map_ext[(size_t)c * DMAXE + j] = j;
             }
             d.neg_inv_q_mt = (u32)h.neg_inv_q_mod_mtilde;
@@ -131,14 +133,17 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 const u64 m = bsk[i];
                 d.bsk[i] = make_mod(m);
                 d.ext[L + i] = d.bsk[i];
-                for (int j = 0; j < L; j++) d.q_to_bsk[i][j] = h.q_to_bsk[i][j];
+                for (int j = 0; j < L; j++) { d.q_to_bsk[i][j] = h.q_to_bsk[i][j]; d.s_q_to_bsk[i][j] = shoup_const(h.q_to_bsk[i][j], m); }
                 d.prod_q_bsk[i] = h.prod_q_mod_bsk[i];
+                d.s_prod_q_bsk[i] = shoup_const(h.prod_q_mod_bsk[i], m);
+                d.s_fl[i] = shoup_const(i < nB ? ModulusInfo(m).mul(h.inv_prod_q_mod_bsk[i], h.inv_punct_B[i]) : h.inv_prod_q_mod_bsk[i], m);
                 d.inv_mt_bsk[i] = shoup_const(h.inv_mtilde_mod_bsk[i], m);
                 d.t_bsk[i] = shoup_const(hp_.t % m, m);
                 d.inv_prod_q_bsk[i] = shoup_const(h.inv_prod_q_mod_bsk[i], m);
                 if (i < nB) {
                     d.inv_punct_B[i] = shoup_const(h.inv_punct_B[i], m);
                     d.B_to_msk[i] = h.B_to_msk[i];
+                    d.s_B_to_msk[i] = shoup_const(h.B_to_msk[i], h.m_sk);
                 }
                 map_ext[(size_t)c * DMAXE + L + i] = hp_.bsk_id(nB, i);
             }

@@ -477,13 +477,51 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext(const DevLevel *__restrict__ 
     }
 }
 
+HD u64 lazy2(u64 x, const ShoupConst &c, u64 q) { return mul_shoup_lazy(x, c.w, c.wq, q); }      // x*c mod q in [0,2q), any x
+
+// Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices: same values, ~35 % fewer multiplies.
+template <int TL>
+__global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
+                                                    size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    constexpr int L = TL, nBsk = TL + 1, E = 2 * TL + 1;
+    const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
+    const u64 *src = in + c * in_stride + p * (size_t)L * n;
+    u64 *dst = out + (size_t)blockIdx.y * E * n;
+    u64 xs[L];
+    u32 mt_acc = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const u64 x = src[(size_t)j * n + k];
+        dst[(size_t)j * n + k] = x;
+        xs[j] = mul_shoup(x, lv->ext_scale[j].w, lv->ext_scale[j].wq, lv->q[j].q);     // canonical: used as an integer
+        mt_acc += (u32)xs[j] * lv->q_to_mt[j];
+    }
+    const u32 r32 = mt_acc * lv->neg_inv_q_mt;
+#pragma unroll
+    for (int i = 0; i < nBsk; i++) {
+        const u64 m = lv->bsk[i].q;
+        u64 r = r32;
+        if (r32 >= 0x80000000u) r += m - ((u64)1 << 32);          // centred lift of r into Z_m
+        u64 v = lazy2(r, lv->s_prod_q_bsk[i], m);                 // (2L + 2) m <= 8 m < 2^64
+#pragma unroll
+        for (int j = 0; j < L; j++) v += lazy2(xs[j], lv->s_q_to_bsk[i][j], m);
+        dst[(size_t)(L + i) * n + k] = mul_shoup(v, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m);
+    }
+}
+
 void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st)
 {
     if (!cts) return;
     const dim3 g = ew_grid(n, cts * polys), t(EW_T);
+#define EXT2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext2<TL>), g, t, 0, st, lv, in, in_stride, polys, out, n); KERNEL_CHECK(); return; }
+    EXT2_CASE(1) EXT2_CASE(2) EXT2_CASE(3)
+#undef EXT2_CASE
 #define EXT_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext<TL, TL>), g, t, 0, st, lv, in, in_stride, polys, out, n); } else
-    EXT_CASE(1) EXT_CASE(2) EXT_CASE(3) EXT_CASE(4)
+    EXT_CASE(4)
     { hipLaunchKernelGGL((k_behz_ext<0, 0>), g, t, 0, st, lv, in, in_stride, polys, out, n); }
 #undef EXT_CASE
     KERNEL_CHECK();
@@ -597,13 +635,78 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict
         if (TL || j < L) o[(size_t)j * n] = sum[j];
 }
 
+// Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices (same values as behz_finish_coeff).
+template <int TL>
+__device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ lv, const u64 *__restrict__ d, size_t n, u64 *res)
+{
+    constexpr int L = TL, nB = TL, nBsk = TL + 1;
+    u64 xq[L];
+#pragma unroll
+    for (int j = 0; j < L; j++)                                  // canonical: used as integers by the base conversion
+        xq[j] = mul_shoup(d[(size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    u64 ys[nB];
+    u64 fl_sk = 0;
+#pragma unroll
+    for (int i = 0; i < nBsk; i++) {
+        const u64 m = lv->bsk[i].q;
+        u64 conv = 0;                                            // < 2 L m
+#pragma unroll
+        for (int j = 0; j < L; j++) conv += lazy2(xq[j], lv->s_q_to_bsk[i][j], m);
+        const u64 xb = lazy2(d[(size_t)(L + i) * n], lv->t_bsk[i], m);
+        const u64 diff = xb + ((u64)(2 * L) * m - conv);         // < (2L + 2) m <= 8 m < 2^64
+        const u64 f = mul_shoup(diff, lv->s_fl[i].w, lv->s_fl[i].wq, m);      // i < nB: already times (B/b_i)^-1
+        if (i < nB) ys[i] = f; else fl_sk = f;
+    }
+    const u64 msk = lv->bsk[nB].q;
+    u64 z_sk = msk - fl_sk;                                      // (z - fl_sk) mod m_sk, lazily
+#pragma unroll
+    for (int i = 0; i < nB; i++) z_sk += lazy2(ys[i], lv->s_B_to_msk[i], msk);
+    const u64 alpha = mul_shoup(z_sk, lv->inv_prod_B_msk.w, lv->inv_prod_B_msk.wq, msk);
+    const bool neg = alpha > lv->msk_half;
+    const u64 a_abs = neg ? msk - alpha : alpha;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const u64 q = lv->q[j].q;
+        u64 z = lazy2(a_abs, neg ? lv->s_prod_B_q[j] : lv->s_neg_prod_B_q[j], q);       // < (2 nB + 2) q <= 8 q
+#pragma unroll
+        for (int i = 0; i < nB; i++) z += lazy2(ys[i], lv->s_B_to_q[j][i], q);
+        res[j] = csub(csub(csub(z, q << 2), q << 1), q);
+    }
+}
+
+template <int TL>
+__global__ __launch_bounds__(EW_T) void k_behz_finish2(const DevLevel *__restrict__ lv, const FinishJob *__restrict__ jobs,
+                                                       int accumulate, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    constexpr int L = TL, E = 2 * TL + 1;
+    const FinishJob job = jobs[blockIdx.y / 3];
+    const size_t p = blockIdx.y % 3;
+    u64 sum[L];
+    u64 *o = job.out + p * (size_t)L * n + k;
+#pragma unroll
+    for (int j = 0; j < L; j++) sum[j] = accumulate ? o[(size_t)j * n] : 0;
+    for (int i = 0; i < job.terms; i++) {
+        u64 res[L];
+        behz_finish_coeff2<TL>(lv, job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k, n, res);
+#pragma unroll
+        for (int j = 0; j < L; j++) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
+    }
+#pragma unroll
+    for (int j = 0; j < L; j++) o[(size_t)j * n] = sum[j];
+}
+
 void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st)
 {
     if (!njobs) return;
     const dim3 g = ew_grid(n, njobs * 3), t(EW_T);
     const int acc = accumulate ? 1 : 0;
+#define FIN2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_finish2<TL>), g, t, 0, st, lv, jobs, acc, n); KERNEL_CHECK(); return; }
+    FIN2_CASE(1) FIN2_CASE(2) FIN2_CASE(3)
+#undef FIN2_CASE
 #define FIN_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_finish<TL, TL>), g, t, 0, st, lv, jobs, acc, n); } else
-    FIN_CASE(1) FIN_CASE(2) FIN_CASE(3) FIN_CASE(4)
+    FIN_CASE(4)
     { hipLaunchKernelGGL((k_behz_finish<0, 0>), g, t, 0, st, lv, jobs, acc, n); }
 #undef FIN_CASE
     KERNEL_CHECK();
