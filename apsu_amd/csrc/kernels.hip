@@ -715,17 +715,23 @@ void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs
 // ============================================================================ K6: relinearize (key switch of c2)
 // relinearize_inplace (receiver_osn.cpp:431 ; bin_bundle.cpp:309), App. B10.
 // decomp: out[b][I][J][k] = c2[b][J][k] mod m_I  for target modulus I in {q_0..q_{L-1}, p}, J < L
-__global__ __launch_bounds__(EW_T) void k_ks_decomp(const DevKey *__restrict__ key, int L, const u64 *__restrict__ c2,
+template <int TL>
+__global__ __launch_bounds__(EW_T) void k_ks_decomp(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ c2,
                                                     size_t c2_stride, u64 *__restrict__ out, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
     const size_t b = blockIdx.y;
+    const int L = TL ? TL : Lrt;
     const u64 *src = c2 + b * c2_stride;
     u64 *dst = out + b * (size_t)(L + 1) * L * n;
-    for (int J = 0; J < L; J++) {
+#pragma unroll
+    for (int J = 0; J < (TL ? TL : DMAXL); J++) {
+        if (!TL && J >= L) continue;
         const u64 v = src[J * n + k];
-        for (int I = 0; I <= L; I++) {
+#pragma unroll
+        for (int I = 0; I <= (TL ? TL : DMAXL); I++) {
+            if (!TL && I > L) continue;
             const Mod m = key->q[I == L ? key->K - 1 : I];
             dst[((size_t)I * L + J) * n + k] = barrett64(v, m);
         }
@@ -735,25 +741,33 @@ __global__ __launch_bounds__(EW_T) void k_ks_decomp(const DevKey *__restrict__ k
 void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
                       hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ks_decomp, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n);
+#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_decomp<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n); break;
+    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_decomp<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n); }
+#undef KS_CASE
     KERNEL_CHECK();
 }
 
 // inner product with the key: acc[b][comp][I][k] = sum_J tdec[b][I][J][k] * rk[J][comp][id(I)][k] mod m_I
-__global__ __launch_bounds__(EW_T) void k_ks_inner(const DevKey *__restrict__ key, int L, const u64 *__restrict__ tdec,
+template <int TL>
+__global__ __launch_bounds__(EW_T) void k_ks_inner(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ tdec,
                                                    const u64 *__restrict__ rk, u64 *__restrict__ acc, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
     const size_t b = blockIdx.y;
+    const int L = TL ? TL : Lrt;
     const int K = key->K;
     const u64 *td = tdec + b * (size_t)(L + 1) * L * n;
     u64 *o = acc + b * (size_t)2 * (L + 1) * n;
-    for (int I = 0; I <= L; I++) {
+#pragma unroll
+    for (int I = 0; I <= (TL ? TL : DMAXL); I++) {
+        if (!TL && I > L) continue;
         const int ki = I == L ? K - 1 : I;
         const Mod m = key->q[ki];
         u128p a0{ 0, 0 }, a1{ 0, 0 };
-        for (int J = 0; J < L; J++) {
+#pragma unroll
+        for (int J = 0; J < (TL ? TL : DMAXL); J++) {
+            if (!TL && J >= L) continue;
             const u64 tv = td[((size_t)I * L + J) * n + k];
             mac128(a0, tv, rk[(((size_t)J * 2 + 0) * K + ki) * n + k]);
             mac128(a1, tv, rk[(((size_t)J * 2 + 1) * K + ki) * n + k]);
@@ -766,24 +780,31 @@ __global__ __launch_bounds__(EW_T) void k_ks_inner(const DevKey *__restrict__ ke
 void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
                      hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ks_inner, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, tdec, rk, acc, n);
+#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_inner<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, tdec, rk, acc, n); break;
+    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_inner<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, tdec, rk, acc, n); }
+#undef KS_CASE
     KERNEL_CHECK();
 }
 
 // mod-down by the special prime with rounding and add into (c0, c1):
 // acc: [batch][2][L+1][n] coefficient form ; ct[b]: [>=2][L][n] at stride ct_stride
-__global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ key, int L, const u64 *__restrict__ acc,
+template <int TL>
+__global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ acc,
                                                      u64 *__restrict__ ct, size_t ct_stride, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
     const size_t b = blockIdx.y;
+    const int L = TL ? TL : Lrt;
     const Mod pm = key->q[key->K - 1];
+#pragma unroll
     for (int comp = 0; comp < 2; comp++) {
         const u64 *a = acc + (b * 2 + comp) * (size_t)(L + 1) * n;
         u64 *c = ct + b * ct_stride + (size_t)comp * L * n;
         const u64 tl = barrett64(a[(size_t)L * n + k] + key->p_half, pm);
-        for (int j = 0; j < L; j++) {
+#pragma unroll
+        for (int j = 0; j < (TL ? TL : DMAXL); j++) {
+            if (!TL && j >= L) continue;
             const Mod m = key->q[j];
             const u64 tk = submod(barrett64(tl, m), key->p_half_mod[j], m.q);
             const u64 v = mul_shoup(submod(a[(size_t)j * n + k], tk, m.q), key->inv_p[j].w, key->inv_p[j].wq, m.q);
@@ -795,7 +816,9 @@ __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ 
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
                        hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ks_moddown, ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n);
+#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n); break;
+    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_moddown<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n); }
+#undef KS_CASE
     KERNEL_CHECK();
 }
 
