@@ -283,9 +283,19 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
     sources = sorted(p["query_powers"])
     b0, ci0, deg0 = mine[0]
     srcs = {e: np.ascontiguousarray(src_host[b0, s]) for s, e in enumerate(sources)}
+    ref.set_threads(1)
     t0 = time.perf_counter()
     pw = C.compute_powers(srcs, nodes, rk_host, ps)
     powers_ms = (time.perf_counter() - t0) * 1e3
+    # the reference's thread pool (-t): one task per DAG node; BinBundles are one task each (receiver_osn.cpp:334-364)
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    powers_ms_t = powers_ms
+    if threads > 1:
+        ref.set_threads(threads)
+        t0 = time.perf_counter()
+        C.compute_powers(srcs, nodes, rk_host, ps)
+        powers_ms_t = (time.perf_counter() - t0) * 1e3
+        ref.set_threads(1)
     # host replica of the synthetic BinBundle (DB build: not timed)
     seed = SEED0 + 1000003 * b0 + 7919 * ci0
     pci = C.plain_chain_idx(ps)
@@ -313,6 +323,10 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
                       "whole query extrapolated = %d x powers + sum over %d BinBundles scaled by degree; CPU restatement of "
                       "SEAL (oracle/), not Microsoft SEAL" % (nb, powers_ms, deg0, bundle_ms, nb, len(units)),
             "powers_ms_per_bundle_idx": round(powers_ms, 1), "bundle_ms": round(bundle_ms, 1),
+            "threads_probe": {"threads": threads, "powers_ms_per_bundle_idx": round(powers_ms_t, 1),
+                              "query_ms_estimate": round(powers_ms_t * nb + -(-len(units) // threads) * bundle_ms, 1),
+                              "note": "ComputePowers measured with one OpenMP task per DAG node; BinBundle tasks are independent "
+                                      "single-thread jobs, so their wall time is ceil(#BinBundles / threads) x bundle_ms (estimate)"},
             "gpu_result_bit_exact_vs_cpu": bit_exact}
 
 

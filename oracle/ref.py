@@ -268,6 +268,16 @@ class RefContext:
         return lib().ref_plain_chain_idx(self.h, C.c_uint32(ps_low_degree))
 
 
+def set_threads(n):
+    """threads used by the oracle's task-parallel drivers (the reference's `-t`, cli/base_clp.h)"""
+    import ctypes.util
+    try:
+        omp = C.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1")
+        omp.omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def create_powers_set(ps_low_degree, target_degree):
     cap = target_degree + 2
     out = np.zeros(cap, dtype=np.uint32)

@@ -97,7 +97,10 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
     for (int i = 0; i < n_nodes; i++) if ((int)nodes[i].depth > max_depth) max_depth = (int)nodes[i].depth;
     /* parallel_apply visits a node once both parents are done; any topological order gives
        the same values.  Visit by depth. */
+    /* the reference runs one task per DAG node on its thread pool (powers.h:158-278); nodes of equal depth
+       are independent, so they are the OpenMP work items here (OMP_NUM_THREADS = the reference's -t) */
     for (int d = 1; d <= max_depth; d++) {
+#pragma omp parallel for schedule(dynamic, 1)
         for (int i = 0; i < n_nodes; i++) {
             if ((int)nodes[i].depth != d) continue;
             const ref_dag_node *nd = &nodes[i];
@@ -108,6 +111,7 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
         }
     }
     int high = ref_clamp_chain_idx(c, 1), low = ref_clamp_chain_idx(c, 2);                /* :451-454 */
+#pragma omp parallel for schedule(dynamic, 1)                                             /* :458-487 one task per power */
     for (int i = 0; i < n_nodes; i++) {
         uint32_t power = nodes[i].power;
         uint64_t *ct = powers[power];
