@@ -225,7 +225,7 @@ int apsu_he_powers_download(apsu_he_ctx *c, const apsu_he_powers *p, uint32_t bu
         const size_t words = (size_t)2 * (lvl + 1) * n;
         REQUIRE(capacity_words >= words, "output buffer too small");
         c->eng->sync();
-        const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)idx * pw.nb + b) * words;
+        const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * words;
         if (hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
         if (chain_idx) *chain_idx = lvl;
         if (is_ntt) *is_ntt = low ? 1 : 0;

@@ -22,6 +22,7 @@ struct DevLevel {
     Mod bsk[DMAXB];                             // B_0..B_{nB-1}, m_sk
     Mod ext[DMAXE];                             // q_0..q_{L-1}, Bsk..   (modulus of each ext limb)
     u64 t;
+    u32 mac_shift[DMAXL], mac_chunk[DMAXL];     // k_mac: operand split width s = ceil(bits(q_j)/2) and terms per carry-free chunk
     // add_plain (App. B7) and plaintext lift (B5)
     u64 coeff_div_plain[DMAXL];
     u64 q_mod_t, threshold;

@@ -114,6 +114,14 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 ModulusInfo mj(qj);
                 d.q[j] = make_mod(qj);
                 d.ext[j] = d.q[j];
+                {
+                    const int bits = 64 - __builtin_clzll(qj);
+                    const int sh = (bits + 1) / 2;                         // both operand halves < 2^sh (sh <= 30)
+                    d.mac_shift[j] = (u32)sh;
+                    // cross sum takes two products (< 2^(2 sh)) per term, plus one slot for the carried residue
+                    const u64 cap = ((u64)1 << (63 - 2 * sh));
+                    d.mac_chunk[j] = (u32)std::min<u64>(cap > 2 ? cap - 1 : 2, 1u << 20);
+                }
                 d.coeff_div_plain[j] = h.coeff_div_plain[j];
                 d.incr[j] = h.upper_half_incr[j];
                 d.half_mod[j] = d.half % qj;
@@ -856,14 +864,14 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             if (first == target) {
                 for (size_t i = 0; i < powers.size(); i++)
                     for (int b = 0; b < nb; b++)
-                        jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), out + ((size_t)i * nb + b) * 2 * Lf * n });
+                        jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), out + ((size_t)b * powers.size() + i) * 2 * Lf * n });
                 { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(jobs), 2 * Lf * n, cnt, st_); }
                 return;
             }
             cur = dst_for(first - 1);
             for (size_t i = 0; i < powers.size(); i++)
                 for (int b = 0; b < nb; b++)
-                    jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), cur + ((size_t)i * nb + b) * 2 * (Lf - 1) * n });
+                    jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), cur + ((size_t)b * powers.size() + i) * 2 * (Lf - 1) * n });
             { PROF(P_MODSWITCH, 0); launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_); }                     // :463,471,478
             lvl = first - 1;
             while (lvl > target) {
@@ -1029,7 +1037,6 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     const int high = pw.high_level, low = pw.low_level;
     const size_t Ll = low + 1, Lh = high + 1;
     const size_t Eh = hlevel(high).L + hlevel(high).nB + 1;
-    const int nb = pw.nb;
 
     // validation mirrors bin_bundle.cpp:116-118,204-213 ("not enough ciphertext powers available")
     std::vector<int> bslot(count);
@@ -1049,9 +1056,10 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     }
     if (any_ps && hp_.using_keyswitching && !rk) throw std::invalid_argument("relinearization keys are required");
 
-    auto low_ptr = [&](uint32_t power, int b) { return pw.low.u() + (((size_t)(power - 1) * nb + b) * 2) * Ll * n; };
-    const u32 low_term_stride = (u32)((size_t)nb * 2 * Ll * n);
-    auto hext_ptr = [&](uint32_t i, int b) { return pw.hext.u() + (((size_t)(i - 1) * nb + b) * 2) * Eh * n; };
+    // powers are stored bundle-index major ([idx][power][2][L][n]): one index's powers are contiguous
+    auto low_ptr = [&](uint32_t power, int b) { return pw.low.u() + (((size_t)b * pw.n_low + (power - 1)) * 2) * Ll * n; };
+    const u32 low_term_stride = (u32)((size_t)2 * Ll * n);
+    auto hext_ptr = [&](uint32_t i, int b) { return pw.hext.u() + (((size_t)b * pw.n_high + (i - 1)) * 2) * Eh * n; };
 
     // workspace budget -> chunk size
     size_t per_bundle_words = 0;
@@ -1241,7 +1249,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
                     ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
-                                            (u32)((size_t)nb * 2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0 });
+                                            (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0 });
                 }
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(cf, (size_t)Bs * 2, high, true);

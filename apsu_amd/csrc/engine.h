@@ -67,9 +67,9 @@ struct Powers {
     std::vector<uint32_t> bundle_indices;
     int low_level = 0, high_level = 0;
     uint32_t n_low = 0, n_high = 0;              // PS: l low powers, H high powers; no PS: all in `low`
-    DevBuf low;                                  // [power-1][nb][2][Ll][n]   NTT form
-    DevBuf high;                                 // [i-1][nb][2][Lh][n]       coefficient form (power i*h)
-    DevBuf hext;                                 // [i-1][nb][2][Eh][n]       extended + NTT form of the same
+    DevBuf low;                                  // [idx][power-1][2][Ll][n]   NTT form
+    DevBuf high;                                 // [idx][i-1][2][Lh][n]       coefficient form (power i*h)
+    DevBuf hext;                                 // [idx][i-1][2][Eh][n]       extended + NTT form of the same
     int slot_of(uint32_t bundle_idx) const;
 };
 

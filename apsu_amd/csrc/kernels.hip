@@ -825,79 +825,145 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // ============================================================================ K3: dyadic multiply-accumulate
 // The inner loops of BatchedPlaintextPolyn::eval / eval_patstock
 // (bin_bundle.cpp:140-149, 250-265, 279-294, 314-324, 328-337): out_g = sum_j C^j (.) a_{g,j} in the NTT
-// domain for up to MAC_G plaintext streams that share the same ciphertext powers (the inner
-// polynomials of the BinBundles of one bundle index).  Each lane owns two adjacent coefficients
-// (16-byte loads), keeps 128-bit lazy accumulators and does one Barrett reduction per output.
-// The HBM-resident plaintexts are streamed exactly once; every power load is shared by MAC_G streams.
+// domain for plaintext streams that share the same ciphertext powers (the inner polynomials of the
+// BinBundles of one bundle index).  The HBM-resident plaintexts are streamed exactly once (16-byte
+// non-temporal loads, two adjacent coefficients per lane); every power load is shared by G streams.
+//
+// Carry-free accumulation: both operands are < q < 2^(2s) (s = ceil(bits(q)/2)), so each is split into two
+// s-bit halves and the three partial sums  S00 += lo*lo,  Sx += lo*hi + hi*lo,  S11 += hi*hi  are plain
+// 64-bit v_mad_u64_u32 accumulations (no carries, no compares): 4 multiply-adds per product and nothing
+// else.  `chunk` terms (2*chunk*2^(2s) < 2^64) are accumulated before the sums are recombined
+// (S00 + Sx*2^s + S11*2^(2s)) and reduced; for the 48..56-bit coefficient primes a whole inner polynomial
+// fits in one chunk.
+template <int G, int C>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
-    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2;
+    static_assert(C == 1 || C == 2, "coefficients per lane");
+    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * C;
     if (k >= n) return;
-    const MacJob job = jobs[blockIdx.z];
+    constexpr int SPLIT = MAC_G / G;                            // a job's streams are covered by SPLIT blocks
+    const MacJob *__restrict__ jp = jobs + blockIdx.z / SPLIT;   // stream pointers are indexed dynamically: read them from memory
+    struct { const u64 *pw; u32 cnt, ng, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0; } job =
+        { jp->pw, jp->cnt, jp->ng, jp->pt_stride, jp->pw_stride, jp->pw_poly_stride, jp->out_poly_stride, jp->limb0 };
+    const int g0 = (blockIdx.z % SPLIT) * G;
+    if (g0 >= (int)job.ng) return;
     const int j = blockIdx.y + job.limb0;                      // limb
     const Mod m = lv->q[j];
+    const u32 s = lv->mac_shift[j], chunk = lv->mac_chunk[j];
+    const u32 lomask = (1u << s) - 1;                          // s <= 30
     const u64 *p0 = job.pw + (size_t)j * n + k;
     const u64 *p1 = p0 + job.pw_poly_stride;
-    const u64 *pt[MAC_G];
-    u128p a0[MAC_G][2], a1[MAC_G][2];
+    const u64 *pt[G];
 #pragma unroll
-    for (int g = 0; g < MAC_G; g++) {
-        pt[g] = job.pt[g < job.ng ? g : 0] + (size_t)j * n + k;
-        a0[g][0] = a0[g][1] = a1[g][0] = a1[g][1] = u128p{ 0, 0 };
-    }
-    // streams beyond job.ng alias stream 0 (cache hits, results discarded): the loop body stays branch
-    // free so all six 16-byte loads of an iteration are in flight together, and the next iteration's
-    // loads are issued before this iteration's arithmetic (register double buffering).
-    u64x2 c0 = ldg16(p0);
-    u64x2 c1 = ldg16(p1);
-    u64x2 a[MAC_G];
+    for (int g = 0; g < G; g++) pt[g] = jp->pt[g0 + g < (int)job.ng ? g0 + g : g0] + (size_t)j * n + k;   // missing streams alias a real one
+
+    // accumulators [stream][coef][poly]
+    u64 s00[G][C][2], sx[G][C][2], s11[G][C][2];
 #pragma unroll
-    for (int g = 0; g < MAC_G; g++) a[g] = ldg16_nt(pt[g]);
-    for (u32 i = 0; i < job.cnt; i++) {
-        const u32 nx = i + 1 < job.cnt ? i + 1 : i;
-        const u64x2 nc0 = ldg16(p0 + (size_t)nx * job.pw_stride);
-        const u64x2 nc1 = ldg16(p1 + (size_t)nx * job.pw_stride);
-        u64x2 na[MAC_G];
+    for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int g = 0; g < MAC_G; g++) na[g] = ldg16_nt(pt[g] + (size_t)nx * job.pt_stride);
+        for (int c = 0; c < C; c++)
 #pragma unroll
-        for (int g = 0; g < MAC_G; g++) {
-            mac128(a0[g][0], a[g][0], c0[0]);
-            mac128(a0[g][1], a[g][1], c0[1]);
-            mac128(a1[g][0], a[g][0], c1[0]);
-            mac128(a1[g][1], a[g][1], c1[1]);
+            for (int p = 0; p < 2; p++) s00[g][c][p] = sx[g][c][p] = s11[g][c][p] = 0;
+
+    struct Term { u64 c[2][C]; u64 a[G][C]; };                  // powers (poly, coef) and plaintext values (stream, coef)
+    auto load_term = [&](u32 i, Term &t) {
+        if (C == 2) {
+            const u64x2 v0 = ldg16(p0 + (size_t)i * job.pw_stride), v1 = ldg16(p1 + (size_t)i * job.pw_stride);
+            t.c[0][0] = v0[0]; t.c[0][C - 1] = v0[1]; t.c[1][0] = v1[0]; t.c[1][C - 1] = v1[1];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const u64x2 a = ldg16_nt(pt[g] + (size_t)i * job.pt_stride);
+                t.a[g][0] = a[0]; t.a[g][C - 1] = a[1];
+            }
+        } else {
+            t.c[0][0] = p0[(size_t)i * job.pw_stride]; t.c[1][0] = p1[(size_t)i * job.pw_stride];
+#pragma unroll
+            for (int g = 0; g < G; g++) t.a[g][0] = __builtin_nontemporal_load(pt[g] + (size_t)i * job.pt_stride);
         }
-        if ((i & 31) == 31) {                                  // q < 2^61: 32 products + carry-in < 2^128
+    };
+    auto mac_term = [&](const Term &t) {
+        u32 clo[2][C], chi[2][C];
 #pragma unroll
-            for (int g = 0; g < MAC_G; g++)
+        for (int p = 0; p < 2; p++)
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    a0[g][c] = u128p{ barrett128(a0[g][c], m), 0 };
-                    a1[g][c] = u128p{ barrett128(a1[g][c], m), 0 };
+            for (int c = 0; c < C; c++) { clo[p][c] = (u32)t.c[p][c] & lomask; chi[p][c] = (u32)(t.c[p][c] >> s); }
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const u32 alo = (u32)t.a[g][c] & lomask, ahi = (u32)(t.a[g][c] >> s);
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    s00[g][c][p] += (u64)alo * clo[p][c];
+                    sx[g][c][p] += (u64)alo * chi[p][c];
+                    sx[g][c][p] += (u64)ahi * clo[p][c];
+                    s11[g][c][p] += (u64)ahi * chi[p][c];
                 }
-        }
-        c0 = nc0; c1 = nc1;
+            }
+    };
+    // recombine S00 + Sx*2^s + S11*2^(2s) (< 2^128) and reduce; the residue re-enters as the next chunk's S00
+    auto fold = [&]() {
 #pragma unroll
-        for (int g = 0; g < MAC_G; g++) a[g] = na[g];
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int c = 0; c < C; c++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    u128p acc{ s00[g][c][p], 0 };
+                    add128(acc, u128p{ sx[g][c][p] << s, sx[g][c][p] >> (64 - s) });
+                    add128(acc, u128p{ s11[g][c][p] << (2 * s), s11[g][c][p] >> (64 - 2 * s) });
+                    s00[g][c][p] = barrett128(acc, m);
+                    sx[g][c][p] = s11[g][c][p] = 0;
+                }
+    };
+
+    const u32 cnt = job.cnt;
+    Term A, B;                                                   // ping-pong register sets: no copies
+    load_term(0, A);
+    u32 in_chunk = 0;
+    const u32 npairs = cnt >> 1;
+    for (u32 pr = 0; pr < npairs; pr++) {                        // branch-free body: two terms per trip
+        const u32 i = pr * 2;
+        load_term(i + 1, B);
+        mac_term(A);
+        load_term(i + 2 < cnt ? i + 2 : cnt - 1, A);             // clamped prefetch (a re-read hits the cache)
+        mac_term(B);
+        in_chunk += 2;
+        if (in_chunk + 3 > chunk) { fold(); in_chunk = 1; }      // the folded residue counts as one term
     }
+    if (cnt & 1) mac_term(A);                                    // A holds the last term
+    fold();
 #pragma unroll
-    for (int g = 0; g < MAC_G; g++) {
-        if (g < job.ng) {
-            u64x2 r0, r1;
-            r0[0] = barrett128(a0[g][0], m); r0[1] = barrett128(a0[g][1], m);
-            r1[0] = barrett128(a1[g][0], m); r1[1] = barrett128(a1[g][1], m);
-            u64 *o = job.out[g] + (size_t)blockIdx.y * n + k;
-            *reinterpret_cast<u64x2 *>(o) = r0;
-            *reinterpret_cast<u64x2 *>(o + job.out_poly_stride) = r1;
+    for (int g = 0; g < G; g++) {
+        if (g0 + g < (int)job.ng) {
+            u64 *o = jp->out[g0 + g] + (size_t)blockIdx.y * n + k;
+            if (C == 2) {
+                u64x2 r0, r1;
+                r0[0] = s00[g][0][0]; r0[1] = s00[g][C - 1][0];
+                r1[0] = s00[g][0][1]; r1[1] = s00[g][C - 1][1];
+                *reinterpret_cast<u64x2 *>(o) = r0;
+                *reinterpret_cast<u64x2 *>(o + job.out_poly_stride) = r1;
+            } else {
+                o[0] = s00[g][0][0];
+                o[job.out_poly_stride] = s00[g][0][1];
+            }
         }
     }
 }
 
+#ifndef APSU_MAC_G
+#define APSU_MAC_G 2
+#endif
+#ifndef APSU_MAC_C
+#define APSU_MAC_C 2
+#endif
 void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
 {
     if (!njobs || !nlimbs) return;
-    hipLaunchKernelGGL(k_mac, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)njobs), dim3(EW_T), 0, st,
-                       lv, jobs, n);
+    constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
+    hipLaunchKernelGGL((k_mac<G, C>), dim3((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G))),
+                       dim3(EW_T), 0, st, lv, jobs, n);
     KERNEL_CHECK();
 }
 
