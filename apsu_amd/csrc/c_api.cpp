@@ -183,6 +183,25 @@ int apsu_he_bundle_download(apsu_he_ctx *c, const apsu_he_bundle *b, uint32_t de
         if (words) *words = w;
     });
 }
+int apsu_he_bundle_image_size(apsu_he_ctx *c, const apsu_he_bundle *b, uint64_t *bytes)
+{ return guarded([&] { REQUIRE(c && b && bytes, "null argument"); *bytes = c->eng->bundle_image_size(*b->b); }); }
+int apsu_he_bundle_save(apsu_he_ctx *c, const apsu_he_bundle *b, uint8_t *buf, uint64_t capacity, uint64_t *written)
+{
+    return guarded([&] {
+        REQUIRE(c && b && buf, "null argument");
+        size_t w = c->eng->save_bundle(*b->b, buf, (size_t)capacity);
+        if (written) *written = w;
+    });
+}
+int apsu_he_bundle_load(apsu_he_ctx *c, const uint8_t *buf, uint64_t size, apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && buf && out, "null argument");
+        auto b = new apsu_he_bundle;
+        try { b->b = c->eng->load_bundle(buf, (size_t)size); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree)
 { return guarded([&] { REQUIRE(b && degree, "null argument"); *degree = b->b->degree; }); }
 int apsu_he_bundle_free(apsu_he_bundle *b) { return guarded([&] { delete b; }); }

@@ -1000,6 +1000,89 @@ std::unique_ptr<Bundle> Engine::build_bundle(uint32_t bundle_idx, uint32_t cache
     return b;
 }
 
+// ---- N2: BinBundle image ------------------------------------------------------------------------------------
+namespace {
+struct ImageHeader {                     // little-endian, 256 bytes
+    char magic[8];                       // "APSUHEB1"
+    uint64_t header_bytes, total_bytes;
+    uint64_t n, t, K, q[8];
+    uint32_t ps_low_degree, max_items_per_bin;
+    uint32_t bundle_idx, cache_idx, degree, use_ps, H, r, pt_level, reserved;
+    uint64_t ntt_count, ntt_bytes, lifted_bytes, a0_bytes;
+    uint64_t checksum;                   // FNV-1a over the payload
+    unsigned char pad[256 - 8 - 16 - 88 - 8 - 32 - 32 - 8];
+};
+static_assert(sizeof(ImageHeader) == 256, "image header layout");
+uint64_t fnv1a64(const unsigned char *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+}
+
+size_t Engine::bundle_image_size(const Bundle &b) const { return sizeof(ImageHeader) + b.ntt.bytes() + b.lifted.bytes() + b.a0.bytes(); }
+
+size_t Engine::save_bundle(const Bundle &b, unsigned char *buf, size_t capacity)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    const size_t total = bundle_image_size(b);
+    if (capacity < total) throw std::invalid_argument("image buffer too small");
+    sync();
+    ImageHeader hd;
+    std::memset(&hd, 0, sizeof(hd));
+    std::memcpy(hd.magic, "APSUHEB1", 8);
+    hd.header_bytes = sizeof(hd); hd.total_bytes = total;
+    hd.n = hp_.n; hd.t = hp_.t; hd.K = hp_.K;
+    for (int j = 0; j < hp_.K && j < 8; j++) hd.q[j] = hp_.key_q[j];
+    hd.ps_low_degree = psu_.query_params.ps_low_degree; hd.max_items_per_bin = psu_.table_params.max_items_per_bin;
+    hd.bundle_idx = b.bundle_idx; hd.cache_idx = b.cache_idx; hd.degree = b.degree; hd.use_ps = b.use_ps; hd.H = b.H; hd.r = b.r;
+    hd.pt_level = (uint32_t)b.pt_level; hd.ntt_count = b.ntt_count;
+    hd.ntt_bytes = b.ntt.bytes(); hd.lifted_bytes = b.lifted.bytes(); hd.a0_bytes = b.a0.bytes();
+    unsigned char *p = buf + sizeof(hd);
+    if (hd.ntt_bytes) HIP_CHECK(hipMemcpy(p, b.ntt.p(), hd.ntt_bytes, hipMemcpyDeviceToHost));
+    p += hd.ntt_bytes;
+    if (hd.lifted_bytes) HIP_CHECK(hipMemcpy(p, b.lifted.p(), hd.lifted_bytes, hipMemcpyDeviceToHost));
+    p += hd.lifted_bytes;
+    HIP_CHECK(hipMemcpy(p, b.a0.p(), hd.a0_bytes, hipMemcpyDeviceToHost));
+    hd.checksum = fnv1a64(buf + sizeof(hd), total - sizeof(hd));
+    std::memcpy(buf, &hd, sizeof(hd));
+    return total;
+}
+
+std::unique_ptr<Bundle> Engine::load_bundle(const unsigned char *buf, size_t size)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    ImageHeader hd;
+    if (size < sizeof(hd)) throw std::invalid_argument("BinBundle image is truncated");
+    std::memcpy(&hd, buf, sizeof(hd));
+    if (std::memcmp(hd.magic, "APSUHEB1", 8) != 0 || hd.header_bytes != sizeof(hd)) throw std::invalid_argument("not a BinBundle image");
+    if (hd.total_bytes != size || hd.total_bytes != sizeof(hd) + hd.ntt_bytes + hd.lifted_bytes + hd.a0_bytes)
+        throw std::invalid_argument("BinBundle image size mismatch");
+    bool same = hd.n == hp_.n && hd.t == hp_.t && hd.K == (uint64_t)hp_.K && hd.ps_low_degree == psu_.query_params.ps_low_degree &&
+                hd.max_items_per_bin == psu_.table_params.max_items_per_bin;
+    for (int j = 0; same && j < hp_.K && j < 8; j++) same = hd.q[j] == hp_.key_q[j];
+    if (!same) throw std::invalid_argument("BinBundle image was built for different parameters");
+    if (fnv1a64(buf + sizeof(hd), size - sizeof(hd)) != hd.checksum) throw std::invalid_argument("BinBundle image is corrupt (checksum)");
+    auto b = std::make_unique<Bundle>();
+    b->bundle_idx = hd.bundle_idx; b->cache_idx = hd.cache_idx;
+    bundle_shape(psu_, hp_, hd.degree, *b);                      // re-derive and cross-check the shape
+    const size_t n = hp_.n, Lh = hp_.clamp_chain_idx(1) + 1;
+    if (b->H != hd.H || b->r != hd.r || (uint32_t)b->use_ps != hd.use_ps || (uint32_t)b->pt_level != hd.pt_level || b->ntt_count != hd.ntt_count ||
+        hd.ntt_bytes != b->ntt_count * (b->pt_level + 1) * n * sizeof(u64) || hd.a0_bytes != n * sizeof(u64) ||
+        hd.lifted_bytes != (b->use_ps ? (size_t)b->H * Lh * n * sizeof(u64) : 0) || hd.bundle_idx >= psu_.bundle_idx_count)
+        throw std::invalid_argument("BinBundle image header is inconsistent");
+    const unsigned char *p = buf + sizeof(hd);
+    b->ntt.alloc(hd.ntt_bytes); b->lifted.alloc(hd.lifted_bytes); b->a0.alloc(hd.a0_bytes);
+    if (hd.ntt_bytes) HIP_CHECK(hipMemcpy(b->ntt.p(), p, hd.ntt_bytes, hipMemcpyHostToDevice));
+    p += hd.ntt_bytes;
+    if (hd.lifted_bytes) HIP_CHECK(hipMemcpy(b->lifted.p(), p, hd.lifted_bytes, hipMemcpyHostToDevice));
+    p += hd.lifted_bytes;
+    HIP_CHECK(hipMemcpy(b->a0.p(), p, hd.a0_bytes, hipMemcpyHostToDevice));
+    return b;
+}
+
 size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind)
 {
     std::lock_guard<std::mutex> g(mu_);

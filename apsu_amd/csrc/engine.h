@@ -108,6 +108,11 @@ public:
     // (bin_bundle.cpp:366-430,934-1026): roots[bin * stride + r], r < counts[bin], are the field elements of a bin.
     std::unique_ptr<Bundle> build_bundle(uint32_t bundle_idx, uint32_t cache_idx, const u64 *roots, const uint32_t *counts,
                                          uint32_t bins, uint32_t stride);
+    // N2: engine-native image of a BinBundle cache (raw limb arrays), replacing the flatbuffers +
+    // SEAL-serialised blobs of ReceiverDB::save/Load (receiver_db.cpp:1182-1429) for the GPU-resident DB.
+    size_t bundle_image_size(const Bundle &b) const;
+    size_t save_bundle(const Bundle &b, unsigned char *buf, size_t capacity);
+    std::unique_ptr<Bundle> load_bundle(const unsigned char *buf, size_t size);
     // test hook: stored form of coefficient d.  kind: 0 = raw mod t (d = 0), 1 = NTT form at pt_level,
     // 2 = pre-lifted + NTT at the high level (coefficient-form a_{i*h}); returns words written
     size_t download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind);

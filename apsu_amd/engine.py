@@ -305,6 +305,24 @@ class HeContext:
         _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
         return Bundle(self, h, bundle_idx, cache_idx, deg.value)
 
+    def save_bundle(self, bundle):
+        """-> bytes: engine-native image of the BinBundle cache (ReceiverDB::save counterpart)"""
+        size = C.c_uint64()
+        _check(load_library().apsu_he_bundle_image_size(self.h, bundle.h, C.byref(size)))
+        buf = np.empty(size.value, dtype=np.uint8)
+        wr = C.c_uint64()
+        _check(load_library().apsu_he_bundle_save(self.h, bundle.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), size, C.byref(wr)))
+        return buf[: wr.value]
+
+    def load_bundle(self, image):
+        """image: bytes / uint8 array / np.memmap produced by save_bundle (ReceiverDB::Load counterpart)"""
+        arr = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8) if not isinstance(image, np.ndarray) else image)
+        h = C.c_void_p()
+        _check(load_library().apsu_he_bundle_load(self.h, arr.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(arr.size), C.byref(h)))
+        deg = C.c_uint32()
+        _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
+        return Bundle(self, h, -1, -1, deg.value)
+
     def bundle_coeff(self, bundle, degree):
         """test hook -> (array, kind): kind 0 raw mod t, 1 NTT form [L][n], 2 pre-lifted NTT at the high level"""
         buf = np.empty((self.first_chain_idx + 1) * self.n, dtype=np.uint64)

@@ -129,6 +129,12 @@ int apsu_he_db_random_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cac
  * polynomial 1.  The result is identical to uploading the reference-built cache with apsu_he_db_upload_bundle. */
 int apsu_he_db_build_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cache_idx, const uint64_t *roots,
                             const uint32_t *counts, uint32_t bins, uint32_t stride, apsu_he_bundle **out);
+/* "next" row N2: engine-native image of one BinBundle cache (256-byte header with a parameter
+ * fingerprint and checksum + the raw limb arrays), the GPU-resident counterpart of ReceiverDB::save / Load
+ * (receiver/apsu/receiver_db.cpp:1182-1429, bin_bundle.fbs).  The buffer may be an mmap of a file. */
+int apsu_he_bundle_image_size(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint64_t *bytes);
+int apsu_he_bundle_save(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint8_t *buf, uint64_t capacity, uint64_t *written);
+int apsu_he_bundle_load(apsu_he_ctx *ctx, const uint8_t *buf, uint64_t size, apsu_he_bundle **out);
 /* test hooks: degree of the batched polynomial; stored form of coefficient `degree`
  * (kind 0: raw mod t [n]; 1: NTT form [(plain_level+1)*n]; 2: pre-lifted + NTT at the high level [(high+1)*n]) */
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);

@@ -138,3 +138,37 @@ def test_build_rejects_bad_input():
     with pytest.raises(ValueError):
         G.build_bundle(0, 0, [list(range(1, 14))])        # bin larger than max_items_per_bin
     G.close()
+
+
+def test_bundle_image_roundtrip(tmp_path):
+    """N2: save -> file -> mmap -> load gives a BinBundle that evaluates bit-identically; bad images are rejected"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 3]})
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    masks = [b["mask"] for b in S.bundles]
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    ref_out = G.eval_bundles(gb, pw, rk, masks)
+    loaded = []
+    for i, b in enumerate(gb):
+        img = G.save_bundle(b)
+        f = tmp_path / ("bundle%d.img" % i)
+        f.write_bytes(img.tobytes())
+        mm = np.memmap(str(f), dtype=np.uint8, mode="r")
+        loaded.append(G.load_bundle(mm))
+        assert loaded[-1].degree == b.degree and loaded[-1].db_bytes == b.db_bytes
+    assert (G.eval_bundles(loaded, pw, rk, masks) == ref_out).all()
+    img = G.save_bundle(gb[0]).copy()
+    bad = img.copy(); bad[300] ^= 1
+    with pytest.raises(ValueError):
+        G.load_bundle(bad)                                    # checksum
+    with pytest.raises(ValueError):
+        G.load_bundle(img[:-8])                               # truncated
+    bad = img.copy(); bad[0] = ord("X")
+    with pytest.raises(ValueError):
+        G.load_bundle(bad)                                    # magic
+    G2 = apsu_amd.HeContext(common.toy_json(ps_low=0, max_items=6, query_powers=(1, 2, 3, 5)))
+    with pytest.raises(ValueError):
+        G2.load_bundle(img)                                   # built for different parameters
+    G.close(); G2.close()

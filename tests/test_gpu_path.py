@@ -206,3 +206,40 @@ def test_full_size_16M_properties():
     assert (s1 == (acc + m1.astype(object)) % C.t).all()
     assert ((s2 - s1) % C.t == (m2.astype(object) - m1.astype(object)) % C.t).all()
     G.close()
+
+
+def test_concurrent_callers_on_one_context():
+    """the reference calls the Evaluator from a thread pool (receiver_osn.cpp:334-364): ABI calls on one context
+    must be thread-safe.  Several host threads evaluate different BinBundles / run tier-1 ops concurrently."""
+    import threading
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 10, 7, 3, 5, 8]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    expect = [common.oracle_eval(S, opw, b) for b in S.bundles]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                out = G.eval_bundles([gb[i]], pw, rk, [S.bundles[i]["mask"]])
+                if not (out[0] == expect[i]).all():
+                    errors.append("bundle %d mismatch" % i)
+                ct = S.src[0][1].copy()
+                G.transform_to_ntt_inplace(ct, S.C.first)
+                G.transform_from_ntt_inplace(ct, S.C.first)
+                if not (ct == S.src[0][1]).all():
+                    errors.append("ntt roundtrip %d" % i)
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(gb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    G.close()
