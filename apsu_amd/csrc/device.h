@@ -77,7 +77,7 @@ struct MacJob {
     u32 cnt, ng;
     u32 pt_stride, pw_stride, pw_poly_stride;        // in u64 words
     u32 out_poly_stride;  // words between the two output polynomials (L*n for a full ciphertext)
-    u32 limb0, pad;       // first limb handled (grid.y indexes limb0 .. limb0+L'-1); modulus = q[limb]
+    u32 limb0, nl;        // limbs limb0 .. limb0+nl-1 are handled (grid.y >= nl exits); modulus = q[limb]
 };
 
 // ---- launch wrappers (all asynchronous on `st`) --------------------------------------------
@@ -129,9 +129,14 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
                        hipStream_t st);
 void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
+// Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
+// Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.
+struct EpiJob { const u64 *ct; const u64 *add1; const u64 *add2; const u64 *a0; const u64 *mask; u64 *out; };
+void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, size_t ct_poly_stride, int clear_bits, size_t n,
+                          int njobs, hipStream_t st);
 // i = 0 block of eval_patstock when exactly one limb is dropped (bin_bundle.cpp:314-324, note N1):
 // acc[p][m] += (S[p][m] + terms*half - sum_t ((V[t][p] + half) mod q_last)) * q_last^-1  mod q_m
-struct I0Job { const u64 *s; const u64 *v; u64 *acc; int terms; int pad; };   // s:[2][L-1][n] v:[terms][2][n] acc:[2][L-1][n]
+struct I0Job { const u64 *s; const u64 *v; u64 *acc; int terms; int store; };   // s:[2][L-1][n] v:[terms][2][n] acc:[2][L-1][n] (store: = instead of +=)
 void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st);
 
 } // namespace apsu_he

@@ -286,11 +286,11 @@ struct ProfScope {
     ~ProfScope() { e->prof_end(); }
 };
 #define PROF(kind, units) ProfScope prof_scope_(this, kind, units)
-static uint64_t mac_units(const std::vector<MacJob> &mj, size_t L) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * L; return u; }
+static uint64_t mac_units(const std::vector<MacJob> &mj) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * j.nl; return u; }
 
 // single-stream description of a multiply-accumulate; group_mac() packs streams that share the
 // ciphertext powers and the term count into MacJobs of up to MAC_G streams
-struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0; };
+struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0, nl; };
 static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
 {
     std::vector<MacJob> jobs;
@@ -301,18 +301,19 @@ static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
         if (ss[a].pw != ss[b].pw) return ss[a].pw < ss[b].pw;
         if (ss[a].limb0 != ss[b].limb0) return ss[a].limb0 < ss[b].limb0;
+        if (ss[a].nl != ss[b].nl) return ss[a].nl < ss[b].nl;
         return ss[a].cnt < ss[b].cnt;
     });
     for (size_t x = 0; x < order.size();) {
         const MacStream &f = ss[order[x]];
         MacJob j{};
         j.pw = f.pw; j.cnt = f.cnt; j.pt_stride = f.pt_stride; j.pw_stride = f.pw_stride; j.pw_poly_stride = f.pw_poly_stride;
-        j.out_poly_stride = f.out_poly_stride; j.limb0 = f.limb0;
+        j.out_poly_stride = f.out_poly_stride; j.limb0 = f.limb0; j.nl = f.nl;
         u32 g = 0;
         while (x < order.size() && g < (u32)MAC_G) {
             const MacStream &s = ss[order[x]];
             if (s.pw != f.pw || s.cnt != f.cnt || s.pt_stride != f.pt_stride || s.pw_stride != f.pw_stride ||
-                s.pw_poly_stride != f.pw_poly_stride || s.out_poly_stride != f.out_poly_stride || s.limb0 != f.limb0) break;
+                s.pw_poly_stride != f.pw_poly_stride || s.out_poly_stride != f.out_poly_stride || s.limb0 != f.limb0 || s.nl != f.nl) break;
             j.pt[g] = s.pt; j.out[g] = s.out; g++; x++;
         }
         j.ng = g;
@@ -1180,30 +1181,19 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 const size_t Lv = lvl + 1;
                 u64 *acc = ws((size_t)Bp * 2 * Lv * n);
                 std::vector<MacStream> ms;
-                std::vector<PlainJob> pj;
+                std::vector<EpiJob> ej;
                 for (int x = 0; x < Bp; x++) {
                     const Bundle &b = *bundles[c0 + pl_ids[x]];
                     u64 *o = acc + (size_t)x * 2 * Lv * n;
                     if (b.degree) ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
-                                                          (u32)(Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0 });   // :140-149
+                                                          (u32)(Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv });   // :140-149
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
-                    pj.push_back(PlainJob{ o, b.a0.u() });                                               // :159
+                    ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res + (size_t)pl_ids[x] * 2 * n });
                 }
-                for (int x = 0; x < Bp; x++) pj.push_back(PlainJob{ acc + (size_t)x * 2 * Lv * n, mask_ptr(pl_ids[x]) });   // :162
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lv)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
-                const PlainJob *pjd = upload_jobs(pj);
-                { PROF(P_OTHER, 0); launch_add_plain(dlevel(lvl), pjd, n, Bp, st_); }
-                { PROF(P_OTHER, 0); launch_add_plain(dlevel(lvl), pjd + Bp, n, Bp, st_); }
-                u64 *cur = acc;
-                for (int lv = lvl; lv > 0; lv--) {                                                        // :168-170
-                    u64 *nxt = ws((size_t)Bp * 2 * lv * n);
-                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), cur, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bp, st_); }
-                    cur = nxt;
-                }
-                std::vector<CtJob> cj;
-                for (int x = 0; x < Bp; x++) cj.push_back(CtJob{ cur + (size_t)x * 2 * n, res + (size_t)pl_ids[x] * 2 * n });
-                { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * n, Bp, st_); }
+                // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
+                { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
             }
 
             // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
@@ -1218,8 +1208,31 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     in_off[x] = NI;
                     NI += nin[x];
                 }
-                u64 *inner = ws((size_t)NI * 2 * Ll * n);
+                // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
+                // the sum (note N1).  With one dropped limb the sum of the rounded terms is
+                //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
+                // where the first sum is exact and may be taken in the NTT domain.  So only the LAST limb of each term
+                // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
+                const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
+                const bool need_vlast = i0_fast && low > high;
+
+                // Every dyadic multiply-accumulate of the evaluation reads only the query powers and the database, so
+                // all of them run as ONE launch, and their results share ONE inverse-NTT launch:
+                //   inner [NI][2][Ll]   sum_j C^j (.) a_{i*h+j}                                  :258-264
+                //   ssum  [Bs][2][Lh]   sum_j C^j (.) a_j on the limbs that survive the switch  (i = 0 block, fast form)
+                //   vlast [Bs*l][2][1]  C^j (.) a_j on the dropped limb, per term               (i = 0 block, fast form)
+                //   term  [Bs*l][2][Ll] C^j (.) a_j, per term                                   (i = 0 block, general form)
+                //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
+                const size_t w_inner = (size_t)NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
+                const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
+                const size_t w_cf = (size_t)Bs * 2 * Lh * n;
+                u64 *inner = ws(w_inner + w_ssum + w_vlast + w_term + w_cf);
+                u64 *ssum = inner + w_inner, *vlast = ssum + w_ssum, *term = vlast + w_vlast, *cf = term + w_term;
                 std::vector<MacStream> ms;
+                std::vector<int> imap;                                  // modulus of every limb polynomial of the merged block
+                auto map_push = [&](size_t polys, int first_limb, int limbs) {
+                    for (size_t p = 0; p < polys; p++) for (int j = 0; j < limbs; j++) imap.push_back(first_limb + j);
+                };
                 for (int x = 0; x < Bs; x++) {
                     const Bundle &b = *bundles[c0 + ps_ids[x]];
                     const int bs = bslot[c0 + ps_ids[x]];
@@ -1227,11 +1240,46 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         const u32 cnt = (u32)i < b.H ? l : b.r;
                         ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
                                                 inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
-                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0 });   // :258-264
+                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
                     }
                 }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
-                d_ntt_ct(inner, (size_t)NI * 2, low, true);                                                 // :268,297
+                map_push((size_t)NI * 2, 0, (int)Ll);
+                if (i0_fast) {
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + ps_ids[x]];
+                        ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + ps_ids[x]]), ssum + (size_t)x * 2 * Lh * n, l,
+                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh });
+                    }
+                    map_push((size_t)Bs * 2, 0, (int)Lh);
+                }
+                if (need_vlast || !i0_fast) {
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + ps_ids[x]];
+                        const int bs = bslot[c0 + ps_ids[x]];
+                        for (u32 j = 1; j <= l; j++) {
+                            if (i0_fast)
+                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                        vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
+                                                        (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1 });
+                            else
+                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                        term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
+                                                        (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                        }
+                    }
+                    if (i0_fast) map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
+                    else map_push((size_t)Bs * l * 2, 0, (int)Ll);
+                }
+                for (int x = 0; x < Bs; x++) {
+                    const Bundle &b = *bundles[c0 + ps_ids[x]];
+                    ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + ps_ids[x]]), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
+                                            (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh });
+                }
+                map_push((size_t)Bs * 2, 0, (int)Lh);
+                // the level-`low` constants serve every limb: levels share their leading primes
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
+                d_ntt(inner, imap.size(), upload_jobs(imap), (int)imap.size(), true);                       // :268,297,320,333
+
                 u64 *innerh = inner;
                 for (int lv = low; lv > high; lv--) {                                                       // :269,298
                     u64 *nxt = ws((size_t)NI * 2 * lv * n);
@@ -1265,99 +1313,36 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
                 if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
 
-                // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
-                // the sum (note N1).  With one dropped limb the sum of the rounded terms is
-                //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
-                // where the first sum is exact and may be taken in the NTT domain.  So only the LAST limb of each term
-                // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
-                const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
-                if (i0_fast) {
-                    u64 *ssum = ws((size_t)Bs * 2 * Lh * n);
-                    ms.clear();
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + ps_ids[x]];
-                        ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + ps_ids[x]]), ssum + (size_t)x * 2 * Lh * n, l,
-                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0 });
-                    }
-                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(low), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
-                    d_ntt_ct(ssum, (size_t)Bs * 2, high, true);
-                    if (low == high) {
-                        { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, ssum, 1, 2, n, Bs, st_); }
-                    } else {
-                        u64 *vlast = ws((size_t)Bs * l * 2 * n);
-                        ms.clear();
-                        for (int x = 0; x < Bs; x++) {
-                            const Bundle &b = *bundles[c0 + ps_ids[x]];
-                            const int bs = bslot[c0 + ps_ids[x]];
-                            for (u32 j = 1; j <= l; j++)
-                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                        vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
-                                                        (u32)(Ll * n), (u32)n, (u32)(Ll - 1) });
-                        }
-                        { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, 1)); launch_mac(dlevel(low), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
-                        d_ntt(vlast, (size_t)Bs * l * 2, map_ct() + (Ll - 1), 1, true);          // every limb polynomial is mod q_last
-                        std::vector<I0Job> ij;
-                        for (int x = 0; x < Bs; x++)
-                            ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, result + (size_t)x * 3 * Lh * n, (int)l, 0 });
-                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
-                    }
+                // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
+                u64 *i0 = nullptr;
+                if (i0_fast && low == high) {
+                    i0 = ssum;
+                } else if (i0_fast) {
+                    i0 = ws((size_t)Bs * 2 * Lh * n);
+                    std::vector<I0Job> ij;
+                    for (int x = 0; x < Bs; x++)
+                        ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
+                    { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
                 } else {
-                // i = 0 block: every term is rounded on its own before the sum (note N1)            :314-324
-                    u64 *term = ws((size_t)Bs * l * 2 * Ll * n);
-                    ms.clear();
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + ps_ids[x]];
-                        const int bs = bslot[c0 + ps_ids[x]];
-                        for (u32 j = 1; j <= l; j++)
-                            ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                    term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
-                                                    (u32)(Ll * n), (u32)(Ll * n), 0 });
-                    }
-                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Ll)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
-                    d_ntt_ct(term, (size_t)Bs * l * 2, low, true);
                     u64 *termh = term;
                     for (int lv = low; lv > high; lv--) {
                         u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
                         { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
                         termh = nxt;
                     }
-                    { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
+                    i0 = ws((size_t)Bs * 2 * Lh * n);
+                    HIP_CHECK(hipMemsetAsync(i0, 0, (size_t)Bs * 2 * Lh * n * sizeof(u64), st_));
+                    { PROF(P_OTHER, 0); launch_add_many(dlevel(high), i0, 2 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
                 }
 
-                // coefficient-form plaintexts a_{i*h} times the high powers (:328-337): exact, so the
-                // products are summed in the NTT domain and transformed back once
-                u64 *cf = ws((size_t)Bs * 2 * Lh * n);
-                ms.clear();
-                for (int x = 0; x < Bs; x++) {
-                    const Bundle &b = *bundles[c0 + ps_ids[x]];
-                    const int bs = bslot[c0 + ps_ids[x]];
-                    ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
-                                            (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0 });
-                }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj, Lh)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
-                d_ntt_ct(cf, (size_t)Bs * 2, high, true);
-                { PROF(P_OTHER, 0); launch_add_many(dlevel(high), result, 3 * Lh * n, cf, 1, 2, n, Bs, st_); }
-
-                std::vector<PlainJob> pj;
-                for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, bundles[c0 + ps_ids[x]]->a0.u() });   // :345
-                for (int x = 0; x < Bs; x++) pj.push_back(PlainJob{ result + (size_t)x * 3 * Lh * n, mask_ptr(ps_ids[x]) });              // :346
-                const PlainJob *pjd = upload_jobs(pj);
-                { PROF(P_OTHER, 0); launch_add_plain(dlevel(high), pjd, n, Bs, st_); }
-                { PROF(P_OTHER, 0); launch_add_plain(dlevel(high), pjd + Bs, n, Bs, st_); }
-
-                u64 *cur = result;
-                size_t stride = 3 * Lh * n;
-                for (int lv = high; lv > 0; lv--) {                                                         // :354-356
-                    u64 *nxt = ws((size_t)Bs * 2 * lv * n);
-                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), cur, stride, 2, nxt, n, Bs, st_); }
-                    cur = nxt;
-                    stride = (size_t)2 * lv * n;
-                }
-                std::vector<CtJob> cj;
-                for (int x = 0; x < Bs; x++) cj.push_back(CtJob{ cur + (size_t)x * stride, res + (size_t)ps_ids[x] * 2 * n });
-                { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * n, Bs, st_); }
+                // :340-343 the two exact addends, :345 add_plain(a_0), :346 add_plain(mask), :354-356 mod switch to the last
+                // level, :357 clear bits — one pass over the result
+                std::vector<EpiJob> ej;
+                for (int x = 0; x < Bs; x++)
+                    ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, cf + (size_t)x * 2 * Lh * n,
+                                         bundles[c0 + ps_ids[x]]->a0.u(), mask_ptr(ps_ids[x]), res + (size_t)ps_ids[x] * 2 * n });
+                { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
             }
-            launch_clear_bits(res, (size_t)B * 2 * n, hp_.irrelevant_bit_count, st_);                       // :171,357
             if (out_on_device) D2D(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             else D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             sync();

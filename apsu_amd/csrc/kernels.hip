@@ -846,7 +846,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     struct { const u64 *pw; u32 cnt, ng, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0; } job =
         { jp->pw, jp->cnt, jp->ng, jp->pt_stride, jp->pw_stride, jp->pw_poly_stride, jp->out_poly_stride, jp->limb0 };
     const int g0 = (blockIdx.z % SPLIT) * G;
-    if (g0 >= (int)job.ng) return;
+    if (g0 >= (int)job.ng || blockIdx.y >= jp->nl) return;
     const int j = blockIdx.y + job.limb0;                      // limb
     const Mod m = lv->q[j];
     const u32 s = lv->mac_shift[j], chunk = lv->mac_chunk[j];
@@ -967,6 +967,93 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
     KERNEL_CHECK();
 }
 
+// Fused tail of BatchedPlaintextPolyn::eval / eval_patstock (bin_bundle.cpp:159-171, 345-357):
+// add_plain(a_0), add_plain(random_plain) [K8], mod_switch_to_next down to the last level [K7],
+// try_clear_irrelevant_bits [K9] — plus up to two exact addends (coefficient-form sums) folded in.
+__device__ __forceinline__ u64 scaled_plain(const DevLevel *__restrict__ lv, u64 m, u64 fix, int j)
+{
+    u128p s = mul128(m, lv->coeff_div_plain[j]);
+    add128(s, u128p{ fix, 0 });
+    return barrett128(s, lv->q[j]);
+}
+__device__ __forceinline__ u64 plain_fix(const DevLevel *__restrict__ lv, u64 m)
+{
+    // floor((m * (Q mod t) + floor((t+1)/2)) / t), exact (m < t < 2^61)
+    u128p num = mul128(m, lv->q_mod_t);
+    add128(num, u128p{ lv->threshold, 0 });
+    const u64 t = lv->t;
+    if (num.hi == 0) return num.lo / t;
+    u64 rem = num.hi % t, lo = num.lo, fix = 0;
+    for (int i = 0; i < 64; i++) {
+        rem = (rem << 1) | (lo >> 63);
+        lo <<= 1;
+        fix <<= 1;
+        if (rem >= t) { rem -= t; fix |= 1; }
+    }
+    return fix;
+}
+
+__global__ __launch_bounds__(EW_T) void k_eval_epilogue(const DevLevel *__restrict__ levels, int lvl, const EpiJob *__restrict__ jobs,
+                                                        size_t ct_poly_stride, u64 clear_mask, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const EpiJob job = jobs[blockIdx.y];
+    const DevLevel *lv = levels + lvl;
+    const int L = lvl + 1;
+    u64 v[2][DMAXL];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int j = 0; j < DMAXL; j++)
+            if (j < L) {
+                const u64 q = lv->q[j].q;
+                u64 x = job.ct[p * ct_poly_stride + (size_t)j * n + k];
+                if (job.add1) x = addmod(x, job.add1[((size_t)p * L + j) * n + k], q);
+                if (job.add2) x = addmod(x, job.add2[((size_t)p * L + j) * n + k], q);
+                v[p][j] = x;
+            }
+    {   // c0 += round(a0 * Q / t) + round(mask * Q / t)
+        const u64 m0 = job.a0[k], m1 = job.mask[k];
+        const u64 f0 = plain_fix(lv, m0), f1 = plain_fix(lv, m1);
+#pragma unroll
+        for (int j = 0; j < DMAXL; j++)
+            if (j < L) {
+                const u64 q = lv->q[j].q;
+                v[0][j] = addmod(addmod(v[0][j], scaled_plain(lv, m0, f0, j), q), scaled_plain(lv, m1, f1, j), q);
+            }
+    }
+    for (int l = lvl; l > 0; l--) {                              // drop q_l with rounding (App. B8)
+        const DevLevel *ll = levels + l;
+        const u64 ql = ll->q[l].q;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            u64 last = 0;
+#pragma unroll
+            for (int j = 0; j < DMAXL; j++) if (j == l) last = v[p][j];
+            last = addmod(last, ll->half, ql);
+#pragma unroll
+            for (int j = 0; j < DMAXL; j++)
+                if (j < l) {
+                    const Mod m = ll->q[j];
+                    const u64 tmp = submod(barrett64(last, m), ll->half_mod[j], m.q);
+                    v[p][j] = mul_shoup(submod(v[p][j], tmp, m.q), ll->inv_q_last[j].w, ll->inv_q_last[j].wq, m.q);
+                }
+        }
+    }
+    job.out[k] = v[0][0] & clear_mask;
+    job.out[n + k] = v[1][0] & clear_mask;
+}
+
+void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, size_t ct_poly_stride, int clear_bits, size_t n,
+                          int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    const u64 mask = clear_bits > 0 ? ~(((u64)1 << clear_bits) - 1) : ~(u64)0;
+    hipLaunchKernelGGL(k_eval_epilogue, ew_grid(n, njobs), dim3(EW_T), 0, st, levels, lvl, jobs, ct_poly_stride, mask, n);
+    KERNEL_CHECK();
+}
+
 // Sum of `terms` individually rounded drop-last-limb results, computed from the exact sum S of the kept
 // limbs and the per-term last limbs V (all coefficient form):  SURVEY note N1 / DESIGN.md §4.
 __global__ __launch_bounds__(EW_T) void k_i0_finish(const DevLevel *__restrict__ lv, const I0Job *__restrict__ jobs, size_t n)
@@ -988,7 +1075,7 @@ __global__ __launch_bounds__(EW_T) void k_i0_finish(const DevLevel *__restrict__
         const size_t o = ((size_t)p * (L - 1) + m) * n + k;
         const u64 val = addmod(job.s[o], corr, mq.q);
         const u64 r = mul_shoup(val, lv->inv_q_last[m].w, lv->inv_q_last[m].wq, mq.q);
-        job.acc[((size_t)p * (L - 1) + m) * n + k] = addmod(job.acc[((size_t)p * (L - 1) + m) * n + k], r, mq.q);
+        job.acc[o] = job.store ? r : addmod(job.acc[o], r, mq.q);
     }
 }
 
