@@ -118,6 +118,12 @@ void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in
                      hipStream_t st);
 struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
 void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
+// The same for a sum of products sharing one output (eval_patstock's sum over i): a, b: [terms][2][E][n];
+// dq: [terms][3][L][n] per-term q limbs; bs: [3][nBsk][n] Bsk limbs summed over the terms
+struct TensorSumJob { const u64 *a, *b; u64 *dq, *bs; int terms; int pad; };
+void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, hipStream_t st);
+struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
+void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)
 struct FinishJob { const u64 *d; u64 *out; int terms; int pad; };
 void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st);

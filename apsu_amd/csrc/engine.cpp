@@ -1290,8 +1290,37 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 u64 *ext = ws((size_t)NI * 2 * Eh * n);
                 { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                 d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
-                u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
                 u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
+                // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
+                // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
+                // kernel and finished once per BinBundle (see behz_finish_coeff).  Bit-identical, 6 instead of 15
+                // inverse transforms per term at L = 2.
+                int max_terms = 0;
+                for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
+                static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
+                const bool summed = !force_per_term && Lh <= 4 &&
+                                    (unsigned __int128)max_terms * hlevel(high).q[0] < ((unsigned __int128)1 << 63);
+                if (summed) {
+                    const size_t nBskh = Eh - Lh;
+                    u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n);
+                    u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
+                    std::vector<TensorSumJob> tj;
+                    std::vector<FinishSumJob> fj;
+                    std::vector<int> dmap;
+                    for (int x = 0; x < Bs; x++) {
+                        if (!nin[x]) { HIP_CHECK(hipMemsetAsync(result + (size_t)x * 3 * Lh * n, 0, 3 * Lh * n * sizeof(u64), st_)); continue; }
+                        const size_t job = (size_t)in_off[x];
+                        tj.push_back(TensorSumJob{ ext + job * 2 * Eh * n, hext_ptr(1, bslot[c0 + ps_ids[x]]), dq + job * 3 * Lh * n,
+                                                   bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
+                        fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                    }
+                    for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
+                    for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i));
+                    { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
+                    d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
+                    { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
+                } else {
+                u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
                 // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
                 // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
                 u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
@@ -1311,6 +1340,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
                 { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
+                }
                 if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
 
                 // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle

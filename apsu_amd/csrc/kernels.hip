@@ -553,19 +553,82 @@ void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batc
     KERNEL_CHECK();
 }
 
+// Step (4) for a SUM of products (eval_patstock's sum over i): the q limbs of every term are kept (their canonical
+// coefficient-form residues are needed per term by the finish), the Bsk limbs are summed here in the NTT domain.
+__global__ __launch_bounds__(EW_T) void k_tensor_sum(const DevLevel *__restrict__ lv, const TensorSumJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const TensorSumJob job = jobs[blockIdx.z];
+    const int E = lv->E, L = lv->L, e = blockIdx.y;
+    const size_t ps = (size_t)E * n, o = (size_t)e * n + k;
+    const Mod m = lv->ext[e];
+    if (e < L) {
+        for (int i = 0; i < job.terms; i++) {
+            const u64 *a = job.a + (size_t)i * 2 * ps, *b = job.b + (size_t)i * 2 * ps;
+            const u64 a0 = a[o], a1 = a[ps + o], b0 = b[o], b1 = b[ps + o];
+            u64 *d = job.dq + (size_t)i * 3 * L * n + o;
+            d[0] = mulmod(a0, b0, m);
+            u128p mid = mul128(a0, b1);
+            mac128(mid, a1, b0);
+            d[(size_t)L * n] = barrett128(mid, m);
+            d[(size_t)2 * L * n] = mulmod(a1, b1, m);
+        }
+    } else {
+        u128p s0{ 0, 0 }, s1{ 0, 0 }, s2{ 0, 0 };
+        u64 r0 = 0, r1 = 0, r2 = 0;
+        for (int i = 0; i < job.terms; i++) {
+            const u64 *a = job.a + (size_t)i * 2 * ps, *b = job.b + (size_t)i * 2 * ps;
+            const u64 a0 = a[o], a1 = a[ps + o], b0 = b[o], b1 = b[ps + o];
+            mac128(s0, a0, b0);
+            mac128(s1, a0, b1);
+            mac128(s1, a1, b0);
+            mac128(s2, a1, b1);
+            if ((i & 7) == 7 || i + 1 == job.terms) {              // 16 products of < 2^62 bits each fit 128 bits
+                r0 = addmod(r0, barrett128(s0, m), m.q);
+                r1 = addmod(r1, barrett128(s1, m), m.q);
+                r2 = addmod(r2, barrett128(s2, m), m.q);
+                s0 = s1 = s2 = u128p{ 0, 0 };
+            }
+        }
+        const int nBsk = E - L;
+        u64 *d = job.bs + (size_t)(e - L) * n + k;
+        d[0] = r0;
+        d[(size_t)nBsk * n] = r1;
+        d[(size_t)2 * nBsk * n] = r2;
+    }
+}
+
+void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_tensor_sum, dim3((unsigned)((n + EW_T - 1) / EW_T), E, njobs), dim3(EW_T), 0, st, lv, jobs, n);
+    KERNEL_CHECK();
+}
+
 // Steps (6)-(8) for one coefficient of one extended polynomial: multiply by t, fast_floor
 // (q u Bsk -> Bsk), fastbconv_sk (Bsk -> q).  d points at limb 0 of the polynomial, stride n.
+//
+// `terms` > 1 finishes a SUM of products in one go (eval_patstock's sum over i, bin_bundle.cpp:273,303): dq holds the q
+// limbs of every term (stride term_stride), dbsk the Bsk limbs of the sum.  The only per-term non-linearity of
+// steps (6)-(8) is the canonical residue [t d (Q/q_j)^-1]_{q_j} feeding fastbconv(q -> Bsk); those residues are
+// summed as integers, everything after is linear mod Bsk_i and fastbconv_sk is exact, so the result equals the
+// sum of the individually finished terms bit for bit (note N1).
 template <int TL, int TNB>
-__device__ __forceinline__ void behz_finish_coeff(const DevLevel *__restrict__ lv, const u64 *__restrict__ d, size_t n,
-                                                  u64 *res /* [L] */)
+__device__ __forceinline__ void behz_finish_coeff(const DevLevel *__restrict__ lv, const u64 *__restrict__ dq, size_t term_stride,
+                                                  int terms, const u64 *__restrict__ dbsk, size_t n, u64 *res /* [L] */)
 {
     const int L = TL ? TL : lv->L, nB = TL ? TNB : lv->nB, nBsk = nB + 1;
     constexpr int LMAX = TL ? TL : DMAXL;
     constexpr int BMAX = TL ? TNB + 1 : DMAXB;
     u64 xq[LMAX];
 #pragma unroll
-    for (int j = 0; j < LMAX; j++)
-        if (TL || j < L) xq[j] = mul_shoup(d[(size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    for (int j = 0; j < LMAX; j++) xq[j] = 0;
+    for (int it = 0; it < terms; it++) {
+#pragma unroll
+        for (int j = 0; j < LMAX; j++)                           // terms * q_j < 2^64 (host-checked)
+            if (TL || j < L) xq[j] += mul_shoup(dq[it * term_stride + (size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    }
     u64 ys[BMAX];
     u64 fl_sk = 0;
 #pragma unroll
@@ -577,7 +640,7 @@ __device__ __forceinline__ void behz_finish_coeff(const DevLevel *__restrict__ l
             for (int j = 0; j < LMAX; j++)
                 if (TL || j < L) mac128(acc, xq[j], lv->q_to_bsk[i][j]);
             const u64 conv = barrett128(acc, m);
-            const u64 xb = mul_shoup(d[(size_t)(L + i) * n], lv->t_bsk[i].w, lv->t_bsk[i].wq, m.q);
+            const u64 xb = mul_shoup(dbsk[(size_t)i * n], lv->t_bsk[i].w, lv->t_bsk[i].wq, m.q);
             const u64 fl = mul_shoup(xb + (m.q - conv), lv->inv_prod_q_bsk[i].w, lv->inv_prod_q_bsk[i].wq, m.q);
             if (i < nB) ys[i] = mul_shoup(fl, lv->inv_punct_B[i].w, lv->inv_punct_B[i].wq, m.q);
             else fl_sk = fl;
@@ -625,7 +688,7 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict
     for (int i = 0; i < job.terms; i++) {
         const u64 *dp = job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k;
         u64 res[LMAX];
-        behz_finish_coeff<TL, TNB>(lv, dp, n, res);
+        behz_finish_coeff<TL, TNB>(lv, dp, 0, 1, dp + (size_t)L * n, n, res);
 #pragma unroll
         for (int j = 0; j < LMAX; j++)
             if (TL || j < L) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
@@ -637,13 +700,18 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict
 
 // Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices (same values as behz_finish_coeff).
 template <int TL>
-__device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ lv, const u64 *__restrict__ d, size_t n, u64 *res)
+__device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ lv, const u64 *__restrict__ dq, size_t term_stride,
+                                                   int terms, const u64 *__restrict__ dbsk, size_t n, u64 *res)
 {
     constexpr int L = TL, nB = TL, nBsk = TL + 1;
     u64 xq[L];
 #pragma unroll
-    for (int j = 0; j < L; j++)                                  // canonical: used as integers by the base conversion
-        xq[j] = mul_shoup(d[(size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    for (int j = 0; j < L; j++) xq[j] = 0;
+    for (int it = 0; it < terms; it++) {
+#pragma unroll
+        for (int j = 0; j < L; j++)                              // canonical: used as integers by the base conversion
+            xq[j] += mul_shoup(dq[it * term_stride + (size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+    }
     u64 ys[nB];
     u64 fl_sk = 0;
 #pragma unroll
@@ -652,7 +720,7 @@ __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ 
         u64 conv = 0;                                            // < 2 L m
 #pragma unroll
         for (int j = 0; j < L; j++) conv += lazy2(xq[j], lv->s_q_to_bsk[i][j], m);
-        const u64 xb = lazy2(d[(size_t)(L + i) * n], lv->t_bsk[i], m);
+        const u64 xb = lazy2(dbsk[(size_t)i * n], lv->t_bsk[i], m);
         const u64 diff = xb + ((u64)(2 * L) * m - conv);         // < (2L + 2) m <= 8 m < 2^64
         const u64 f = mul_shoup(diff, lv->s_fl[i].w, lv->s_fl[i].wq, m);      // i < nB: already times (B/b_i)^-1
         if (i < nB) ys[i] = f; else fl_sk = f;
@@ -689,7 +757,8 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish2(const DevLevel *__restric
     for (int j = 0; j < L; j++) sum[j] = accumulate ? o[(size_t)j * n] : 0;
     for (int i = 0; i < job.terms; i++) {
         u64 res[L];
-        behz_finish_coeff2<TL>(lv, job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k, n, res);
+        const u64 *dp = job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k;
+        behz_finish_coeff2<TL>(lv, dp, 0, 1, dp + (size_t)L * n, n, res);
 #pragma unroll
         for (int j = 0; j < L; j++) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
     }
@@ -709,6 +778,39 @@ void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs
     FIN_CASE(4)
     { hipLaunchKernelGGL((k_behz_finish<0, 0>), g, t, 0, st, lv, jobs, acc, n); }
 #undef FIN_CASE
+    KERNEL_CHECK();
+}
+
+// Finish of a summed product: one job = one BinBundle; out[3][L][n] = sum over terms of the finished products.
+template <int TL, bool LAZY>
+__global__ __launch_bounds__(EW_T) void k_behz_finish_sum(const DevLevel *__restrict__ lv, const FinishSumJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const int L = TL ? TL : lv->L, nBsk = TL ? TL + 1 : lv->nBsk;
+    constexpr int LMAX = TL ? TL : DMAXL;
+    const FinishSumJob job = jobs[blockIdx.y / 3];
+    const size_t p = blockIdx.y % 3;
+    const u64 *dq = job.dq + p * (size_t)L * n + k;
+    const u64 *db = job.bs + p * (size_t)nBsk * n + k;
+    u64 res[LMAX];
+    if constexpr (LAZY) behz_finish_coeff2<TL>(lv, dq, (size_t)3 * L * n, job.terms, db, n, res);
+    else behz_finish_coeff<TL, TL>(lv, dq, (size_t)3 * L * n, job.terms, db, n, res);
+    u64 *o = job.out + p * (size_t)L * n + k;
+#pragma unroll
+    for (int j = 0; j < LMAX; j++)
+        if (TL || j < L) o[(size_t)j * n] = res[j];
+}
+
+void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    const dim3 g = ew_grid(n, njobs * 3), t(EW_T);
+#define FS_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_finish_sum<TL, true>), g, t, 0, st, lv, jobs, n); KERNEL_CHECK(); return; }
+    FS_CASE(1) FS_CASE(2) FS_CASE(3)
+#undef FS_CASE
+    if (L == 4 && nB == 4) hipLaunchKernelGGL((k_behz_finish_sum<4, false>), g, t, 0, st, lv, jobs, n);
+    else hipLaunchKernelGGL((k_behz_finish_sum<0, false>), g, t, 0, st, lv, jobs, n);
     KERNEL_CHECK();
 }
 

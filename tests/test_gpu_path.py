@@ -243,3 +243,16 @@ def test_concurrent_callers_on_one_context():
         t.join()
     assert not errors, errors
     G.close()
+
+
+def test_per_term_product_path_matches():
+    # the summed-Bsk finish of eval_patstock's products (default) and the per-term finish (APSU_HE_EVAL_PER_TERM, read
+    # once per process) must agree; the per-term form runs in a child process
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_path as t\n"
+            "t.test_config_1M_1024_com(); t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced()\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, APSU_HE_EVAL_PER_TERM="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
