@@ -937,6 +937,9 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // else.  `chunk` terms (2*chunk*2^(2s) < 2^64) are accumulated before the sums are recombined
 // (S00 + Sx*2^s + S11*2^(2s)) and reduced; for the 48..56-bit coefficient primes a whole inner polynomial
 // fits in one chunk.
+#ifndef APSU_MAC_RING
+#define APSU_MAC_RING 4
+#endif
 template <int G, int C>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
@@ -1021,6 +1024,35 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     };
 
     const u32 cnt = job.cnt;
+#if APSU_MAC_RING == 4
+    // four register sets, three terms in flight behind the one being consumed (HBM latency x bandwidth needs
+    // more than 64 KB of loads in flight per CU)
+    Term A, B, Cc, D;
+    const u32 last = cnt - 1;
+    load_term(0, A);
+    load_term(1 < cnt ? 1 : last, B);
+    load_term(2 < cnt ? 2 : last, Cc);
+    u32 in_chunk = 0;
+    const u32 nquads = cnt >> 2;
+    for (u32 qd = 0; qd < nquads; qd++) {                        // branch-free body: four terms per trip
+        const u32 i = qd * 4;
+        load_term(i + 3, D);
+        mac_term(A);
+        load_term(i + 4 < cnt ? i + 4 : last, A);                // clamped prefetch (a re-read hits the cache)
+        mac_term(B);
+        load_term(i + 5 < cnt ? i + 5 : last, B);
+        mac_term(Cc);
+        load_term(i + 6 < cnt ? i + 6 : last, Cc);
+        mac_term(D);
+        in_chunk += 4;
+        if (in_chunk + 7 > chunk) { fold(); in_chunk = 1; }      // room for the next quad or the tail; the residue counts as one term
+    }
+    const u32 rem = cnt & 3;                                     // A, B, Cc hold the next three terms
+    if (rem > 0) mac_term(A);
+    if (rem > 1) mac_term(B);
+    if (rem > 2) mac_term(Cc);
+    fold();
+#else
     Term A, B;                                                   // ping-pong register sets: no copies
     load_term(0, A);
     u32 in_chunk = 0;
@@ -1036,6 +1068,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     }
     if (cnt & 1) mac_term(A);                                    // A holds the last term
     fold();
+#endif
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {

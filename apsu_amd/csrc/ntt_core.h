@@ -70,6 +70,22 @@ HD u64 mul_lazy4(u64 x, u64 w, u64 wq, u64 nq)
     return lo + (mid << 32);                                       // x*w - h*q  (mod 2^64)
 }
 
+// Lazy butterfly (x, y) -> (x + v, x - v + 4q) with v = y*w mod q in [0,4q).  The sum rides on the multiply-add
+// chain of the low product (its 64-bit addend is free), the difference is (2x + 4q) - (x + v): three 64-bit
+// add-class instructions fewer per butterfly pair than add / sub / add (64-bit adds cost as much as a multiply here).
+HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
+{
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u64 t1 = (u64)y1 * a0, t2 = (u64)y0 * a1;
+    const u64 h = (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);          // floor(y*wq / 2^64) - {0,1,2}
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
+    const u32 mid = y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+    const u64 s = lo + ((u64)mid << 32);                           // x + v  (mod 2^64)
+    y = ((x << 1) + q4) - s;                                       // x - v + 4q
+    x = s;
+}
+
 enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
 
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
@@ -150,10 +166,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                         const int gap = COLS ? (bit << LOWBITS) : bit;
                         const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
-                        const u64 v = mul_lazy4(y, tv[0], tv[1], nq);
-                        const u64 a = NARROW ? x : csub(x, q4);
-                        x = a + v;
-                        y = a - v + q4;
+                        if (!NARROW) x = csub(x, q4);
+                        bfly_lazy4(x, y, tv[0], tv[1], nq, q4);
                     }
                     continue;
                 }
@@ -165,10 +179,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 for (int gg = 0; gg < G; gg++) {
                     if (!COLS && gg != g) continue;
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
-                    const u64 v = mul_lazy4(y, t.w, t.wq, nq);
-                    const u64 a = NARROW ? x : csub(x, q4);
-                    x = a + v;
-                    y = a - v + q4;
+                    if (!NARROW) x = csub(x, q4);
+                    bfly_lazy4(x, y, t.w, t.wq, nq, q4);
                 }
             }
         }

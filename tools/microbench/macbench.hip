@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 namespace apsu_he { void throw_hip(hipError_t e, const char* f, int l) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), f, l); abort(); } }
 using namespace apsu_he;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -11,29 +12,88 @@ __global__ void k_fillrand(u64* p, size_t words, u64 mask) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
         u64 z = i * 0x9e3779b97f4a7c15ULL + 0x1234; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; p[i] = (z ^ (z >> 31)) & mask; }
 }
+
+// ---- bisect kernels: same loads as k_mac<2,2>, different bodies
+template <int MODE>
+__global__ __launch_bounds__(256) void k_morph(const MacJob *__restrict__ jobs, size_t n, u64 *sink)
+{
+    const size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const MacJob *__restrict__ jp = jobs + blockIdx.z / 2;
+    const int g0 = (blockIdx.z % 2) * 2;
+    const int j = blockIdx.y;
+    const u64 *p0 = jp->pw + (size_t)j * n + k, *p1 = p0 + jp->pw_poly_stride;
+    const u64 *a0 = jp->pt[g0] + (size_t)j * n + k, *a1 = jp->pt[g0 + 1] + (size_t)j * n + k;
+    const u32 cnt = jp->cnt, pts = jp->pt_stride, pws = jp->pw_stride;
+    u64 acc = 0;
+    if (MODE == 0) {            // simple loop, compiler-scheduled
+        for (u32 i = 0; i < cnt; i++) {
+            const u64x2 c0 = ldg16(p0 + (size_t)i * pws), c1 = ldg16(p1 + (size_t)i * pws);
+            const u64x2 x = ldg16_nt(a0 + (size_t)i * pts), y = ldg16_nt(a1 + (size_t)i * pts);
+            acc += (x[0] * c0[0]) ^ (x[1] * c1[1]) ^ (y[0] * c0[1]) ^ (y[1] * c1[0]);
+        }
+    } else if (MODE == 1) {     // unroll 4
+#pragma unroll 4
+        for (u32 i = 0; i < cnt; i++) {
+            const u64x2 c0 = ldg16(p0 + (size_t)i * pws), c1 = ldg16(p1 + (size_t)i * pws);
+            const u64x2 x = ldg16_nt(a0 + (size_t)i * pts), y = ldg16_nt(a1 + (size_t)i * pts);
+            acc += (x[0] * c0[0]) ^ (x[1] * c1[1]) ^ (y[0] * c0[1]) ^ (y[1] * c1[0]);
+        }
+    } else if (MODE == 2) {     // no power loads at all
+#pragma unroll 4
+        for (u32 i = 0; i < cnt; i++) {
+            const u64x2 x = ldg16_nt(a0 + (size_t)i * pts), y = ldg16_nt(a1 + (size_t)i * pts);
+            acc += (x[0] * 3) ^ (x[1] * 5) ^ (y[0] * 7) ^ (y[1] * 11);
+        }
+    } else if (MODE == 3) {     // 4 streams per block (G = 4): half the power loads per DB byte
+        const u64 *a2 = jp->pt[(g0 + 2) & 3] + (size_t)j * n + k, *a3 = jp->pt[(g0 + 3) & 3] + (size_t)j * n + k;
+        if (g0) return;
+#pragma unroll 2
+        for (u32 i = 0; i < cnt; i++) {
+            const u64x2 c0 = ldg16(p0 + (size_t)i * pws), c1 = ldg16(p1 + (size_t)i * pws);
+            const u64x2 x = ldg16_nt(a0 + (size_t)i * pts), y = ldg16_nt(a1 + (size_t)i * pts);
+            const u64x2 z = ldg16_nt(a2 + (size_t)i * pts), w = ldg16_nt(a3 + (size_t)i * pts);
+            acc += (x[0] * c0[0]) ^ (x[1] * c1[1]) ^ (y[0] * c0[1]) ^ (y[1] * c1[0]) ^ (z[0] * c0[0]) ^ (z[1] * c1[1]) ^ (w[0] * c0[1]) ^ (w[1] * c1[0]);
+        }
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
 int main(int argc, char** argv) {
     const size_t n = 8192, L = 3, ptw = L * n;
-    const int terms = 44, streams = 784, nb = argc > 1 ? atoi(argv[1]) : 4;       // nb: bundle indices interleaved in the powers layout
+    const int terms = 44, streams = 784, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
     const size_t words = (size_t)streams * terms * ptw;
     u64 *db, *pw, *out; DevLevel* lv; MacJob* dj;
-    CHECK(hipMalloc(&db, words * 8)); CHECK(hipMalloc(&pw, (size_t)terms * nb * 2 * L * n * 8)); CHECK(hipMalloc(&out, (size_t)streams * 2 * L * n * 8));
-    k_fillrand<<<4096, 256>>>(db, words, ((u64)1 << 55) - 1); k_fillrand<<<1024, 256>>>(pw, (size_t)terms * nb * 2 * L * n, ((u64)1 << 55) - 1);
+    CHECK(hipMalloc(&db, words * 8)); const size_t pstride = nb * 2 * L * n + pad + 2 * ppad; CHECK(hipMalloc(&pw, (size_t)terms * pstride * 8)); CHECK(hipMalloc(&out, (size_t)streams * 2 * L * n * 8));
+    k_fillrand<<<4096, 256>>>(db, words, ((u64)1 << 55) - 1); k_fillrand<<<1024, 256>>>(pw, (size_t)terms * pstride, ((u64)1 << 55) - 1);
     DevLevel h; memset(&h, 0, sizeof(h)); h.L = 3;
     u64 q[3] = { 0xfffffffff70001ULL, 0xfffffffff78001ULL, 0xfffffffffb4001ULL };
     for (int j = 0; j < 3; j++) { unsigned __int128 all = ~(unsigned __int128)0; unsigned __int128 r = all / q[j]; h.q[j] = Mod{ q[j], (u64)r, (u64)(r >> 64) }; h.mac_shift[j] = 28; h.mac_chunk[j] = 127; }
     CHECK(hipMalloc(&lv, sizeof(h))); CHECK(hipMemcpy(lv, &h, sizeof(h), hipMemcpyHostToDevice));
     std::vector<MacJob> jobs;
     for (int s = 0; s < streams; s += MAC_G) {
-        MacJob j{}; j.pw = pw; j.cnt = terms; j.ng = MAC_G; j.pt_stride = ptw; j.pw_stride = nb * 2 * L * n; j.pw_poly_stride = L * n; j.out_poly_stride = L * n; j.limb0 = 0;
+        MacJob j{}; j.pw = pw; j.cnt = terms; j.ng = MAC_G; j.pt_stride = ptw; j.pw_stride = pstride; j.pw_poly_stride = L * n + ppad; j.nl = 3; j.out_poly_stride = L * n; j.limb0 = 0;
         for (int g = 0; g < MAC_G; g++) { j.pt[g] = db + (size_t)(s + g) * terms * ptw; j.out[g] = out + (size_t)(s + g) * 2 * L * n; }
         jobs.push_back(j);
     }
     CHECK(hipMalloc(&dj, jobs.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(MacJob), hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; rep++) {
-        CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj, n, (int)jobs.size(), 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
-        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep) printf("k_mac<%d,%d> nb=%d: %.3f ms  %.0f GB/s (DB bytes)\n", APSU_MAC_G, APSU_MAC_C, nb, ms, words * 8 / (ms * 1e-3) / 1e9);
+    {
+        std::vector<float> t;
+        for (int rep = 0; rep < 16; rep++) {
+            CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj, n, (int)jobs.size(), 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep >= 2) t.push_back(ms);
+        }
+        std::sort(t.begin(), t.end());
+        printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, APSU_MAC_RING, nb, pad,
+               t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
+    }
+    if (!getenv("MORPH")) return 0;
+    for (int rep = 0; rep < 2; rep++) {
+#define MORPH(M, NAME) { CHECK(hipEventRecord(e0)); hipLaunchKernelGGL((k_morph<M>), dim3(16, 3, (unsigned)jobs.size() * 2), dim3(256), 0, 0, dj, n, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep) printf("%-40s %.3f ms  %.0f GB/s\n", NAME, ms, words * 8 / (ms * 1e-3) / 1e9); }
+        MORPH(0, "morph simple loop")
+        MORPH(1, "morph unroll 4")
+        MORPH(2, "morph no power loads")
+        MORPH(3, "morph G=4")
     }
     return 0;
 }
