@@ -85,6 +85,9 @@ struct MacJob {
 // tabs[modmap[g % period]].
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
                 int period, hipStream_t st);
+// forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n
+void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
+                       hipStream_t st);
 // out = a (.) b per limb; a:[batch][polys][L][n], b:[batch][L][n] (b_batch_stride may be 0)
 void launch_dyadic_plain(const DevLevel *lv, const u64 *ct, const u64 *pt, u64 *out, int polys, size_t n, int batch,
                          size_t pt_batch_stride, hipStream_t st);

@@ -415,8 +415,14 @@ void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
     const int L = chain_idx + 1;
     const size_t n = hp_.n;
     u64 *tdec = ws((size_t)batch * (L + 1) * L * n);
-    { PROF(P_KEYSWITCH, 0); launch_ks_decomp(dkey(), L, ct3 + (size_t)2 * L * n, ct_stride, tdec, n, batch, st_); }
-    d_ntt(tdec, (size_t)batch * (L + 1) * L, map_ks(chain_idx), (L + 1) * L, false);
+    {   // tdec[b][I][J] = NTT_I(c2[b][J] mod m_I): the decomposition is the NTT's load (no separate pass)
+        std::vector<const u64 *> src((size_t)batch * (L + 1) * L);
+        for (int b = 0; b < batch; b++)
+            for (int I = 0; I <= L; I++)
+                for (int J = 0; J < L; J++) src[((size_t)b * (L + 1) + I) * L + J] = ct3 + (size_t)b * ct_stride + ((size_t)2 * L + J) * n;
+        PROF(P_NTT_FWD, src.size());
+        launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_);
+    }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
     { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
@@ -807,15 +813,17 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         // sources (receiver_osn.cpp:304-317)
         {
             int si = 0;
+            std::vector<CtJob> cj;                               // device-resident sources: one gather launch
             for (auto &kv : dag_.nodes()) {
                 if (!kv.second.is_source()) continue;
                 for (int b = 0; b < nb; b++) {
                     const u64 *sp = src[(size_t)b * dag_.source_count() + si];
-                    if (on_device) D2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
+                    if (on_device) cj.push_back(CtJob{ sp, slot_ptr(s.slot_of[kv.first], b) });
                     else H2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
                 }
                 si++;
             }
+            if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), st_); }
         }
         if (dag_.depth() > 0) {
             u64 *ext = ws(P * nb * 2 * Ef * n);

@@ -17,8 +17,8 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, bool NARROW, int T>
-__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid)
+template <int LOGN, bool INV, bool NARROW, int T, bool RED = false>
+__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr)
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
@@ -27,7 +27,8 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
             *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = *reinterpret_cast<const u64x2 *>(p + e);
         __syncthreads();
     }
-    ntt_pass<LOGN, INV, NARROW, 0>(lds, p, tid, T, tab);
+    if constexpr (RED) ntt_pass<LOGN, INV, NARROW, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
+    else ntt_pass<LOGN, INV, NARROW, 0>(lds, p, tid, T, tab);
     if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 1>(lds, p, tid, T, tab); }
     if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 2>(lds, p, tid, T, tab); }
     if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 3>(lds, p, tid, T, tab); }
@@ -54,6 +55,35 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     u64 *p = data + g * N;
     if (tab.narrow) ntt_body<LOGN, INV, true, T>(lds, p, tab, tid);       // wave-uniform branch
     else ntt_body<LOGN, INV, false, T>(lds, p, tab, tid);
+}
+
+// Forward NTT of gathered limbs: limb g is read from src[g] (residues of another modulus, reduced on load) and written
+// to data + g*N.  Replaces the decompose kernel of the key switch (App. B10): out[I][J] = NTT_I(c2_J mod m_I).
+template <int LOGN, int T>
+__global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restrict__ src, u64 *__restrict__ data,
+                                                  const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period)
+{
+    constexpr int N = 1 << LOGN;
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const NttTable tab = tabs[modmap[g % (size_t)period]];
+    u64 *p = data + g * N;
+    if (tab.narrow) ntt_body<LOGN, false, true, T, true>(lds, p, tab, tid, src[g]);
+    else ntt_body<LOGN, false, false, T, true>(lds, p, tab, tid, src[g]);
+}
+
+void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
+                       hipStream_t st)
+{
+    if (!count) return;
+#define G_CASE(LN, T) case LN: hipLaunchKernelGGL((k_ntt_gather<LN, T>), dim3((unsigned)count), dim3(T), 0, st, src, data, tabs, modmap, period); break;
+    switch (logn) {
+    G_CASE(13, 512) G_CASE(12, 256) G_CASE(11, 128) G_CASE(10, 64) G_CASE(8, 64) G_CASE(6, 64)
+    default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+#undef G_CASE
+    KERNEL_CHECK();
 }
 
 template <int LOGN, int T>

@@ -91,7 +91,7 @@ enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
-template <int LOGN, int S, int K, bool INV, bool NARROW, int IN, int OUT>
+template <int LOGN, int S, int K, bool INV, bool NARROW, int IN, int OUT, bool RED = false>
 HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 {
     constexpr int R = 1 << K;                  // radix
@@ -143,6 +143,16 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
             for (int j = 0; j < R; j++) {
                 const int e = idx(g, j);
                 r[g][j] = (IN == IO_GLOBAL) ? glob[e] : lds[lds_slot(e)];
+            }
+    }
+
+    if (RED && IN == IO_GLOBAL) {              // gathered input holds residues of ANOTHER modulus: reduce on load
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const u64 v = r[g][j] - mulhi64(r[g][j], tab.r1) * q;
+                r[g][j] = csub(v, q);
             }
     }
 
@@ -269,7 +279,7 @@ constexpr int plan_s(int logn, int p)
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads LDS (caller staged the limb there),
 //            the last pass writes the scaled result straight to global memory.
-template <int LOGN, bool INV, bool NARROW, int PASS>
+template <int LOGN, bool INV, bool NARROW, int PASS, bool RED = false>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
 {
     constexpr int P = plan_passes(LOGN);
@@ -278,5 +288,5 @@ HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
     constexpr int S = plan_s(LOGN, p);
     constexpr int IN = (!INV && PASS == 0) ? IO_GLOBAL : IO_LDS;
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, NARROW, IN, OUT>(lds, glob, w, tab);
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, NARROW, IN, OUT, RED>(lds, glob, w, tab);
 }

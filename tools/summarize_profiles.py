@@ -6,11 +6,13 @@ src, dst = os.path.join("gpurun_out", tag), "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)          # gpurun merges every call's files: take the last run
+shutil.copy(newest(os.path.join(src, "stats", "*", "*kernel_stats.csv")), os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "ntt_stream.txt"), os.path.join(dst, tag + "_ntt_stream.txt"))
 
 def agg(path):
-    rows = list(csv.DictReader(open(glob.glob(path)[0])))
+    rows = list(csv.DictReader(open(newest(path))))
     d = collections.defaultdict(lambda: [0.0, 0, 0])
     for r in rows:
         name = r["Kernel_Name"]
