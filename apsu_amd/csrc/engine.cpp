@@ -57,6 +57,13 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    {   // the second stream carries short latency-bound chains that must make progress next to a grid-filling kernel
+        // of the main stream (the BinBundle inner products): highest dispatch priority
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
 
     const size_t n = hp_.n;
     const int nmod = (int)hp_.ntt.size();
@@ -205,6 +212,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     size_t init = 4096 * n * sizeof(u64);          // 256 MiB at n = 8192; grows on demand
     if (const char *env = std::getenv("APSU_HE_ARENA_BYTES")) init = std::strtoull(env, nullptr, 10);
     arena_.alloc(init);
+    parked_.arena.alloc(std::max<size_t>(init / 4, (size_t)1 << 20));
     stage_bytes_ = 4u << 20;
     HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
 }
@@ -212,13 +220,26 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
 Engine::~Engine()
 {
     if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    if (parked_.st) { (void)hipStreamSynchronize(parked_.st); (void)hipStreamDestroy(parked_.st); }
+    if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
 }
 
 void Engine::sync()
 {
     HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipStreamSynchronize(parked_.st));
     if (prof_on_) prof_collect();
+}
+
+void Engine::switch_lane(int lane)
+{
+    if (lane == cur_lane_) return;
+    std::swap(st_, parked_.st);
+    std::swap(arena_, parked_.arena);
+    std::swap(arena_off_, parked_.off);
+    std::swap(job_seq_, parked_.job_seq);
+    cur_lane_ = lane;
 }
 
 // ---- profiling: one HIP event pair per launch on the engine's stream, resolved at the next sync
@@ -226,6 +247,7 @@ void Engine::profile_enable(int mode)
 {
     std::lock_guard<std::mutex> g(mu_);
     HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipStreamSynchronize(parked_.st));
     prof_collect();
     prof_on_ = mode != 0;
     prof_ntt_only_ = mode == 2;
@@ -235,6 +257,7 @@ void Engine::profile_read(ProfStats *out, bool reset)
 {
     std::lock_guard<std::mutex> g(mu_);
     HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipStreamSynchronize(parked_.st));
     prof_collect();
     if (out) *out = prof_;
     if (reset) prof_ = ProfStats{};
@@ -332,7 +355,7 @@ void Engine::check_level(int chain_idx) const
 u64 *Engine::ws(size_t words)
 {
     size_t bytes = (words * sizeof(u64) + 255) & ~(size_t)255;
-    if (arena_off_ + bytes > arena_.bytes()) throw ArenaOverflow{ arena_off_ + bytes };
+    if (arena_off_ + bytes > arena_.bytes()) { overflow_lane_ = cur_lane_; throw ArenaOverflow{ arena_off_ + bytes }; }
     u64 *p = reinterpret_cast<u64 *>(static_cast<char *>(arena_.p()) + arena_off_);
     arena_off_ += bytes;
     return p;
@@ -340,13 +363,19 @@ u64 *Engine::ws(size_t words)
 
 void Engine::ws_reset(size_t need)
 {
+    if (need) {                                   // grow the lane whose bump allocator overflowed
+        switch_lane(overflow_lane_);
+        if (need > arena_.bytes()) {
+            sync();
+            arena_.release();
+            arena_.alloc(need + need / 4);
+        }
+    }
+    switch_lane(0);
     arena_off_ = 0;
     job_seq_ = job_seq_base_;
-    if (need > arena_.bytes()) {
-        sync();
-        arena_.release();
-        arena_.alloc(need + need / 4);
-    }
+    parked_.off = 0;
+    parked_.job_seq = job_seq_base_ + 128;        // lane 1 uses the upper half of the call's job-cache slots
 }
 
 template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
@@ -721,16 +750,20 @@ std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cach
 }
 
 // ============================================================================ tier 2: ComputePowers
-void Engine::build_schedule()
+void Engine::build_schedule_for(Sched &s, const std::vector<char> &member)
 {
-    Sched &s = sched_;
+    s = Sched{};
     const auto &nodes = dag_.nodes();
     const uint32_t max_power = *dag_.target_powers().rbegin();
     std::vector<char> is_parent(max_power + 1, 0);
-    for (auto &kv : nodes)
+    uint32_t depth = 0;
+    for (auto &kv : nodes) {
+        if (!member[kv.first]) continue;
+        depth = std::max(depth, kv.second.depth);
         if (!kv.second.is_source()) { is_parent[kv.second.parents.first] = 1; is_parent[kv.second.parents.second] = 1; }
+    }
     std::vector<PowersDag::PowersNode> order;
-    for (auto &kv : nodes) order.push_back(kv.second);
+    for (auto &kv : nodes) if (member[kv.first]) order.push_back(kv.second);
     std::stable_sort(order.begin(), order.end(), [&](const auto &a, const auto &b) {
         if (a.depth != b.depth) return a.depth < b.depth;
         if (is_parent[a.power] != is_parent[b.power]) return is_parent[a.power] > is_parent[b.power];
@@ -738,8 +771,8 @@ void Engine::build_schedule()
     });
     s.slot_of.assign(max_power + 1, -1);
     for (size_t i = 0; i < order.size(); i++) { s.slot_power.push_back(order[i].power); s.slot_of[order[i].power] = (int)i; }
-    s.levels.assign(dag_.depth() + 1, Sched::Level{ 0, 0, 0 });
-    for (uint32_t d = 0; d <= dag_.depth(); d++) {
+    s.levels.assign(depth + 1, Sched::Level{ 0, 0, 0 });
+    for (uint32_t d = 0; d <= depth; d++) {
         int s0 = -1, s1 = -1, sp = -1;
         for (size_t i = 0; i < order.size(); i++) {
             if (order[i].depth != d) continue;
@@ -747,6 +780,7 @@ void Engine::build_schedule()
             s1 = (int)i + 1;
             if (is_parent[order[i].power]) sp = (int)i + 1;
         }
+        if (s0 < 0) s0 = s1 = 0;                      // no node of this subset at this depth
         if (sp < 0) sp = s0;
         s.levels[d] = Sched::Level{ s0, s1, sp };
     }
@@ -755,67 +789,71 @@ void Engine::build_schedule()
             s.nodes.push_back({ (int)i, s.slot_of[order[i].parents.first], s.slot_of[order[i].parents.second] });
     const uint32_t ps = psu_.query_params.ps_low_degree;
     for (uint32_t p : dag_.target_powers()) {
+        if (!member[p]) continue;
         if (!ps || p <= ps) s.low_powers.push_back(p);
         else s.high_powers.push_back(p);
     }
 }
 
-std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
-                                               const RelinKeys *rk)
+void Engine::build_schedule()
 {
-    std::lock_guard<std::mutex> g(mu_);
-    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
-    if (nb <= 0) throw std::invalid_argument("no bundle indices given");
-    if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
-    const Sched &s = sched_;
+    const auto &nodes = dag_.nodes();
+    const uint32_t max_power = *dag_.target_powers().rbegin();
+    build_schedule_for(sched_, std::vector<char>(max_power + 1, 1));
+    // The powers that stay at the low level and the Paterson-Stockmeyer high powers usually descend from different
+    // query powers (all four reference parameter sets).  Then ComputePowers is two independent chains: the second one
+    // runs on its own stream, next to the first and to the BinBundle inner products that only need the low powers.
+    split_ok_ = false;
+    if (sched_.high_powers.empty() || sched_.low_powers.empty() || dag_.depth() == 0) return;
+    auto closure = [&](const std::vector<uint32_t> &targets) {
+        std::vector<char> m(max_power + 1, 0);
+        std::vector<uint32_t> stack(targets.begin(), targets.end());
+        while (!stack.empty()) {
+            const uint32_t p = stack.back();
+            stack.pop_back();
+            if (m[p]) continue;
+            m[p] = 1;
+            const auto &nd = nodes.at(p);
+            if (!nd.is_source()) { stack.push_back(nd.parents.first); stack.push_back(nd.parents.second); }
+        }
+        return m;
+    };
+    const auto ml = closure(sched_.low_powers), mh = closure(sched_.high_powers);
+    for (uint32_t p = 0; p <= max_power; p++) if (ml[p] && mh[p]) return;
+    build_schedule_for(sched_low_, ml);
+    build_schedule_for(sched_high_, mh);
+    split_ok_ = true;
+}
+
+// One walk over a (sub)schedule of the PowersDag on the current lane: sources, the level-synchronous products, and the
+// final per-power conversions (receiver_osn.cpp:395-488).
+//   stage 0: workspace + sources;  stage d >= 1: the products of depth d;  stage -1: final conversions.
+// The stages of one walk must run in order on one lane; `run` carries the walk's buffers between them, so two walks
+// (the halves of a split DAG) can be interleaved level by level on two lanes.
+struct Engine::DagRun { u64 *pwf = nullptr, *ext = nullptr, *dbuf = nullptr; size_t arena_mark = 0; };
+
+void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *const *src, bool on_device, const RelinKeys *rk,
+                     Powers &pwr, bool do_low, bool do_high)
+{
+    Powers *pw = &pwr;
     const size_t n = hp_.n;
-    job_seq_base_ = 0;                                       // job-cache slots 0..255: ComputePowers
-    const int first = hp_.first_chain_idx, high = hp_.clamp_chain_idx(1), low = hp_.clamp_chain_idx(2);
-    const uint32_t ps = psu_.query_params.ps_low_degree;
-    const int low_target = ps ? low : high;                 // receiver_osn.cpp:459-487
+    const int first = hp_.first_chain_idx, high = hp_.clamp_chain_idx(1);
+    const int low_target = pw->low_level;
     const size_t Lf = first + 1, Ef = dlevel(first) ? (size_t)(hlevel(first).L + hlevel(first).nB + 1) : 0;
     const size_t P = s.slot_power.size();
     const size_t slot_w = 3 * Lf * n;                       // (c0, c1, c2 scratch) per power and bundle index
-
-    const size_t Ll_ = low_target + 1, Lh_ = high + 1, Eh_ = hlevel(high).L + hlevel(high).nB + 1;
-    const size_t need_low = s.low_powers.size() * nb * 2 * Ll_ * n * sizeof(u64);
-    const size_t need_high = s.high_powers.size() * nb * 2 * Lh_ * n * sizeof(u64);
-    const size_t need_hext = s.high_powers.size() * nb * 2 * Eh_ * n * sizeof(u64);
-    std::unique_ptr<Powers> pw;
-    for (size_t i = 0; i < powers_pool_.size(); i++) {
-        Powers &c = *powers_pool_[i];
-        if (c.low.bytes() == need_low && c.high.bytes() == need_high && c.hext.bytes() == need_hext) {
-            pw = std::move(powers_pool_[i]);
-            powers_pool_.erase(powers_pool_.begin() + i);
-            break;
-        }
-    }
-    const bool recycled = (bool)pw;
-    if (!pw) pw = std::make_unique<Powers>();
-    pw->nb = nb;
-    pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
-    pw->low_level = low_target;
-    pw->high_level = high;
-    pw->n_low = (uint32_t)s.low_powers.size();
-    pw->n_high = (uint32_t)s.high_powers.size();
     const size_t Lh = high + 1, Eh = hlevel(high).L + hlevel(high).nB + 1;
-    if (!recycled) {
-        pw->low.alloc(need_low);
-        if (pw->n_high) {
-            pw->high.alloc(need_high);
-            pw->hext.alloc(need_hext);
-        }
-    }
-
-    WITH_ARENA({
-        u64 *pwf = ws(P * nb * slot_w);
-        auto slot_ptr = [&](int slot, int b) { return pwf + ((size_t)slot * nb + b) * slot_w; };
+    auto slot_ptr = [&](int slot, int b) { return run.pwf + ((size_t)slot * nb + b) * slot_w; };
+    auto ext_ptr = [&](int slot, int b) { return run.ext + ((size_t)slot * nb + b) * 2 * Ef * n; };
+    {
         // sources (receiver_osn.cpp:304-317)
-        {
+        if (stage == 0) {
+            run.pwf = ws(P * nb * slot_w);
             int si = 0;
             std::vector<CtJob> cj;                               // device-resident sources: one gather launch
             for (auto &kv : dag_.nodes()) {
                 if (!kv.second.is_source()) continue;
+                if (s.slot_of[kv.first] < 0) { si++; continue; }        // belongs to the other half of a split DAG
                 for (int b = 0; b < nb; b++) {
                     const u64 *sp = src[(size_t)b * dag_.source_count() + si];
                     if (on_device) cj.push_back(CtJob{ sp, slot_ptr(s.slot_of[kv.first], b) });
@@ -824,16 +862,21 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 si++;
             }
             if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), st_); }
+            if (s.levels.size() > 1) {
+                run.ext = ws(P * nb * 2 * Ef * n);
+                size_t max_nodes = 0;
+                for (size_t d = 1; d < s.levels.size(); d++) max_nodes = std::max(max_nodes, (size_t)(s.levels[d].s1 - s.levels[d].s0));
+                run.dbuf = ws(max_nodes * nb * 3 * Ef * n);
+            }
+            run.arena_mark = arena_off_;
+            return;
         }
-        if (dag_.depth() > 0) {
-            u64 *ext = ws(P * nb * 2 * Ef * n);
-            auto ext_ptr = [&](int slot, int b) { return ext + ((size_t)slot * nb + b) * 2 * Ef * n; };
-            size_t max_nodes = 0;
-            for (size_t d = 1; d < s.levels.size(); d++) max_nodes = std::max(max_nodes, (size_t)(s.levels[d].s1 - s.levels[d].s0));
-            u64 *dbuf = ws(max_nodes * nb * 3 * Ef * n);
-            const size_t arena_mark = arena_off_;
-            for (size_t d = 1; d < s.levels.size(); d++) {
-                arena_off_ = arena_mark;
+        if (stage > 0) {
+            if ((size_t)stage >= s.levels.size()) return;
+            u64 *dbuf = run.dbuf;
+            {
+                const size_t d = (size_t)stage;
+                arena_off_ = run.arena_mark;
                 // extend + NTT the parents that became available at depth d-1
                 const auto &pl = s.levels[d - 1];
                 const int npar = pl.sp - pl.s0;
@@ -843,6 +886,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 }
                 const auto &cl = s.levels[d];
                 const int nn = cl.s1 - cl.s0;
+                if (nn <= 0) return;
                 std::vector<TensorJob> tj;
                 std::vector<FinishJob> fj;
                 for (auto &nd : s.nodes) {
@@ -856,10 +900,11 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }                 // :422/:424
                 d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext(first), (int)Ef, true);
                 { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
-                if (hp_.using_keyswitching) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
+                if (hp_.using_keyswitching && nn > 0) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
             }
-            arena_off_ = arena_mark;
+            return;
         }
+        arena_off_ = run.arena_mark;
         // final per-power conversions (receiver_osn.cpp:459-487)
         auto convert = [&](const std::vector<uint32_t> &powers, int target, u64 *out) {
             if (powers.empty()) return;
@@ -890,16 +935,102 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
                 lvl--;
             }
         };
-        convert(s.low_powers, low_target, pw->low.u());
-        d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                          // :467,475
-        if (pw->n_high) {
+        if (do_low) {
+            convert(s.low_powers, low_target, pw->low.u());
+            d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                      // :467,475
+        }
+        if (do_high && pw->n_high) {
             convert(s.high_powers, high, pw->high.u());
             // derived form used by eval_patstock's ct x ct products and coefficient-form plaintext products
             { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
             d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
         }
+    }
+}
+
+std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
+                                               const RelinKeys *rk)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (nb <= 0) throw std::invalid_argument("no bundle indices given");
+    if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
+    const Sched &s = sched_;
+    const size_t n = hp_.n;
+    job_seq_base_ = 0;                                       // job-cache slots 0..255: ComputePowers
+    const int high = hp_.clamp_chain_idx(1), low = hp_.clamp_chain_idx(2);
+    const uint32_t ps = psu_.query_params.ps_low_degree;
+    const int low_target = ps ? low : high;                 // receiver_osn.cpp:459-487
+    const size_t Ll_ = low_target + 1, Lh_ = high + 1, Eh_ = hlevel(high).L + hlevel(high).nB + 1;
+    const size_t need_low = s.low_powers.size() * nb * 2 * Ll_ * n * sizeof(u64);
+    const size_t need_high = s.high_powers.size() * nb * 2 * Lh_ * n * sizeof(u64);
+    const size_t need_hext = s.high_powers.size() * nb * 2 * Eh_ * n * sizeof(u64);
+    std::unique_ptr<Powers> pw;
+    for (size_t i = 0; i < powers_pool_.size(); i++) {
+        Powers &c = *powers_pool_[i];
+        if (c.low.bytes() == need_low && c.high.bytes() == need_high && c.hext.bytes() == need_hext) {
+            pw = std::move(powers_pool_[i]);
+            powers_pool_.erase(powers_pool_.begin() + i);
+            break;
+        }
+    }
+    const bool recycled = (bool)pw;
+    if (!pw) pw = std::make_unique<Powers>();
+    pw->nb = nb;
+    pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
+    pw->low_level = low_target;
+    pw->high_level = high;
+    pw->n_low = (uint32_t)s.low_powers.size();
+    pw->n_high = (uint32_t)s.high_powers.size();
+    if (!recycled) {
+        pw->low.alloc(need_low);
+        if (pw->n_high) {
+            pw->high.alloc(need_high);
+            pw->hext.alloc(need_hext);
+        }
+    }
+
+    struct LaneGuard { Engine *e; ~LaneGuard() { e->switch_lane(0); } } lane_guard{ this };
+    // Two-stream walk (APSU_HE_SPLIT=1): the high-power half of the DAG runs on the second stream next to the low-power
+    // half and to the BinBundle inner products.  Measured on 16M-4096: 4.17 -> 4.03 ms per query at four bundle indices,
+    // nothing at one (the merged level-synchronous walk already has the longer chain's launch count), and per-kernel
+    // timings stop being additive — so it is opt-in.
+    static const bool split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v && atoi(v) != 0; }();
+    const bool split = split_ok_ && on_device && split_env;   // host inputs end with a sync anyway
+    pw->high_async = split;
+    if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
+    WITH_ARENA({
+        if (!split) {
+            DagRun r;
+            run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
+            for (int d = 1; d < (int)sched_.levels.size(); d++) run_dag(sched_, r, d, nb, src, on_device, rk, *pw, true, true);
+            run_dag(sched_, r, -1, nb, src, on_device, rk, *pw, true, true);
+        } else {
+            // everything queued so far on the main stream (the previous query's evaluation may still read a pooled
+            // Powers buffer) precedes the second stream's work; the two walks are queued level by level so that
+            // both streams have work from the start
+            DagRun rl, rh;
+            HIP_CHECK(hipEventRecord(ev_main_, st_));
+            run_dag(sched_low_, rl, 0, nb, src, on_device, rk, *pw, true, false);
+            switch_lane(1);
+            HIP_CHECK(hipStreamWaitEvent(st_, ev_main_, 0));
+            run_dag(sched_high_, rh, 0, nb, src, on_device, rk, *pw, false, true);
+            const int depth = (int)std::max(sched_low_.levels.size(), sched_high_.levels.size());
+            for (int d = 1; d < depth; d++) {
+                switch_lane(0);
+                run_dag(sched_low_, rl, d, nb, src, on_device, rk, *pw, true, false);
+                switch_lane(1);
+                run_dag(sched_high_, rh, d, nb, src, on_device, rk, *pw, false, true);
+            }
+            switch_lane(0);
+            run_dag(sched_low_, rl, -1, nb, src, on_device, rk, *pw, true, false);
+            switch_lane(1);
+            run_dag(sched_high_, rh, -1, nb, src, on_device, rk, *pw, false, true);
+            HIP_CHECK(hipEventRecord(pw->high_ready, st_));
+            switch_lane(0);
+        }
         // device-resident inputs: no sync, consumers (eval_bundles, powers_download) are ordered on / synchronise
-        // with the engine's stream.  Host inputs: the caller's buffers must have been consumed before returning.
+        // with the engine's streams.  Host inputs: the caller's buffers must have been consumed before returning.
         if (!on_device) sync();
     });
     return pw;
@@ -1233,9 +1364,12 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
                 const size_t w_inner = (size_t)NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
                 const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
+                // high powers still in flight on the second stream (split ComputePowers): everything that needs only the
+                // low powers goes first, the cf products wait for them
+                const bool late_high = pw.high_async && pw.high_ready;
                 const size_t w_cf = (size_t)Bs * 2 * Lh * n;
-                u64 *inner = ws(w_inner + w_ssum + w_vlast + w_term + w_cf);
-                u64 *ssum = inner + w_inner, *vlast = ssum + w_ssum, *term = vlast + w_vlast, *cf = term + w_term;
+                u64 *inner = ws(w_inner + w_ssum + w_vlast + w_term + (late_high ? 0 : w_cf));
+                u64 *ssum = inner + w_inner, *vlast = ssum + w_ssum, *term = vlast + w_vlast, *cf = late_high ? nullptr : term + w_term;
                 std::vector<MacStream> ms;
                 std::vector<int> imap;                                  // modulus of every limb polynomial of the merged block
                 auto map_push = [&](size_t polys, int first_limb, int limbs) {
@@ -1278,12 +1412,14 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     if (i0_fast) map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
                     else map_push((size_t)Bs * l * 2, 0, (int)Ll);
                 }
-                for (int x = 0; x < Bs; x++) {
-                    const Bundle &b = *bundles[c0 + ps_ids[x]];
-                    ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + ps_ids[x]]), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
-                                            (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh });
-                }
-                map_push((size_t)Bs * 2, 0, (int)Lh);
+                auto cf_streams = [&](std::vector<MacStream> &out) {
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + ps_ids[x]];
+                        out.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + ps_ids[x]]), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
+                                                 (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh });
+                    }
+                };
+                if (!late_high) { cf_streams(ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
                 // the level-`low` constants serve every limb: levels share their leading primes
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt(inner, imap.size(), upload_jobs(imap), (int)imap.size(), true);                       // :268,297,320,333
@@ -1298,6 +1434,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 u64 *ext = ws((size_t)NI * 2 * Eh * n);
                 { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                 d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
+                if (late_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
                 u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
                 // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
                 // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
@@ -1310,8 +1447,14 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                     (unsigned __int128)max_terms * hlevel(high).q[0] < ((unsigned __int128)1 << 63);
                 if (summed) {
                     const size_t nBskh = Eh - Lh;
-                    u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n);
+                    u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
                     u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
+                    if (late_high) {                                    // the cf sums join this inverse-NTT launch
+                        cf = bsum + (size_t)Bs * 3 * nBskh * n;
+                        std::vector<MacStream> cs;
+                        cf_streams(cs);
+                        auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
+                    }
                     std::vector<TensorSumJob> tj;
                     std::vector<FinishSumJob> fj;
                     std::vector<int> dmap;
@@ -1324,10 +1467,18 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     }
                     for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
                     for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i));
+                    if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
                     { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
                     { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
                 } else {
+                if (late_high) {
+                    cf = ws(w_cf);
+                    std::vector<MacStream> cs;
+                    cf_streams(cs);
+                    { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
+                    d_ntt_ct(cf, (size_t)Bs * 2, high, true);
+                }
                 u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
                 // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
                 // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)

@@ -70,6 +70,14 @@ struct Powers {
     DevBuf low;                                  // [idx][power-1][2][Ll][n]   NTT form
     DevBuf high;                                 // [idx][i-1][2][Lh][n]       coefficient form (power i*h)
     DevBuf hext;                                 // [idx][i-1][2][Eh][n]       extended + NTT form of the same
+    // high/hext are produced on the engine's second stream when the PowersDag splits (see Engine::compute_powers);
+    // consumers on the main stream wait for this event first.  Null / never recorded = already ordered.
+    hipEvent_t high_ready = nullptr;
+    bool high_async = false;
+    ~Powers() { if (high_ready) (void)hipEventDestroy(high_ready); }
+    Powers() = default;
+    Powers(const Powers &) = delete;
+    Powers &operator=(const Powers &) = delete;
     int slot_of(uint32_t bundle_idx) const;
 };
 
@@ -166,6 +174,14 @@ private:
     DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ks_, d_map_ksacc_;
     DevBuf arena_;
     size_t arena_off_ = 0;
+    // Lanes: lane 0 = the main stream, lane 1 = a second stream with its own arena for work that is independent of
+    // the main chain (the high-power half of ComputePowers).  st_/arena_/arena_off_/job_seq_ always describe the
+    // CURRENT lane; switch_lane() parks them and loads the other lane's, so every helper works on either.
+    struct Lane { hipStream_t st = nullptr; DevBuf arena; size_t off = 0, job_seq = 0; };
+    Lane parked_;                     // the lane that is not current
+    int cur_lane_ = 0, overflow_lane_ = 0;
+    void switch_lane(int lane);
+    hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
     // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the
@@ -188,8 +204,13 @@ private:
         std::vector<Level> levels;
         std::vector<std::array<int, 3>> nodes;           // per non-source slot: {slot, slot_p1, slot_p2}
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
-    } sched_;
+    } sched_, sched_low_, sched_high_;
+    bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     void build_schedule();
+    void build_schedule_for(Sched &s, const std::vector<char> &member);
+    struct DagRun;                    // per-call state of one walk over a schedule
+    void run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *const *src, bool on_device, const RelinKeys *rk, Powers &pw,
+                 bool do_low, bool do_high);
     void finish_bundle(Bundle &b, const u64 *raw);     // raw: [degree+1][n] coefficient-form plaintexts mod t (device)
     DevBuf d_slot_map_;
 

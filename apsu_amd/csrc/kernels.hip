@@ -5,6 +5,7 @@
 // level constants read through wave-uniform loads.  No MFMA: the work is modular-integer
 // butterflies and dyadic products (BASELINE.json north_star).
 #include "device.h"
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -968,7 +969,10 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // (S00 + Sx*2^s + S11*2^(2s)) and reduced; for the 48..56-bit coefficient primes a whole inner polynomial
 // fits in one chunk.
 #ifndef APSU_MAC_RING
-#define APSU_MAC_RING 4
+#define APSU_MAC_RING 2
+#endif
+#ifndef APSU_MAC_LDS_KB
+#define APSU_MAC_LDS_KB 0
 #endif
 template <int G, int C>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
@@ -1127,8 +1131,11 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
+    // Unused dynamic LDS caps the workgroups per CU, leaving registers and wave slots for the short kernels of the
+    // engine's second stream (ComputePowers' high-power chain) while this grid-filling launch streams the DB.
+    static const unsigned reserve = [] { const char *e = std::getenv("APSU_HE_MAC_LDS_KB"); return (unsigned)(e ? atoi(e) : APSU_MAC_LDS_KB) * 1024u; }();
     hipLaunchKernelGGL((k_mac<G, C>), dim3((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G))),
-                       dim3(EW_T), 0, st, lv, jobs, n);
+                       dim3(EW_T), reserve, st, lv, jobs, n);
     KERNEL_CHECK();
 }
 

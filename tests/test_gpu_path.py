@@ -245,14 +245,17 @@ def test_concurrent_callers_on_one_context():
     G.close()
 
 
-def test_per_term_product_path_matches():
-    # the summed-Bsk finish of eval_patstock's products (default) and the per-term finish (APSU_HE_EVAL_PER_TERM, read
-    # once per process) must agree; the per-term form runs in a child process
+def test_fallback_paths_match():
+    # the summed-Bsk finish of eval_patstock's products and the two-stream ComputePowers are the defaults; their
+    # alternatives (per-term finish: APSU_HE_EVAL_PER_TERM; ComputePowers forced onto one / two streams: APSU_HE_SPLIT=0/1; read once per
+    # process) must give the same bits, so the same scenarios run in child processes with each switch set
     import subprocess, sys, os
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import test_gpu_path as t\n"
             "t.test_config_1M_1024_com(); t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced()\n"
+            "t.test_config_16M_4096_reduced()\n"
             % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    env = dict(os.environ, APSU_HE_EVAL_PER_TERM="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
+    for switch, value in (("APSU_HE_EVAL_PER_TERM", "1"), ("APSU_HE_SPLIT", "0"), ("APSU_HE_SPLIT", "1")):
+        env = dict(os.environ, **{switch: value})
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, switch + "=" + value + "\n" + r.stdout + r.stderr
