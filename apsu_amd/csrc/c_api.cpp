@@ -202,6 +202,11 @@ int apsu_he_bundle_load(apsu_he_ctx *c, const uint8_t *buf, uint64_t size, apsu_
         *out = b;
     });
 }
+int apsu_he_mask_generate(apsu_he_ctx *c, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks)
+{ return guarded([&] { REQUIRE(c && (masks_dev || !count), "null argument"); c->eng->mask_generate(seed, count, masks_dev, values, blocks); }); }
+int apsu_he_decrypt_decode(apsu_he_ctx *c, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
+                           uint64_t *values, uint64_t *blocks)
+{ return guarded([&] { REQUIRE(c && sk_ntt && (cts || !count), "null argument"); c->eng->decrypt_decode(sk_ntt, cts, cts_on_device != 0, count, values, blocks); }); }
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree)
 { return guarded([&] { REQUIRE(b && degree, "null argument"); *degree = b->b->degree; }); }
 int apsu_he_bundle_free(apsu_he_bundle *b) { return guarded([&] { delete b; }); }

@@ -114,6 +114,10 @@ void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t
 void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
                              hipStream_t st);
 void launch_scatter_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st);
+void launch_gather_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st);
+// N4: item -> 128-bit block packing for PEQT, and the rounding step of the querier's decryption
+void launch_pack_blocks(const u64 *values, size_t n, u32 items, u32 felts, u32 len, u64 *out, int batch, hipStream_t st);
+void launch_decrypt_round(const u64 *ct, size_t ct_stride, const u64 *v, u64 q0, u64 t, u64 *out, size_t n, int batch, hipStream_t st);
 void launch_flag_monomial(const u64 *pt, size_t n, int batch, unsigned char *flag, hipStream_t st);
 // BEHZ
 // ct c at in + c*in_stride holds `polys` polys [L][n]; out packed [c][polys][E][n]

@@ -1247,6 +1247,87 @@ size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capa
     return words;
 }
 
+// ============================================================================ N4: masks, packing, loopback decrypt
+static uint32_t plain_modulus_len(u64 t)
+{
+    // receiver_osn.cpp:54-57: smallest len with (1 << len) - 1 >= plain_modulus
+    uint32_t len = 1;
+    while ((((u64)1 << len) - 1) < t) len++;
+    return len;
+}
+
+void Engine::mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
+    if (!count) return;
+    const size_t n = hp_.n;
+    const uint32_t items = psu_.items_per_bundle, felts = psu_.item_params.felts_per_item;
+    const int tid = hp_.plain_id();
+    TIER1_SLOTS();
+    WITH_ARENA({
+        u64 *vals = ws((size_t)count * n);
+        { PROF(P_OTHER, 0); launch_fill_random(vals, (size_t)count * n, seed, hp_.t, st_); }                       // :248-251
+        // BatchEncoder::encode (:271): slot permutation, inverse negacyclic NTT mod t
+        { PROF(P_OTHER, 0); launch_scatter_slots(vals, reinterpret_cast<const uint32_t *>(d_slot_map_.p()), masks_dev, n, (int)count, st_); }
+        d_ntt(masks_dev, count, map_ct() + tid, 1, true);
+        if (blocks_host) {                                                                                        // :256-266
+            u64 *blk = ws((size_t)count * items * 2);
+            { PROF(P_OTHER, 0); launch_pack_blocks(vals, n, items, felts, plain_modulus_len(hp_.t), blk, (int)count, st_); }
+            D2H(blocks_host, blk, (size_t)count * items * 2);
+        }
+        if (values_host) D2H(values_host, vals, (size_t)count * n);
+        sync();
+    });
+}
+
+void Engine::decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_device, uint32_t count, u64 *values_host, u64 *blocks_host)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
+    if (!count) return;
+    const size_t n = hp_.n;
+    const uint32_t items = psu_.items_per_bundle, felts = psu_.item_params.felts_per_item;
+    const int tid = hp_.plain_id();
+    for (size_t k = 0; k < n; k++)
+        if (sk_ntt_host[k] >= hp_.key_q[0]) throw std::invalid_argument("secret key is not reduced modulo q_0");
+    TIER1_SLOTS();
+    WITH_ARENA({
+        u64 *sk = ws(n);
+        H2D(sk, sk_ntt_host, n);
+        const u64 *ct = cts;
+        if (!on_device) {
+            u64 *c = ws((size_t)count * 2 * n);
+            H2D(c, cts, (size_t)count * 2 * n);
+            ct = c;
+        }
+        // c1 -> NTT, (.) s, INTT  (dot_product_ct_sk_array at one limb)
+        u64 *v = ws((size_t)count * n);
+        std::vector<CtJob> cj;
+        for (uint32_t i = 0; i < count; i++) cj.push_back(CtJob{ ct + ((size_t)i * 2 + 1) * n, v + (size_t)i * n });
+        { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), n, (int)count, st_); }
+        d_ntt(v, count, map_ct(), 1, false);
+        { PROF(P_OTHER, 0); launch_dyadic_plain(dlevel(0), v, sk, v, 1, n, (int)count, 0, st_); }
+        d_ntt(v, count, map_ct(), 1, true);
+        // x = c0 + v; m = round(t x / q_0) mod t
+        u64 *pt = ws((size_t)count * n);
+        { PROF(P_OTHER, 0); launch_decrypt_round(ct, 2 * n, v, hp_.key_q[0], hp_.t, pt, n, (int)count, st_); }
+        // BatchEncoder::decode: forward NTT mod t, slot gather
+        d_ntt(pt, count, map_ct() + tid, 1, false);
+        u64 *vals = ws((size_t)count * n);
+        { PROF(P_OTHER, 0); launch_gather_slots(pt, reinterpret_cast<const uint32_t *>(d_slot_map_.p()), vals, n, (int)count, st_); }
+        if (blocks_host) {                                                                      // sender_osn.cpp:684-690
+            u64 *blk = ws((size_t)count * items * 2);
+            { PROF(P_OTHER, 0); launch_pack_blocks(vals, n, items, felts, plain_modulus_len(hp_.t), blk, (int)count, st_); }
+            D2H(blocks_host, blk, (size_t)count * items * 2);
+        }
+        if (values_host) D2H(values_host, vals, (size_t)count * n);
+        sync();
+    });
+}
+
 // ============================================================================ tier 2: BinBundle evaluation
 void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
                           const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device)

@@ -121,6 +121,10 @@ public:
     size_t bundle_image_size(const Bundle &b) const;
     size_t save_bundle(const Bundle &b, unsigned char *buf, size_t capacity);
     std::unique_ptr<Bundle> load_bundle(const unsigned char *buf, size_t size);
+    // N4: mask generation + block packing (receiver_osn.cpp:53-73,217-284) and the querier's
+    // decrypt + decode + packing (result_package.cpp:175-213 ; sender_osn.cpp:675-700)
+    void mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host);
+    void decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_device, uint32_t count, u64 *values_host, u64 *blocks_host);
     // test hook: stored form of coefficient d.  kind: 0 = raw mod t (d = 0), 1 = NTT form at pt_level,
     // 2 = pre-lifted + NTT at the high level (coefficient-form a_{i*h}); returns words written
     size_t download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind);

@@ -423,6 +423,84 @@ void launch_scatter_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n
     KERNEL_CHECK();
 }
 
+// BatchEncoder::decode's slot gather (after the forward NTT mod t): out[b][i] = in[b][slot_map[i]]
+__global__ __launch_bounds__(EW_T) void k_gather_slots(const u64 *__restrict__ in, const u32 *__restrict__ slot_map,
+                                                       u64 *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (i >= n) return;
+    const size_t b = blockIdx.y;
+    out[b * n + i] = in[b * n + slot_map[i]];
+}
+
+void launch_gather_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st)
+{
+    if (!batch) return;
+    hipLaunchKernelGGL(k_gather_slots, ew_grid(n, batch), dim3(EW_T), 0, st, in, slot_map, out, n);
+    KERNEL_CHECK();
+}
+
+// N4: vec_to_oc_block (receiver_osn.cpp:53-73): the felts of one item packed into a 128-bit block for the PEQT step,
+// out[item] = (lower, higher).  len = bit length of the plain modulus as the reference computes it; the odd-felt
+// branch shifts the upper half by len/2 - 1 (not len/2) exactly as the reference does; 64-bit shifts wrap.
+__global__ __launch_bounds__(EW_T) void k_pack_blocks(const u64 *__restrict__ values, size_t n, u32 items, u32 felts, u32 len,
+                                                      u64 *__restrict__ out)
+{
+    const size_t it = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (it >= items) return;
+    const size_t b = blockIdx.y;
+    const u64 *in = values + b * n + it * felts;
+    const u64 mask = ((u64)1 << len) - 1, mask_lower = ((u64)1 << (len >> 1)) - 1, mask_higher = mask - mask_lower;
+    u64 lower = 0, higher = 0;
+    if (felts & 1) {
+        lower = in[felts - 1] & mask_lower;
+        higher = (in[felts - 1] & mask_higher) >> ((len >> 1) - 1);
+    }
+    for (u32 p = 0; p + 1 < felts; p += 2) {
+        lower = (in[p] & mask) | (lower << len);
+        higher = (in[p + 1] & mask) | (higher << len);
+    }
+    out[(b * items + it) * 2] = lower;
+    out[(b * items + it) * 2 + 1] = higher;
+}
+
+void launch_pack_blocks(const u64 *values, size_t n, u32 items, u32 felts, u32 len, u64 *out, int batch, hipStream_t st)
+{
+    if (!batch || !items) return;
+    hipLaunchKernelGGL(k_pack_blocks, ew_grid(items, batch), dim3(EW_T), 0, st, values, n, items, felts, len, out);
+    KERNEL_CHECK();
+}
+
+// N4: the querier's decryption of a result at the last level (result_package.cpp:175-213, Decryptor::decrypt):
+// x = c0 + v (v = INTT(NTT(c1) . s), one limb q0), m = round(t x / q0) mod t.
+__global__ __launch_bounds__(EW_T) void k_decrypt_round(const u64 *__restrict__ ct, size_t ct_stride, const u64 *__restrict__ v,
+                                                        u64 q0, u64 t, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const size_t b = blockIdx.y;
+    const u64 x = addmod(ct[b * ct_stride + k], v[b * n + k], q0);
+    u128p num = mul128(x, t);
+    add128(num, u128p{ q0 >> 1, 0 });
+    // floor(num / q0) mod t by restoring division, the quotient folded mod t on the fly (num < 2^124)
+    u64 rem = 0, quo = 0;
+    for (int i = 127; i >= 0; i--) {
+        const u64 bit = i >= 64 ? (num.hi >> (i - 64)) & 1 : (num.lo >> i) & 1;
+        rem = (rem << 1) | bit;                                   // rem < q0 < 2^62 before the shift
+        quo <<= 1;                                                // quo < t < 2^61
+        if (rem >= q0) { rem -= q0; quo |= 1; }
+        if (quo >= t) quo -= t;
+    }
+    out[b * n + k] = quo;
+}
+
+void launch_decrypt_round(const u64 *ct, size_t ct_stride, const u64 *v, u64 q0, u64 t, u64 *out, size_t n, int batch, hipStream_t st)
+{
+    if (!batch) return;
+    hipLaunchKernelGGL(k_decrypt_round, ew_grid(n, batch), dim3(EW_T), 0, st, ct, ct_stride, v, q0, t, out, n);
+    KERNEL_CHECK();
+}
+
 // flag[b] = 1 iff plaintext b has exactly one non-zero coefficient (SEAL's monomial shortcut in multiply_plain)
 __global__ __launch_bounds__(EW_T) void k_flag_monomial(const u64 *__restrict__ pt, size_t n, unsigned char *__restrict__ flag)
 {

@@ -323,6 +323,31 @@ class HeContext:
         _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
         return Bundle(self, h, -1, -1, deg.value)
 
+    def mask_generate(self, seed, count, masks_dev, want_values=True, want_blocks=True):
+        """N4: `count` random masks (receiver_osn.cpp:217-284).  masks_dev: device pointer to count*n words receiving the
+        encoded plaintexts.  -> (values [count][n] or None, blocks [count][items_per_bundle][2] (low, high) or None)"""
+        vals = np.empty((count, self.n), dtype=np.uint64) if want_values else None
+        blks = np.empty((count, self.info.items_per_bundle, 2), dtype=np.uint64) if want_blocks else None
+        _check(load_library().apsu_he_mask_generate(self.h, C.c_uint64(seed), C.c_uint32(count), C.c_void_p(int(masks_dev)),
+                                                    _p(vals) if want_values else None, _p(blks) if want_blocks else None))
+        return vals, blks
+
+    def decrypt_decode(self, sk_ntt, cts, count=None, on_device=False, want_blocks=True):
+        """N4: the querier's decrypt + decode + packing of `count` results (result_package.cpp:175-213).
+        sk_ntt: secret key mod q_0 in NTT form [n]; cts: [count][2][1][n] array, or a device pointer with on_device."""
+        if not on_device:
+            cts = np.ascontiguousarray(cts, dtype=np.uint64)
+            count = cts.size // (2 * self.n)
+            ptr = _p(cts)
+        else:
+            ptr = C.c_void_p(int(cts))
+        vals = np.empty((count, self.n), dtype=np.uint64)
+        blks = np.empty((count, self.info.items_per_bundle, 2), dtype=np.uint64) if want_blocks else None
+        sk = np.ascontiguousarray(sk_ntt, dtype=np.uint64)
+        _check(load_library().apsu_he_decrypt_decode(self.h, _p(sk), ptr, 1 if on_device else 0, C.c_uint32(count), _p(vals),
+                                                     _p(blks) if want_blocks else None))
+        return vals, blks
+
     def bundle_coeff(self, bundle, degree):
         """test hook -> (array, kind): kind 0 raw mod t, 1 NTT form [L][n], 2 pre-lifted NTT at the high level"""
         buf = np.empty((self.first_chain_idx + 1) * self.n, dtype=np.uint64)

@@ -135,6 +135,23 @@ int apsu_he_db_build_bundle(apsu_he_ctx *ctx, uint32_t bundle_idx, uint32_t cach
 int apsu_he_bundle_image_size(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint64_t *bytes);
 int apsu_he_bundle_save(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint8_t *buf, uint64_t capacity, uint64_t *written);
 int apsu_he_bundle_load(apsu_he_ctx *ctx, const uint8_t *buf, uint64_t size, apsu_he_bundle **out);
+/* "next" row N4: the per-BinBundle host work either side of the evaluation, on the GPU.
+ * apsu_he_mask_generate replaces the "random gen" block of Receiver::RunQuery (receiver/apsu/receiver_osn.cpp:217-284):
+ * for each of `count` BinBundles, n slot values uniform mod plain_modulus, BatchEncoder::encode of them
+ * (masks_dev: count*n words on the device, the `masks` of apsu_he_eval_bundles with masks_on_device = 1), and
+ * vec_to_oc_block of every item (receiver_osn.cpp:53-73; blocks: count*items_per_bundle*2 words, (low, high)
+ * halves of the 128-bit block; host; may be NULL).  values (host, count*n; may be NULL) receives the slot values.
+ * The reference draws them from SEAL's Blake2xb PRNG under a fresh random seed; here value(c, i) =
+ * splitmix64(seed + (c*n + i + 1) * 0x9e3779b97f4a7c15) mod plain_modulus — a different uniform stream, the
+ * same encode and packing.
+ * apsu_he_decrypt_decode is the querier's side of a loopback check (sender/apsu/sender_osn.cpp:675-700,
+ * common/apsu/network/result_package.cpp:175-213): Decryptor::decrypt of `count` results (size 2, last level,
+ * 2*n words each), BatchEncoder::decode, and the same block packing.  sk_ntt: the secret key modulo q_0 in NTT
+ * form (n words, host).  The rounding is the exact round(t*x/q_0): equal to SEAL's decrypt for every
+ * ciphertext with a positive noise budget. */
+int apsu_he_mask_generate(apsu_he_ctx *ctx, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks);
+int apsu_he_decrypt_decode(apsu_he_ctx *ctx, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
+                           uint64_t *values, uint64_t *blocks);
 /* test hooks: degree of the batched polynomial; stored form of coefficient `degree`
  * (kind 0: raw mod t [n]; 1: NTT form [(plain_level+1)*n]; 2: pre-lifted + NTT at the high level [(high+1)*n]) */
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);

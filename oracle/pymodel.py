@@ -476,3 +476,25 @@ def eval_patstock(M, powers, coeffs, ps_low_degree, rk, mask):
     for l in range(high, 0, -1):
         result = M.mod_switch_to_next(result, l)
     return M.clear_irrelevant_bits(result)
+
+
+def vec_to_oc_block(values, felts_per_item, plain_modulus):
+    """receiver/apsu/receiver_osn.cpp:53-73 with Python integers; uint64_t wrap-around made explicit.
+    -> (lower, higher), the two 64-bit halves handed to oc::toBlock(higher, lower)."""
+    M = (1 << 64) - 1
+    ln = 1
+    while ((1 << ln) - 1) < plain_modulus:
+        ln += 1
+    mask = (1 << ln) - 1
+    mask_lower = (1 << (ln >> 1)) - 1
+    mask_higher = mask - mask_lower
+    lower = higher = 0
+    if felts_per_item & 1:
+        lower = values[felts_per_item - 1] & mask_lower
+        higher = (values[felts_per_item - 1] & mask_higher) >> ((ln >> 1) - 1)
+    pla = 0
+    while pla < felts_per_item - 1:
+        lower = ((values[pla] & mask) | (lower << ln)) & M
+        higher = ((values[pla + 1] & mask) | (higher << ln)) & M
+        pla += 2
+    return lower, higher

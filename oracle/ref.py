@@ -208,6 +208,15 @@ class RefContext:
         lib().ref_batch_decode(self.h, _p(np.ascontiguousarray(pt)), _p(v))
         return v
 
+    def vec_to_oc_block(self, values, felts_per_item):
+        """-> [items][2] (low, high): receiver_osn.cpp:53-73 applied to consecutive groups of felts_per_item slot values"""
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        items = values.size // felts_per_item
+        out = np.empty((items, 2), dtype=np.uint64)
+        for i in range(items):
+            lib().ref_vec_to_oc_block(_p(values[i * felts_per_item:]), C.c_size_t(felts_per_item), C.c_uint64(self.t), _p(out[i]))
+        return out
+
     def polyn_with_roots(self, roots):
         roots = np.ascontiguousarray(roots, dtype=np.uint64)
         out = np.empty(roots.size + 1, dtype=np.uint64)

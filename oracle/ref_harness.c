@@ -181,6 +181,28 @@ void ref_batch_decode(const ref_ctx *c, const uint64_t *pt, uint64_t *values)
     free(tmp);
 }
 
+/* receiver/apsu/receiver_osn.cpp:53-73.  The reference computes the masks with `1 << len` on an int and shifts
+ * uint64_t accumulators, which wrap; the odd-felt branch shifts the upper half by len/2 - 1 (sic). */
+void ref_vec_to_oc_block(const uint64_t *in, size_t felts_per_item, uint64_t plain_modulus, uint64_t out[2])
+{
+    uint32_t len = 1;
+    while ((((uint64_t)1 << len) - 1) < plain_modulus) len++;                      /* :54-57 */
+    uint64_t mask = ((uint64_t)1 << len) - 1;                                       /* :58 */
+    uint64_t mask_lower = ((uint64_t)1 << (len >> 1)) - 1;                          /* :59 */
+    uint64_t mask_higher = mask - mask_lower;                                       /* :60 */
+    uint64_t lower = 0, higher = 0;
+    if (felts_per_item & 1) {                                                       /* :63-66 */
+        lower = in[felts_per_item - 1] & mask_lower;
+        higher = (in[felts_per_item - 1] & mask_higher) >> ((len >> 1) - 1);
+    }
+    for (size_t pla = 0; pla + 1 < felts_per_item; pla += 2) {                      /* :67-70 */
+        lower = (in[pla] & mask) | (lower << len);
+        higher = (in[pla + 1] & mask) | (higher << len);
+    }
+    out[0] = lower;
+    out[1] = higher;
+}
+
 void ref_polyn_with_roots(const ref_ctx *c, const uint64_t *roots, size_t count, uint64_t *out)
 {
     const ref_mod *t = &c->t;

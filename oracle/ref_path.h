@@ -39,6 +39,9 @@ int  ref_decrypt(const ref_ctx *c, const uint64_t *sk_ntt, const uint64_t *ct, i
                  int chain_idx, uint64_t *pt_mod_t);
 void ref_batch_encode(const ref_ctx *c, const uint64_t *values, uint64_t *pt_mod_t);
 void ref_batch_decode(const ref_ctx *c, const uint64_t *pt_mod_t, uint64_t *values);
+/* receiver/apsu/receiver_osn.cpp:53-73 (vec_to_oc_block): the felts of one item packed into a 128-bit block;
+ * out[0] = low 64 bits ("lower"), out[1] = high 64 bits ("higher") of oc::toBlock(higher, lower) */
+void ref_vec_to_oc_block(const uint64_t *in, size_t felts_per_item, uint64_t plain_modulus, uint64_t out[2]);
 /* common/apsu/util/interpolate.cpp:63-80 ; out has count+1 entries, degree ascending */
 void ref_polyn_with_roots(const ref_ctx *c, const uint64_t *roots, size_t count, uint64_t *out);
 

@@ -1,0 +1,87 @@
+"""N4: mask generation + block packing and the querier's decrypt/decode on the GPU, against the oracle
+(receiver_osn.cpp:53-73,217-284 ; result_package.cpp:175-213 ; sender_osn.cpp:675-700)."""
+import numpy as np
+import pytest
+
+import common
+from common import ref
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import apsu_amd                                            # noqa: E402
+from bench import splitmix_values                          # noqa: E402
+
+
+def _masks(G, C, js_felts, seed, count):
+    n = G.n
+    buf = torch.empty(count * n, dtype=torch.int64, device="cuda")
+    vals, blks = G.mask_generate(seed, count, buf.data_ptr())
+    torch.cuda.synchronize()
+    enc = buf.cpu().numpy().view(np.uint64).reshape(count, n)
+    for c in range(count):
+        assert (vals[c] == splitmix_values(seed, c, n, G.t)).all()          # the documented generator
+        assert (vals[c] < G.t).all()
+        assert (enc[c] == C.encode(vals[c])).all()                           # BatchEncoder::encode
+        assert (blks[c] == C.vec_to_oc_block(vals[c], js_felts)[: blks.shape[1]]).all()
+    return buf, vals, blks, enc
+
+
+@pytest.mark.parametrize("felts", [5, 6, 8])
+def test_mask_generate_toy(felts):
+    # even and odd felts_per_item: the odd branch of vec_to_oc_block has its own shift
+    js = common.toy_json(felts=felts)
+    C = ref.RefContext.from_params(ref.load_params(js))
+    G = apsu_amd.HeContext(js)
+    _, vals, blks, _ = _masks(G, C, felts, 0x1234, 3)
+    assert blks.shape == (3, G.n // felts, 2)
+    assert len({int(v) for v in vals[0][:64]}) > 32                           # not constant
+
+
+def test_mask_generate_16M_params():
+    js = common.param_json("16M-4096")
+    C = ref.RefContext.from_params(ref.load_params(js))
+    G = apsu_amd.HeContext(js)
+    _masks(G, C, 5, 77, 2)
+
+
+def test_loopback_masks_eval_decrypt():
+    """all-GPU loopback: masks drawn on the device, evaluation with device-resident masks, the querier's
+    decrypt/decode/packing on the device; every stage equals the oracle and the plaintext meaning holds"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 4, 0], 1: [7]})
+    G = apsu_amd.HeContext(js)
+    n = G.n
+    count = len(S.bundles)
+    buf, vals, blks, enc = _masks(G, S.C, 5, 99, count)          # toy_json: felts_per_item = 5
+    for i, b in enumerate(S.bundles):                                        # the scenario now uses the GPU's masks
+        b["mask_vals"], b["mask"] = vals[i], enc[i]
+    rk = G.upload_relin_keys(S.rk) if S.rk is not None else None
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    out = G.eval_bundles(gb, pw, rk, [buf.data_ptr() + i * n * 8 for i in range(count)], masks_on_device=True)
+    opw = common.oracle_powers(S)
+    for i, b in enumerate(S.bundles):
+        assert (out[i] == common.oracle_eval(S, opw, b)).all()
+    got, gblk = G.decrypt_decode(S.sk[0], out)
+    felts = 5
+    for i, b in enumerate(S.bundles):
+        pt, budget = S.C.decrypt(S.sk, np.ascontiguousarray(out[i]), 0)
+        assert budget > 0
+        exp = S.C.decode(pt)
+        assert (got[i] == exp).all()                                          # Decryptor::decrypt + BatchEncoder::decode
+        assert (got[i].astype(object) == common.expected_slots(S, b)).all()   # P(x) + mask
+        assert (gblk[i] == S.C.vec_to_oc_block(exp, felts)[: gblk.shape[1]]).all()
+    # device-resident ciphertexts give the same answer
+    dct = torch.from_numpy(np.ascontiguousarray(out).view(np.int64)).cuda()
+    got2, _ = G.decrypt_decode(S.sk[0], dct.data_ptr(), count=count, on_device=True, want_blocks=False)
+    assert (got2 == got).all()
+
+
+def test_n4_rejects_bad_input():
+    js = common.toy_json()
+    G = apsu_amd.HeContext(js)
+    with pytest.raises(ValueError):                                       # secret key not reduced modulo q_0
+        G.decrypt_decode(np.full(G.n, G.q[0], dtype=np.uint64), np.zeros((1, 2, 1, G.n), dtype=np.uint64))
+    vals, blks = G.mask_generate(1, 0, 0)                                 # count = 0: nothing to do
+    assert vals.shape[0] == 0 and blks.shape[0] == 0

@@ -121,3 +121,31 @@ def test_scenarios_decrypt_semantics():
             got = S.C.decode(pt)
             nroots = int(S.C.n * 0.5) if b["degree"] >= 1 else 0
             assert (got[:nroots] == b["mask_vals"][:nroots]).all()
+
+
+def test_vec_to_oc_block_matches_model_and_known_answers():
+    # N4 packing (receiver_osn.cpp:53-73): C oracle vs the independent Python model, plus hand-computed answers
+    from oracle import pymodel
+    C = ref.RefContext(64, coeff_bits=[40, 40, 36], plain_bits=17)          # a 17-bit t -> len = 17
+    assert (1 << 16) <= C.t < (1 << 17)
+    # even felts: lower collects felts 0,2,.. and higher felts 1,3,.., most recent in the low bits
+    v = np.array([0x1ABCD, 0x0F00F, 0x00001, 0x10000], dtype=np.uint64)
+    got = C.vec_to_oc_block(v, 4)
+    assert int(got[0][0]) == ((0x1ABCD << 17) | 0x00001) and int(got[0][1]) == ((0x0F00F << 17) | 0x10000)
+    # odd felts: the last felt is split at len/2 = 8 bits, its upper part shifted down by 7 (sic)
+    v = np.array([5, 6, 0x1FFFF], dtype=np.uint64)
+    got = C.vec_to_oc_block(v, 3)
+    assert int(got[0][0]) == ((0xFF << 17) | 5) and int(got[0][1]) == (((0x1FF00 >> 7) << 17) | 6)
+    rng = np.random.default_rng(3)
+    for felts in (2, 3, 5, 6, 7, 8):
+        vals = rng.integers(0, C.t, 4 * felts, dtype=np.uint64)
+        blocks = C.vec_to_oc_block(vals, felts)
+        for i in range(4):
+            lo, hi = pymodel.vec_to_oc_block([int(x) for x in vals[i * felts:(i + 1) * felts]], felts, C.t)
+            assert (int(blocks[i][0]), int(blocks[i][1])) == (lo, hi)
+    # a 22-bit plain modulus with 7 felts overflows 64 bits per half: the wrap-around must match
+    C2 = ref.RefContext(64, coeff_bits=[50, 50, 40], plain_bits=22)
+    vals = rng.integers(0, C2.t, 7, dtype=np.uint64)
+    lo, hi = pymodel.vec_to_oc_block([int(x) for x in vals], 7, C2.t)
+    got = C2.vec_to_oc_block(vals, 7)
+    assert (int(got[0][0]), int(got[0][1])) == (lo, hi)
