@@ -123,6 +123,9 @@ void launch_flag_monomial(const u64 *pt, size_t n, int batch, unsigned char *fla
 // ct c at in + c*in_stride holds `polys` polys [L][n]; out packed [c][polys][E][n]
 void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st);
+// mod_switch_to_next + extension in one pass (input: L + 1 limbs per polynomial at level lv + 1); false = not available for this size
+bool launch_drop_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                          hipStream_t st);
 struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
 void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
 // The same for a sum of products sharing one output (eval_patstock's sum over i): a, b: [terms][2][E][n];

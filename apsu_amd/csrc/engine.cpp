@@ -1505,15 +1505,23 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt(inner, imap.size(), upload_jobs(imap), (int)imap.size(), true);                       // :268,297,320,333
 
-                u64 *innerh = inner;
-                for (int lv = low; lv > high; lv--) {                                                       // :269,298
-                    u64 *nxt = ws((size_t)NI * 2 * lv * n);
-                    { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
-                    innerh = nxt;
-                }
-                // ct x ct with the high powers (:272,301): extend, NTT, tensor, INTT, finish (+ sum over i, :273,303)
+                // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
+                // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
                 u64 *ext = ws((size_t)NI * 2 * Eh * n);
-                { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+                bool fused_drop = false;
+                if (low == high + 1) {
+                    PROF(P_BEHZ_EXT, 0);
+                    fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_);
+                }
+                if (!fused_drop) {
+                    u64 *innerh = inner;
+                    for (int lv = low; lv > high; lv--) {
+                        u64 *nxt = ws((size_t)NI * 2 * lv * n);
+                        { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
+                        innerh = nxt;
+                    }
+                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+                }
                 d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
                 if (late_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
                 u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240

@@ -589,21 +589,38 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext(const DevLevel *__restrict__ 
 HD u64 lazy2(u64 x, const ShoupConst &c, u64 q) { return mul_shoup_lazy(x, c.w, c.wq, q); }      // x*c mod q in [0,2q), any x
 
 // Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices: same values, ~35 % fewer multiplies.
-template <int TL>
+// DROP: the input is one level higher (TL + 1 limbs per polynomial) and is first mod-switched to this level
+// (mod_switch_to_next_inplace, bin_bundle.cpp:269,298) — the drop and the extension share one pass over the data.
+template <int TL, bool DROP>
 __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
                                                     size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
-    constexpr int L = TL, nBsk = TL + 1, E = 2 * TL + 1;
+    constexpr int L = TL, nBsk = TL + 1, E = 2 * TL + 1, LIN = TL + (DROP ? 1 : 0);
     const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
-    const u64 *src = in + c * in_stride + p * (size_t)L * n;
+    const u64 *src = in + c * in_stride + p * (size_t)LIN * n;
     u64 *dst = out + (size_t)blockIdx.y * E * n;
+    u64 xin[L];
+    if (DROP) {
+        const DevLevel *ld = lv + 1;                              // constants of the level being left
+        const u64 ql = ld->q[L].q;
+        const u64 last = addmod(src[(size_t)L * n + k], ld->half, ql);
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const Mod m = ld->q[j];
+            const u64 tmp = submod(barrett64(last, m), ld->half_mod[j], m.q);
+            xin[j] = mul_shoup(submod(src[(size_t)j * n + k], tmp, m.q), ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < L; j++) xin[j] = src[(size_t)j * n + k];
+    }
     u64 xs[L];
     u32 mt_acc = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {
-        const u64 x = src[(size_t)j * n + k];
+        const u64 x = xin[j];
         dst[(size_t)j * n + k] = x;
         xs[j] = mul_shoup(x, lv->ext_scale[j].w, lv->ext_scale[j].wq, lv->q[j].q);     // canonical: used as an integer
         mt_acc += (u32)xs[j] * lv->q_to_mt[j];
@@ -621,12 +638,25 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__
     }
 }
 
+// drop one limb, then extend: `in` holds polynomials of L + 1 limbs at level lv + 1.  Only for the unrolled sizes;
+// returns false when the caller has to run the two steps separately.
+bool launch_drop_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
+                          hipStream_t st)
+{
+    if (!cts) return true;
+    const dim3 g = ew_grid(n, cts * polys), t(EW_T);
+#define EXT2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext2<TL, true>), g, t, 0, st, lv, in, in_stride, polys, out, n); KERNEL_CHECK(); return true; }
+    EXT2_CASE(1) EXT2_CASE(2) EXT2_CASE(3)
+#undef EXT2_CASE
+    return false;
+}
+
 void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st)
 {
     if (!cts) return;
     const dim3 g = ew_grid(n, cts * polys), t(EW_T);
-#define EXT2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext2<TL>), g, t, 0, st, lv, in, in_stride, polys, out, n); KERNEL_CHECK(); return; }
+#define EXT2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext2<TL, false>), g, t, 0, st, lv, in, in_stride, polys, out, n); KERNEL_CHECK(); return; }
     EXT2_CASE(1) EXT2_CASE(2) EXT2_CASE(3)
 #undef EXT2_CASE
 #define EXT_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext<TL, TL>), g, t, 0, st, lv, in, in_stride, polys, out, n); } else
