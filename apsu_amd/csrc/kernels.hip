@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 }
 
 #ifndef APSU_MAC_G
-#define APSU_MAC_G 2
+#define APSU_MAC_G 4
 #endif
 #ifndef APSU_MAC_C
 #define APSU_MAC_C 2
