@@ -69,7 +69,10 @@ struct DevKey {
 
 // Multiply-accumulate job: for g < ng:  out[g][2][L][n] = sum_{j<cnt} PW_j (.) PT_{g,j}   (NTT domain).
 // All streams of a job share the ciphertext powers PW (same bundle index) and the term count.
-constexpr int MAC_G = 4;
+#ifndef APSU_MAC_GMAX
+#define APSU_MAC_GMAX 4
+#endif
+constexpr int MAC_G = APSU_MAC_GMAX;
 struct MacJob {
     const u64 *pt[MAC_G]; // first plaintext of stream g; term j at + j*pt_stride ; limb l at + l*n
     u64 *out[MAC_G];      // [2][L][n]

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_morph(const MacJob *__restrict__ jobs, 
 }
 int main(int argc, char** argv) {
     const size_t n = 8192, L = 3, ptw = L * n;
-    const int terms = 44, streams = 784, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
+    const int terms = 44, streams = 784 - 784 % MAC_G, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
     const size_t words = (size_t)streams * terms * ptw;
     u64 *db, *pw, *out; DevLevel* lv; MacJob* dj;
     CHECK(hipMalloc(&db, words * 8)); const size_t pstride = nb * 2 * L * n + pad + 2 * ppad; CHECK(hipMalloc(&pw, (size_t)terms * pstride * 8)); CHECK(hipMalloc(&out, (size_t)streams * 2 * L * n * 8));

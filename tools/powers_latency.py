@@ -16,10 +16,14 @@ for idx in ([0], [0, 1], [0, 1, 2, 3]):
     for _ in range(3): pw = ctx.compute_powers(idx, sp, rk, on_device=True)
     ctx.sync() if hasattr(ctx, "sync") else torch.cuda.synchronize()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): pw = ctx.compute_powers(idx, sp, rk, on_device=True)
+    for _ in range(20):
+        pw = None                                         # as in a query loop: the previous powers are released first (buffer pool)
+        pw = ctx.compute_powers(idx, sp, rk, on_device=True)
     torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 50
     ctx.profile_enable(1); ctx.profile_read()
-    for _ in range(5): pw = ctx.compute_powers(idx, sp, rk, on_device=True)
+    for _ in range(5):
+        pw = None
+        pw = ctx.compute_powers(idx, sp, rk, on_device=True)
     torch.cuda.synchronize(); p = ctx.profile_read(); ctx.profile_enable(0)
     ks = sum(v[0] for v in p.values()) / 5
     print(f"nb={len(idx)}: wall {wall:.3f} ms/call, kernel sum {ks:.3f} ms, launches {sum(v[1] for v in p.values())//5}: " +
