@@ -141,8 +141,6 @@ void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJo
 struct FinishJob { const u64 *d; u64 *out; int terms; int pad; };
 void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs, bool accumulate, size_t n, int njobs, hipStream_t st);
 // key switching
-void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
-                      hipStream_t st);
 void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
                      hipStream_t st);
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,

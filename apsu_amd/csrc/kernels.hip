@@ -955,39 +955,7 @@ void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJo
 
 // ============================================================================ K6: relinearize (key switch of c2)
 // relinearize_inplace (receiver_osn.cpp:431 ; bin_bundle.cpp:309), App. B10.
-// decomp: out[b][I][J][k] = c2[b][J][k] mod m_I  for target modulus I in {q_0..q_{L-1}, p}, J < L
-template <int TL>
-__global__ __launch_bounds__(EW_T) void k_ks_decomp(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ c2,
-                                                    size_t c2_stride, u64 *__restrict__ out, size_t n)
-{
-    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
-    if (k >= n) return;
-    const size_t b = blockIdx.y;
-    const int L = TL ? TL : Lrt;
-    const u64 *src = c2 + b * c2_stride;
-    u64 *dst = out + b * (size_t)(L + 1) * L * n;
-#pragma unroll
-    for (int J = 0; J < (TL ? TL : DMAXL); J++) {
-        if (!TL && J >= L) continue;
-        const u64 v = src[J * n + k];
-#pragma unroll
-        for (int I = 0; I <= (TL ? TL : DMAXL); I++) {
-            if (!TL && I > L) continue;
-            const Mod m = key->q[I == L ? key->K - 1 : I];
-            dst[((size_t)I * L + J) * n + k] = barrett64(v, m);
-        }
-    }
-}
-
-void launch_ks_decomp(const DevKey *key, int L, const u64 *c2, size_t c2_stride, u64 *out, size_t n, int batch,
-                      hipStream_t st)
-{
-#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_decomp<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n); break;
-    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_decomp<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, c2, c2_stride, out, n); }
-#undef KS_CASE
-    KERNEL_CHECK();
-}
-
+// The RNS decomposition c2[J] mod m_I is done by k_ntt_gather on load (no separate pass).
 // inner product with the key: acc[b][comp][I][k] = sum_J tdec[b][I][J][k] * rk[J][comp][id(I)][k] mod m_I
 template <int TL>
 __global__ __launch_bounds__(EW_T) void k_ks_inner(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ tdec,
