@@ -139,13 +139,20 @@ def main():
     src_ptrs = [[src_dev.data_ptr() + ((b * ns + s) * 2 * Lf * n) * esz for s in range(ns)] for b in my_indices]
     mask_ptrs = [mask_dev.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine]
     max_local, _rows = gather_slots(assign)
-    out_dev = torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev)
+    # two result buffers, alternated per step: the collective of step k (torch's stream) may still read one while
+    # step k+1 (the engine's stream) fills the other
+    out_bufs = [torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev) for _ in range(2)]
+    out_dev = out_bufs[0]
+    step_no = [0]
     gdev = dev if backend == "nccl" else torch.device("cpu")
     gathered = torch.zeros((world * max_local, 2, n), dtype=torch.int64, device=gdev) if world > 1 else None
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     def step():
+        nonlocal out_dev
+        out_dev = out_bufs[step_no[0] & 1]
+        step_no[0] += 1
         pw = ctx.compute_powers(my_indices, src_ptrs, rk, on_device=True) if my_indices else None
         if bundles:
             ctx.eval_bundles(bundles, pw, rk, mask_ptrs, out=out_dev.data_ptr(), masks_on_device=True, out_on_device=True)
