@@ -412,7 +412,11 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
 void Engine::recycle_powers(std::unique_ptr<Powers> p)
 {
     std::lock_guard<std::mutex> g(mu_);
-    if (p && powers_pool_.size() < 4) powers_pool_.push_back(std::move(p));
+    if (!p) return;
+    // keep the most recently released buffers: a context that changes its batch shape must not be left with a pool
+    // full of buffers of the old shape (every call would then allocate and free ~100 MB)
+    if (powers_pool_.size() >= 4) powers_pool_.erase(powers_pool_.begin());
+    powers_pool_.push_back(std::move(p));
 }
 
 // run `fn` with the arena, growing it and retrying when the bump allocator overflows
