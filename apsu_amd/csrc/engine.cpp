@@ -1386,7 +1386,8 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     for (int c0 = 0; c0 < count; c0 += chunk) {
         const int B = std::min(chunk, count - c0);
         WITH_ARENA({
-            u64 *res = ws((size_t)B * 2 * n);                       // final [B][2][1][n]
+            // final [B][2][1][n]: written in place when the caller's buffer is on the device
+            u64 *res = out_on_device ? out + (size_t)c0 * 2 * n : ws((size_t)B * 2 * n);
             u64 *mask_d = nullptr;
             if (!masks_on_device) {
                 mask_d = ws((size_t)B * n);
@@ -1625,8 +1626,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                          bundles[c0 + ps_ids[x]]->a0.u(), mask_ptr(ps_ids[x]), res + (size_t)ps_ids[x] * 2 * n });
                 { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
             }
-            if (out_on_device) D2D(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
-            else D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
+            if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             sync();
         });
     }
