@@ -17,7 +17,7 @@ import apsu_amd                                            # noqa: E402
 
 
 def random_params(rng):
-    n = rng.choice([64, 256, 1024])
+    n = rng.choice([64, 256, 1024, 4096])
     K = rng.choice([2, 3, 4, 5])
     widths = [rng.choice([30, 36, 40, 45, 50, 56, 60]) for _ in range(K)]
     felts = rng.choice([5, 6, 7, 8])
@@ -40,7 +40,7 @@ def random_params(rng):
     }), max_items
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_parameter_sets(seed):
     rng = random.Random(1000 + seed)
     for _ in range(40):                                     # draw until the reference's own validation accepts the set
