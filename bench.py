@@ -66,6 +66,14 @@ def main():
 
     import torch
     import apsu_amd
+    # a checkout without build artefacts: local rank 0 compiles, the other ranks wait for the libraries
+    import __graft_entry__
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        __graft_entry__.ensure_built()
+    else:
+        deadline = time.time() + 900
+        while not os.path.exists(os.path.join(ROOT, "apsu_amd", "libapsu_he_gpu.so")) and time.time() < deadline:
+            time.sleep(1.0)
     from apsu_amd.sharding import gather_slots, partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a checkout without build artefacts (the .so files are git-ignored): compile once, as the driver's build() does
+    import __graft_entry__
+    __graft_entry__.ensure_built()
 
 
 @pytest.fixture(scope="session")
