@@ -1,0 +1,115 @@
+/* Pure-C host of the drop-in boundary (include/apsu_he.h): no Python, no torch.
+ *   gcc -O2 -Iinclude examples/c_abi_demo.c -Lapsu_amd -lapsu_he_gpu -Wl,-rpath,$PWD/apsu_amd -o c_abi_demo
+ *   ./c_abi_demo tests/params/1M-1024-com.json
+ * Runs the tier-1 NTT round trip and the tier-2 path (ComputePowers + eval_bundles on a synthetic BinBundle with a
+ * mask drawn by apsu_he_mask_generate), and prints FNV-1a checksums of every result.  tests/test_gpu_c_host.py builds
+ * it, runs it, and compares the checksums with the same calls made through the Python binding. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <hip/hip_runtime_api.h>
+#include "apsu_he.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, apsu_he_last_error()); return 1; } } while (0)
+
+static uint64_t fnv(const void *p, size_t bytes)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+static uint64_t mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: %s PSUParams.json\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror(argv[1]); return 2; }
+    char *json = (char *)calloc(1, 1 << 16);
+    if (fread(json, 1, (1 << 16) - 1, f) == 0) return 2;
+    fclose(f);
+
+    apsu_he_ctx *ctx = NULL;
+    CHECK(apsu_he_create(json, 0, &ctx));
+    apsu_he_info info;
+    CHECK(apsu_he_get_info(ctx, &info));
+    const size_t n = info.poly_modulus_degree;
+    const int K = info.coeff_modulus_size, first = info.first_chain_idx, Lf = first + 1;
+    printf("abi %d n %zu K %d first %d sources %u targets %u\n", apsu_he_abi_version(), n, K, first, info.source_power_count,
+           info.target_power_count);
+
+    /* tier 1: transform_to_ntt / from_ntt round trip on a pseudo-random size-2 ciphertext */
+    uint64_t *ct = (uint64_t *)malloc(2 * Lf * n * 8), *ct0 = (uint64_t *)malloc(2 * Lf * n * 8);
+    for (int p = 0; p < 2; p++)
+        for (int j = 0; j < Lf; j++)
+            for (size_t k = 0; k < n; k++) ct[((size_t)p * Lf + j) * n + k] = mix(1 + ((size_t)p * Lf + j) * n + k) % info.coeff_modulus[j];
+    memcpy(ct0, ct, 2 * Lf * n * 8);
+    CHECK(apsu_he_transform_to_ntt(ctx, ct, 2, first));
+    printf("ntt %016llx\n", (unsigned long long)fnv(ct, 2 * Lf * n * 8));
+    CHECK(apsu_he_transform_from_ntt(ctx, ct, 2, first));
+    printf("roundtrip %s\n", memcmp(ct, ct0, 2 * Lf * n * 8) == 0 ? "ok" : "MISMATCH");
+
+    /* tier 2: query powers for bundle index 0, one synthetic BinBundle, mask generated on the device */
+    const uint32_t ns = info.source_power_count;
+    uint64_t *src = (uint64_t *)malloc((size_t)ns * 2 * Lf * n * 8);
+    const uint64_t **srcp = (const uint64_t **)malloc(ns * sizeof(*srcp));
+    for (uint32_t s = 0; s < ns; s++) {
+        for (int p = 0; p < 2; p++)
+            for (int j = 0; j < Lf; j++)
+                for (size_t k = 0; k < n; k++)
+                    src[(((size_t)s * 2 + p) * Lf + j) * n + k] = mix(77 + (((size_t)s * 2 + p) * Lf + j) * n + k) % info.coeff_modulus[j];
+        srcp[s] = src + (size_t)s * 2 * Lf * n;
+    }
+    apsu_he_relin *rk = NULL;
+    if (info.using_keyswitching) {
+        size_t words = (size_t)(K - 1) * 2 * K * n;
+        uint64_t *ksk = (uint64_t *)malloc(words * 8);
+        for (int d = 0; d < K - 1; d++)
+            for (int c = 0; c < 2; c++)
+                for (int j = 0; j < K; j++)
+                    for (size_t k = 0; k < n; k++) {
+                        size_t i = (((size_t)d * 2 + c) * K + j) * n + k;
+                        ksk[i] = mix(1000003 + i) % info.coeff_modulus[j];
+                    }
+        CHECK(apsu_he_relin_upload(ctx, ksk, &rk));
+        free(ksk);
+    }
+    uint32_t idx = 0;
+    apsu_he_powers *pw = NULL;
+    CHECK(apsu_he_compute_powers(ctx, &idx, 1, srcp, 0, rk, &pw));
+    apsu_he_bundle *bundle = NULL;
+    CHECK(apsu_he_db_random_bundle(ctx, 0, 0, info.max_items_per_bin - 1, 4242, &bundle));
+    uint64_t *mask_dev = NULL;
+    if (hipMalloc((void **)&mask_dev, n * 8) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+    uint64_t *blocks = (uint64_t *)malloc((size_t)info.items_per_bundle * 2 * 8);
+    CHECK(apsu_he_mask_generate(ctx, 99, 1, mask_dev, NULL, blocks));
+    printf("blocks %016llx\n", (unsigned long long)fnv(blocks, (size_t)info.items_per_bundle * 16));
+    uint64_t *out = (uint64_t *)malloc(2 * n * 8);
+    const apsu_he_bundle *bl[1] = { bundle };
+    const uint64_t *ml[1] = { mask_dev };
+    CHECK(apsu_he_eval_bundles(ctx, bl, 1, pw, rk, ml, 1, out, 0));
+    printf("result %016llx\n", (unsigned long long)fnv(out, 2 * n * 8));
+
+    /* error behaviour: too few powers for a bundle index that was not computed */
+    apsu_he_bundle *other = NULL;
+    CHECK(apsu_he_db_random_bundle(ctx, 1, 0, 3, 1, &other));
+    const apsu_he_bundle *bl2[1] = { other };
+    int rc = apsu_he_eval_bundles(ctx, bl2, 1, pw, rk, ml, 1, out, 0);
+    printf("missing-powers status %d (%s)\n", rc, rc == APSU_HE_INVALID_ARGUMENT ? "invalid_argument" : "unexpected");
+
+    (void)hipFree(mask_dev);
+    CHECK(apsu_he_bundle_free(other));
+    CHECK(apsu_he_bundle_free(bundle));
+    CHECK(apsu_he_powers_free(pw));
+    if (rk) CHECK(apsu_he_relin_free(rk));
+    CHECK(apsu_he_destroy(ctx));
+    printf("done\n");
+    return 0;
+}
