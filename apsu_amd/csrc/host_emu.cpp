@@ -29,7 +29,6 @@ template <int LOGN, bool INV, bool NARROW> static void emu_ntt_n(u64 *data, cons
 {
     constexpr int N = 1 << LOGN;
     std::vector<u64> lds(lds_slots(N));
-    if (INV) for (int e = 0; e < N; e++) lds[lds_slot(e)] = data[e];
     emu_pass<LOGN, INV, NARROW, 0>(lds.data(), data, T, tab);
     if (!INV) for (int e = 0; e < N; e++) data[e] = ntt_fwd_finish<NARROW>(lds[lds_slot(e)], tab);
 }

@@ -23,11 +23,8 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
-    if (INV) {                                   // stage the limb in LDS: the first inverse pass reads 16 contiguous coefficients per lane
-        for (int e = 2 * tid; e < N; e += 2 * T)
-            *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = *reinterpret_cast<const u64x2 *>(p + e);
-        __syncthreads();
-    }
+    // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
+    //  line is consumed by the wave's eight consecutive loads, so no LDS staging pass is needed)
     if constexpr (RED) ntt_pass<LOGN, INV, NARROW, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
     else ntt_pass<LOGN, INV, NARROW, 0>(lds, p, tid, T, tab);
     if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 1>(lds, p, tid, T, tab); }

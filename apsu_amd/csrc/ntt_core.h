@@ -277,7 +277,7 @@ constexpr int plan_s(int logn, int p)
 // Executes pass number PASS (in execution order) for "thread" tid of a T-thread workgroup.
 // The caller separates passes with __syncthreads() (device) or by looping tid (host emulation).
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
-//            then stores it coalesced);   inverse: pass 0 reads LDS (caller staged the limb there),
+//            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
 template <int LOGN, bool INV, bool NARROW, int PASS, bool RED = false>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
@@ -286,7 +286,7 @@ HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
     constexpr int K = plan_k(LOGN, p);
     constexpr int S = plan_s(LOGN, p);
-    constexpr int IN = (!INV && PASS == 0) ? IO_GLOBAL : IO_LDS;
+    constexpr int IN = (PASS == 0) ? IO_GLOBAL : IO_LDS;          // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
     for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, NARROW, IN, OUT, RED>(lds, glob, w, tab);
 }
