@@ -371,24 +371,58 @@ void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t
 }
 
 // ============================================================================ N1: BinBundle build on the GPU
-// polyn_with_roots (common/apsu/util/interpolate.cpp:27-80) for every bin of a BinBundle: one thread per
-// bin multiplies (x - a) into its monic polynomial, coefficients kept column-wise ([degree][slot], so the
-// accesses of a wave are coalesced).  Bins beyond `bins` and degrees beyond a bin's count hold 0
+// polyn_with_roots (common/apsu/util/interpolate.cpp:27-80) for every bin of a BinBundle.  One WAVE per bin: the
+// monic polynomial lives in registers, coefficient i in lane i % 64, slot i / 64, so multiplying by (x - a) is one
+// multiply-add per held coefficient plus a one-lane shift (P'[i] = P[i-1] - a P[i]); only the slots that can be
+// non-zero after r roots are touched.  No LDS, no barriers.  Results are written column-wise ([degree][slot]); the
+// buffer is zeroed beforehand, so bins beyond `bins` and degrees beyond a bin's count hold 0
 // (BatchedPlaintextPolyn ctor, bin_bundle.cpp:395-405).
-__global__ __launch_bounds__(EW_T) void k_polyn_with_roots(const u64 *__restrict__ roots, const u32 *__restrict__ counts,
-                                                           u32 bins, u32 stride, u32 max_deg, Mod t, u64 *__restrict__ poly, size_t n)
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_polyn_with_roots(const u64 *__restrict__ roots, const u32 *__restrict__ counts,
+                                                          u32 bins, u32 stride, Mod t, u64 *__restrict__ poly, size_t n)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);           // bin of this wave
+    if (s >= bins) return;
+    const u32 cnt = counts[s];
+    u64 P[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; j++) P[j] = 0;
+    if (lane == 0) P[0] = 1;
+    const u64 *rt = roots + (size_t)s * stride;
+    for (u32 r = 0; r < cnt; r++) {
+        const u64 a = rt[r];
+        const u64 neg_a = a ? t.q - a : 0;
+        const int jmax = (int)((r + 1) >> 6);                    // highest slot holding a coefficient of degree <= r + 1
+#pragma unroll
+        for (int j = SLOTS - 1; j >= 0; j--) {
+            if (j > jmax) continue;                              // wave-uniform
+            u64 prev = __shfl_up((unsigned long long)P[j], 1, 64);                       // P[i-1] of the lane below
+            const u64 wrap = j > 0 ? (u64)__shfl((unsigned long long)P[j > 0 ? j - 1 : 0], 63, 64) : 0;   // lane 0: last lane of slot j-1
+            if (lane == 0) prev = wrap;
+            P[j] = addmod(mulmod(P[j], neg_a, t), prev, t.q);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SLOTS; j++) {
+        const u32 d = (u32)j * 64 + lane;
+        if (d <= cnt) poly[(size_t)d * n + s] = P[j];
+    }
+}
+
+// fallback for polynomials that do not fit a wave's registers (more than 6144 coefficients): one thread per bin,
+// coefficients in global memory
+__global__ __launch_bounds__(EW_T) void k_polyn_with_roots_serial(const u64 *__restrict__ roots, const u32 *__restrict__ counts,
+                                                                  u32 bins, u32 stride, Mod t, u64 *__restrict__ poly, size_t n)
 {
     const size_t s = (size_t)blockIdx.x * EW_T + threadIdx.x;
-    if (s >= n) return;
-    u64 *P = poly + s;                                          // P[d * n]
-    for (u32 d = 0; d <= max_deg; d++) P[(size_t)d * n] = 0;
     if (s >= bins) return;
+    u64 *P = poly + s;                                          // P[d * n], zeroed by the caller
     const u32 cnt = counts[s];
     P[0] = 1;
     for (u32 r = 0; r < cnt; r++) {
         const u64 a = roots[(size_t)s * stride + r];
         const u64 neg_a = a ? t.q - a : 0;
-        // P'[i] = P[i-1] + (-a) * P[i], right to left; P'[0] = (-a) * P[0]
         for (u32 i = r + 1; i > 0; i--)
             P[(size_t)i * n] = addmod(mulmod(P[(size_t)i * n], neg_a, t), P[(size_t)(i - 1) * n], t.q);
         P[0] = mulmod(P[0], neg_a, t);
@@ -398,8 +432,14 @@ __global__ __launch_bounds__(EW_T) void k_polyn_with_roots(const u64 *__restrict
 void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
                              hipStream_t st)
 {
-    hipLaunchKernelGGL(k_polyn_with_roots, dim3((unsigned)((n + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, roots, counts, bins, stride,
-                       max_deg, t, poly, n);
+    { hipError_t e_ = hipMemsetAsync(poly, 0, (size_t)(max_deg + 1) * n * sizeof(u64), st); if (e_ != hipSuccess) throw_hip(e_, __FILE__, __LINE__); }
+    if (!bins) return;
+    const u32 slots = max_deg / 64 + 1;
+    const dim3 g((bins + 3) / 4), b(256);
+#define PW_CASE(S) if (slots <= S) { hipLaunchKernelGGL((k_polyn_with_roots<S>), g, b, 0, st, roots, counts, bins, stride, t, poly, n); KERNEL_CHECK(); return; }
+    PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(8) PW_CASE(16) PW_CASE(24) PW_CASE(32) PW_CASE(48) PW_CASE(64) PW_CASE(96)
+#undef PW_CASE
+    hipLaunchKernelGGL(k_polyn_with_roots_serial, dim3((bins + EW_T - 1) / EW_T), dim3(EW_T), 0, st, roots, counts, bins, stride, t, poly, n);
     KERNEL_CHECK();
 }
 

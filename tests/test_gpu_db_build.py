@@ -172,3 +172,21 @@ def test_bundle_image_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         G2.load_bundle(img)                                   # built for different parameters
     G.close(); G2.close()
+
+
+def test_build_spans_several_register_slots_and_the_serial_fallback():
+    # the wave-per-bin kernel keeps coefficient i in lane i % 64, slot i / 64: degrees that cross slot boundaries
+    # (63, 64, 65, 200), and a degree beyond its 6144-coefficient capacity that takes the thread-per-bin fallback
+    rng = np.random.default_rng(11)
+    for max_items, counts in ((210, [63, 64, 65, 200, 0, 1, 129]), (6200, [6199, 70, 0])):
+        js = common.toy_json(ps_low=0, max_items=max_items, query_powers=(1,))
+        p = ref.load_params(js)
+        C = ref.RefContext.from_params(p)
+        bins = [[int(v) for v in rng.choice(C.t - 1, size=c, replace=False) + 1] for c in counts]
+        A, coeffs, flags = oracle_build(C, 0, bins)
+        G = apsu_amd.HeContext(js)
+        gb = G.build_bundle(0, 0, bins)
+        assert gb.degree == max(counts)
+        for d in sorted({0, 1, 2, 62, 63, 64, 65, 128, 199, 200, max(counts) - 1, max(counts)} & set(range(max(counts) + 1))):
+            got, kind = G.bundle_coeff(gb, d)
+            assert (got == coeffs[d]).all(), "max_items %d coefficient %d" % (max_items, d)
