@@ -85,3 +85,42 @@ def test_n4_rejects_bad_input():
         G.decrypt_decode(np.full(G.n, G.q[0], dtype=np.uint64), np.zeros((1, 2, 1, G.n), dtype=np.uint64))
     vals, blks = G.mask_generate(1, 0, 0)                                 # count = 0: nothing to do
     assert vals.shape[0] == 0 and blks.shape[0] == 0
+
+
+def test_all_gpu_loopback_1M_params():
+    """N1 + hot path + N4 chained on the device at 1M-1024-com: BinBundle built from items on the GPU, masks drawn on the
+    GPU, evaluation, the querier's decrypt/decode on the GPU.  Only key generation and query encryption (the other
+    party) come from the oracle.  A slot decrypts to its mask exactly where the query value is an item of the bin."""
+    rng = np.random.default_rng(21)
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: []})
+    G = apsu_amd.HeContext(js)
+    n = G.n
+    n_bins = S.p["items_per_bundle"] * S.p["felts_per_item"]
+    bins = []
+    for s in range(n_bins):
+        c = int(rng.integers(1, 100))
+        b = [int(v) for v in rng.choice(G.t - 1, size=c, replace=False) + 1]
+        if s % 3 == 0:
+            b[int(rng.integers(0, c))] = int(S.x[0][s])          # the query value is a member of every third bin
+        bins.append(b)
+    gb = G.build_bundle(0, 0, bins)
+    buf = torch.empty(n, dtype=torch.int64, device="cuda")
+    mask_vals, blocks = G.mask_generate(2024, 1, buf.data_ptr())
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    out = torch.empty((1, 2, n), dtype=torch.int64, device="cuda")
+    G.eval_bundles([gb], pw, rk, [buf.data_ptr()], out=out.data_ptr(), masks_on_device=True, out_on_device=True)
+    got, gblk = G.decrypt_decode(S.sk[0], out.data_ptr(), count=1, on_device=True)
+    member = np.array([int(S.x[0][s]) in bins[s] for s in range(n_bins)])
+    assert member[::3].all()
+    assert (got[0][:n_bins][member] == mask_vals[0][:n_bins][member]).all()
+    assert (got[0][:n_bins][~member] != mask_vals[0][:n_bins][~member]).mean() > 0.99       # P(x) != 0 off the set
+    # a matching item gives the same PEQT block on both sides
+    felts = S.p["felts_per_item"]
+    items_all_member = [i for i in range(S.p["items_per_bundle"]) if member[i * felts:(i + 1) * felts].all()]
+    for i in items_all_member:
+        assert (gblk[0][i] == blocks[0][i]).all()
+    # and the host-side oracle decrypts the same plaintext
+    pt, budget = S.C.decrypt(S.sk, np.ascontiguousarray(out.cpu().numpy().view(np.uint64).reshape(2, 1, n)), 0)
+    assert budget > 0 and (S.C.decode(pt) == got[0]).all()
