@@ -995,12 +995,15 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     }
 
     struct LaneGuard { Engine *e; ~LaneGuard() { e->switch_lane(0); } } lane_guard{ this };
-    // Two-stream walk (APSU_HE_SPLIT=1): the high-power half of the DAG runs on the second stream next to the low-power
-    // half and to the BinBundle inner products.  Measured on 16M-4096: 4.17 -> 4.03 ms per query at four bundle indices,
-    // nothing at one (the merged level-synchronous walk already has the longer chain's launch count), and per-kernel
-    // timings stop being additive — so it is opt-in.
-    static const bool split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v && atoi(v) != 0; }();
-    const bool split = split_ok_ && on_device && split_env;   // host inputs end with a sync anyway
+    // Two-stream walk: the high-power half of the DAG runs on the second stream next to the low-power half and to the
+    // BinBundle inner products.  Measured per rank on 16M-4096 (tools/rank_cost.py): 0.95 -> 0.86 ms with one bundle
+    // index and 3-4 BinBundles, 1.18 -> 1.11 with 7, 1.97 -> 1.91 with two indices, 3.84 -> 3.61 with all four.  Default:
+    // on for one or two bundle indices (the shards of a multi-GPU run, where launches do not fill the machine), off for
+    // larger batches, where per-kernel timings are the evidence and stop being additive under concurrency (DESIGN.md
+    // section 5); APSU_HE_SPLIT=0/1 forces it.  Event profiling always takes the one-stream walk: a launch bracketed
+    // by events next to another stream's kernels measures the sharing, not the kernel.
+    static const int split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+    const bool split = split_ok_ && on_device && !prof_on_ && (split_env < 0 ? nb <= 2 : split_env == 1);   // host inputs end with a sync anyway
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
     WITH_ARENA({
