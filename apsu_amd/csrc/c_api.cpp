@@ -202,6 +202,8 @@ int apsu_he_bundle_load(apsu_he_ctx *c, const uint8_t *buf, uint64_t size, apsu_
         *out = b;
     });
 }
+int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_two_stream(mode); }); }
 int apsu_he_mask_generate(apsu_he_ctx *c, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks)
 { return guarded([&] { REQUIRE(c && (masks_dev || !count), "null argument"); c->eng->mask_generate(seed, count, masks_dev, values, blocks); }); }
 int apsu_he_decrypt_decode(apsu_he_ctx *c, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,

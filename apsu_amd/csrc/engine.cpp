@@ -1003,7 +1003,8 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // section 5); APSU_HE_SPLIT=0/1 forces it.  Event profiling always takes the one-stream walk: a launch bracketed
     // by events next to another stream's kernels measures the sharing, not the kernel.
     static const int split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
-    const bool split = split_ok_ && on_device && !prof_on_ && (split_env < 0 ? nb <= 2 : split_env == 1);   // host inputs end with a sync anyway
+    const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : split_env;                  // API override, then environment
+    const bool split = split_ok_ && on_device && !prof_on_ && (split_mode < 0 ? nb <= 2 : split_mode == 1);   // host inputs end with a sync anyway
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
     WITH_ARENA({

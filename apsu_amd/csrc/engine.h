@@ -144,6 +144,8 @@ public:
     struct ProfStats { double ms[P_COUNT]; uint64_t launches[P_COUNT]; uint64_t units[P_COUNT]; };
     void profile_enable(int mode);      // 0 off, 1 every kernel class, 2 NTT launches only (cheapest)
     void profile_read(ProfStats *out, bool reset);
+    // two-stream ComputePowers: -1 = default policy (on for one or two bundle indices), 0 = off, 1 = on
+    void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
 
 private:
     // arena (bump allocator reset per top-level operation)
@@ -210,6 +212,7 @@ private:
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_, sched_low_, sched_high_;
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
+    int two_stream_mode_ = -1;
     void build_schedule();
     void build_schedule_for(Sched &s, const std::vector<char> &member);
     struct DagRun;                    // per-call state of one walk over a schedule

@@ -323,6 +323,10 @@ class HeContext:
         _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
         return Bundle(self, h, -1, -1, deg.value)
 
+    def set_two_stream(self, mode):
+        """-1 default policy, 0 off, 1 on: ComputePowers' high-power chain on a second stream"""
+        _check(load_library().apsu_he_set_two_stream(self.h, int(mode)))
+
     def mask_generate(self, seed, count, masks_dev, want_values=True, want_blocks=True):
         """N4: `count` random masks (receiver_osn.cpp:217-284).  masks_dev: device pointer to count*n words receiving the
         encoded plaintexts.  -> (values [count][n] or None, blocks [count][items_per_bundle][2] (low, high) or None)"""

@@ -205,6 +205,22 @@ def main():
         fence()
         prof_all = take_profile()
         ctx.profile_enable(2)
+    # the same query with ComputePowers' high-power chain forced onto the second stream (untimed extra steps; `value`
+    # above is the default policy, which keeps large batches on one stream so that per-kernel timings stay additive)
+    two_stream_ms = None
+    if not args.no_profile:
+        ctx.profile_enable(0)
+        ctx.set_two_stream(1)
+        for _ in range(2):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            step()
+        fence()
+        two_stream_ms = (time.perf_counter() - t1) * 1e3 / max(2, args.steps // 2)
+        ctx.set_two_stream(-1)
+        ctx.profile_enable(2)
     ms_local = elapsed * 1e3 / max(1, args.steps)
     ms_step = ms_local
     if world > 1:
@@ -225,6 +241,9 @@ def main():
                    "setup_s": round(t_setup, 2)},
     }
 
+    if two_stream_ms is not None and world == 1:
+        result["two_stream"] = {"ms_per_step": round(two_stream_ms, 4), "note": "APSU_HE_SPLIT=1 / apsu_he_set_two_stream(ctx, 1): "
+                                "same results, not the default for batches of more than two bundle indices (DESIGN.md section 5)"}
     if prof is not None:
         steps = max(1, sampled)
         ntt_ms = prof["ntt_fwd"][0] + prof["ntt_inv"][0]

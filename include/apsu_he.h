@@ -178,6 +178,12 @@ int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles,
                          const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out_cts,
                          int out_on_device);
 
+/* Scheduling option: ComputePowers may walk the high-power half of the PowersDag on a second HIP stream, next to the
+ * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on for calls
+ * with one or two bundle indices), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1 sets the default for
+ * contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
+int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
+
 /* ---- measurement hooks (replace the reference's STOPWATCH timers, receiver_osn.cpp:167,403,504) ----
  * Per-kernel-class device time from HIP events recorded on the engine's stream around each launch.
  * Classes (index): 0 ntt_fwd, 1 ntt_inv, 2 dyadic_mac, 3 behz_ext, 4 behz_tensor, 5 behz_finish,
