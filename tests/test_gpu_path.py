@@ -246,16 +246,19 @@ def test_concurrent_callers_on_one_context():
 
 
 def test_fallback_paths_match():
-    # the summed-Bsk finish of eval_patstock's products and the two-stream ComputePowers are the defaults; their
-    # alternatives (per-term finish: APSU_HE_EVAL_PER_TERM; ComputePowers forced onto one / two streams: APSU_HE_SPLIT=0/1; read once per
-    # process) must give the same bits, so the same scenarios run in child processes with each switch set
+    # the summed-Bsk finish of eval_patstock's products and the default stream policy of ComputePowers have
+    # alternatives (per-term finish: APSU_HE_EVAL_PER_TERM; ComputePowers forced onto one / two streams: APSU_HE_SPLIT=0/1;
+    # read once per process); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte workspace budget
+    # evaluates one BinBundle per chunk.  All must give the same bits, so scenarios run in child processes per switch.
     import subprocess, sys, os
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import test_gpu_path as t\n"
-            "t.test_config_1M_1024_com(); t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced()\n"
-            "t.test_config_16M_4096_reduced()\n"
+    head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu_path as t\n"
             % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    for switch, value in (("APSU_HE_EVAL_PER_TERM", "1"), ("APSU_HE_SPLIT", "0"), ("APSU_HE_SPLIT", "1")):
+    small = "t.test_toy_paterson_stockmeyer_ragged_degrees(); t.test_toy_without_paterson_stockmeyer(); t.test_config_1M_1024_com()\n"
+    big = ("t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced(); "
+           "t.test_config_16M_4096_reduced()\n")
+    for switch, value, code in (("APSU_HE_EVAL_PER_TERM", "1", small + big), ("APSU_HE_SPLIT", "0", small + big),
+                                ("APSU_HE_SPLIT", "1", small + big), ("APSU_HE_ARENA_BYTES", "1048576", small),
+                                ("APSU_HE_EVAL_WS_BYTES", "1", small)):
         env = dict(os.environ, **{switch: value})
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, switch + "=" + value + "\n" + r.stdout + r.stderr
