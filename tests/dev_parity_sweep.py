@@ -1,5 +1,6 @@
-"""Developer check run on the GPU box: every tier-1 op and the tier-2 path against the oracle.
-Prints one line per check and keeps going on mismatch (maximises information per gpurun call)."""
+"""Developer check run on the GPU box (`python tests/dev_parity_sweep.py`, not collected by pytest): every tier-1 op and
+the tier-2 path against the oracle.  Prints one line per check and keeps going on mismatch (maximises information
+per gpurun call).  Lives under tests/ because it uses the oracle."""
 import sys, os, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
