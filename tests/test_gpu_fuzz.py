@@ -20,8 +20,10 @@ def random_params(rng):
     n = rng.choice([64, 256, 1024, 4096])
     K = rng.choice([2, 3, 4, 5])
     widths = [rng.choice([30, 36, 40, 45, 50, 56, 60]) for _ in range(K)]
-    felts = rng.choice([5, 6, 7, 8])
-    plain_bits = rng.choice([b for b in (16, 17, 18, 20, 22) if 80 <= (b - 1) * felts <= 128] or [17])
+    felts = rng.choice([2, 3, 4, 5, 6, 7, 8])
+    # plain moduli above 2^32 take the long-division branch of add_plain's rounding (the noise budget is gone there,
+    # bit-exactness is still checked)
+    plain_bits = rng.choice([b for b in (16, 17, 18, 20, 22, 28, 33, 41, 44) if 80 <= (b - 1) * felts <= 128] or [17])
     max_items = rng.randint(3, 24)
     ps_low = rng.choice([0, 0] + list(range(2, max(3, max_items // 2 + 1))))
     targets = ref.create_powers_set(ps_low, max_items)
@@ -40,7 +42,7 @@ def random_params(rng):
     }), max_items
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(28))
 def test_random_parameter_sets(seed):
     rng = random.Random(1000 + seed)
     for _ in range(40):                                     # draw until the reference's own validation accepts the set
