@@ -20,7 +20,8 @@
 //   narrow moduli ((4*log2(n)+1)*q < 2^64, e.g. the 48..58-bit coefficient primes): the forward
 //     transform needs NO conditional subtraction at all (values grow by < 4q per stage) and ends with
 //     one Barrett reduction per coefficient;
-//   wide moduli (the 61-bit BEHZ primes): values live in [0,8q), one conditional subtraction per butterfly.
+//   wide moduli (the 61-bit BEHZ primes): values live in [0,2^64), one subtraction of 4q per butterfly, conditional
+//   on the top bit alone (csub_top).
 // The inverse is computed as a decimation-in-time CYCLIC inverse transform (bit-reversed input, natural
 // output, twiddles psi^(-j*n/g)) followed by the twist n^-1 * psi^-j, so it uses the very same butterfly
 // (x + w*y, x - w*y) and range discipline as the forward transform.
@@ -86,6 +87,11 @@ HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
     x = s;
 }
 
+// Range control for wide moduli (q < 2^61, 4q < 2^63): subtract 4q exactly when the top bit is set.  The result is
+// below max(2^63, 2^64 - 4q), so a following x + v (v < 4q) and x - v + 4q still fit 64 bits; no comparison with 4q
+// is needed.  n4 = 2^64 - 4q.
+HD u64 csub_top(u64 x, u64 n4) { return x + ((u64)((int64_t)x >> 63) & n4); }
+
 enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
 
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
@@ -101,7 +107,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
     constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;      // column groups per block
     constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);      // every lane of a wave shares the twiddles
     const TwPair *__restrict__ W = tab.fwd;
-    const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2;
+    const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2, n4 = (u64)0 - q4;
 
     int block, c0;
     if (COLS) { block = w / CG; c0 = (w % CG) * G; }
@@ -176,7 +182,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                         const int gap = COLS ? (bit << LOWBITS) : bit;
                         const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
-                        if (!NARROW) x = csub(x, q4);
+                        if (!NARROW) x = csub_top(x, n4);
                         bfly_lazy4(x, y, tv[0], tv[1], nq, q4);
                     }
                     continue;
@@ -189,7 +195,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 for (int gg = 0; gg < G; gg++) {
                     if (!COLS && gg != g) continue;
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
-                    if (!NARROW) x = csub(x, q4);
+                    if (!NARROW) x = csub_top(x, n4);
                     bfly_lazy4(x, y, t.w, t.wq, nq, q4);
                 }
             }
@@ -205,8 +211,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 if (INV) {
                     const u64x2 sv = ldg16(reinterpret_cast<const u64 *>(tab.scale + idx(g, j)));
                     v = mul_shoup(v, sv[0], sv[1], q);
-                } else if (NARROW) { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }
-                else v = csub(csub(csub(v, q4), q << 1), q);
+                } else { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }       // any 64-bit v
                 r[g][j] = v;
             }
     }
@@ -246,8 +251,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 template <bool NARROW>
 HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 {
-    if (NARROW) { v = v - mulhi64(v, tab.r1) * tab.q; return csub(v, tab.q); }
-    return csub(csub(csub(v, tab.q << 2), tab.q << 1), tab.q);
+    v = v - mulhi64(v, tab.r1) * tab.q;                           // any 64-bit v (wide moduli leave values up to 2^64 - 1)
+    return csub(v, tab.q);
 }
 
 // ---- pass schedule (stage counts per pass, summing to LOGN), resolved at compile time ----
