@@ -939,7 +939,17 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 lvl--;
             }
         };
-        if (do_low) {
+        if (do_low && first == low_target && !s.low_powers.empty()) {
+            // no level change: the forward NTT (:467,475) reads the slots and writes the packed output directly
+            const size_t np = s.low_powers.size();
+            std::vector<const u64 *> srcp(np * nb * 2 * Lf);
+            for (int b = 0; b < nb; b++)
+                for (size_t i = 0; i < np; i++)
+                    for (size_t pl = 0; pl < 2 * Lf; pl++)
+                        srcp[(((size_t)b * np + i) * 2 * Lf) + pl] = slot_ptr(s.slot_of[s.low_powers[i]], b) + pl * n;
+            PROF(P_NTT_FWD, srcp.size());
+            launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_);
+        } else if (do_low) {
             convert(s.low_powers, low_target, pw->low.u());
             d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                      // :467,475
         }
