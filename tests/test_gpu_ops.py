@@ -176,3 +176,25 @@ def test_ntt_large_batch_streams_correctly():
     G.transform_from_ntt_inplace(g, 2)
     assert (g == ct).all()                                   # size-independent round-trip property
     G.close()
+
+
+@pytest.mark.parametrize("n", [2048, 8192])
+def test_ntt_every_prime_width(n):
+    # coefficient primes of every width the engine may meet, across the narrow / wide boundary of the lazy butterflies
+    # ((4 log n + 1) q < 2^64 up to 58 bits at n = 8192): forward and inverse transforms against the oracle
+    rng = np.random.default_rng(n)
+    for bits in (30, 33, 40, 47, 52, 55, 56, 57, 58, 59, 60):
+        C = ref.RefContext(n, [bits, bits], 65537, 0)
+        G = apsu_amd.HeContext(n=n, coeff_modulus=C.q, plain_modulus=C.t)
+        lvl = C.first
+        ct = rand_ct(C, rng, 2, lvl, edge=True)
+        a, g = ct.copy(), ct.copy()
+        C.transform_to_ntt(a, lvl)
+        G.transform_to_ntt_inplace(g, lvl)
+        assert (a == g).all(), "forward, %d-bit primes" % bits
+        G.transform_from_ntt_inplace(g, lvl)
+        assert (g == ct).all(), "inverse, %d-bit primes" % bits
+        if C.K > 1:                                  # multiply + relinearize exercise the 61-bit auxiliary primes next to them
+            b = rand_ct(C, rng, 2, lvl)
+            assert (C.multiply(ct, b, lvl) == G.multiply(ct, b, lvl)).all(), "multiply, %d-bit primes" % bits
+        G.close()

@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256) void k_morph(const MacJob *__restrict__ jobs, 
 int main(int argc, char** argv) {
     const size_t n = 8192, L = 3, ptw = L * n;
     const int terms = 44, streams = 784 - 784 % MAC_G, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
+    const size_t skew = getenv("SKEW") ? atoi(getenv("SKEW")) : 0;   // extra words between consecutive streams (breaks the 8.25 MB stride)
     const size_t words = (size_t)streams * terms * ptw;
     u64 *db, *pw, *out; DevLevel* lv; MacJob* dj;
-    CHECK(hipMalloc(&db, words * 8)); const size_t pstride = nb * 2 * L * n + pad + 2 * ppad; CHECK(hipMalloc(&pw, (size_t)terms * pstride * 8)); CHECK(hipMalloc(&out, (size_t)streams * 2 * L * n * 8));
-    k_fillrand<<<4096, 256>>>(db, words, ((u64)1 << 55) - 1); k_fillrand<<<1024, 256>>>(pw, (size_t)terms * pstride, ((u64)1 << 55) - 1);
+    CHECK(hipMalloc(&db, (words + (size_t)streams * skew) * 8)); const size_t pstride = nb * 2 * L * n + pad + 2 * ppad; CHECK(hipMalloc(&pw, (size_t)terms * pstride * 8)); CHECK(hipMalloc(&out, (size_t)streams * 2 * L * n * 8));
+    k_fillrand<<<4096, 256>>>(db, words + (size_t)streams * skew, ((u64)1 << 55) - 1); k_fillrand<<<1024, 256>>>(pw, (size_t)terms * pstride, ((u64)1 << 55) - 1);
     DevLevel h; memset(&h, 0, sizeof(h)); h.L = 3;
     u64 q[3] = { 0xfffffffff70001ULL, 0xfffffffff78001ULL, 0xfffffffffb4001ULL };
     for (int j = 0; j < 3; j++) { unsigned __int128 all = ~(unsigned __int128)0; unsigned __int128 r = all / q[j]; h.q[j] = Mod{ q[j], (u64)r, (u64)(r >> 64) }; h.mac_shift[j] = 28; h.mac_chunk[j] = 127; }
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
     std::vector<MacJob> jobs;
     for (int s = 0; s < streams; s += MAC_G) {
         MacJob j{}; j.pw = pw; j.cnt = terms; j.ng = MAC_G; j.pt_stride = ptw; j.pw_stride = pstride; j.pw_poly_stride = L * n + ppad; j.nl = 3; j.out_poly_stride = L * n; j.limb0 = 0;
-        for (int g = 0; g < MAC_G; g++) { j.pt[g] = db + (size_t)(s + g) * terms * ptw; j.out[g] = out + (size_t)(s + g) * 2 * L * n; }
+        for (int g = 0; g < MAC_G; g++) { j.pt[g] = db + (size_t)(s + g) * (terms * ptw + skew); j.out[g] = out + (size_t)(s + g) * 2 * L * n; }
         jobs.push_back(j);
     }
     CHECK(hipMalloc(&dj, jobs.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj, jobs.data(), jobs.size() * sizeof(MacJob), hipMemcpyHostToDevice));
