@@ -10,10 +10,18 @@
 
 using namespace apsu_he;
 
-struct apsu_he_ctx { std::unique_ptr<Engine> eng; };
+#include <mutex>
+#include <unordered_set>
+
+struct apsu_he_powers;
+// live_powers: the apsu_he_powers handles whose buffers return to this context's pool when they are freed.
+// apsu_he_destroy orphans them (their device buffers are released there), so freeing a handle after its context is
+// safe — the Python binding's garbage collector does exactly that.
+struct apsu_he_ctx { std::unique_ptr<Engine> eng; std::unordered_set<apsu_he_powers *> live_powers; };
 struct apsu_he_relin { std::unique_ptr<RelinKeys> rk; };
 struct apsu_he_bundle { std::unique_ptr<Bundle> b; };
-struct apsu_he_powers { std::unique_ptr<Powers> p; Engine *eng = nullptr; };
+struct apsu_he_powers { std::unique_ptr<Powers> p; apsu_he_ctx *ctx = nullptr; };
+static std::mutex g_registry_mu;      // guards every ctx::live_powers and powers::ctx (lock order: registry, then Engine)
 
 static thread_local std::string g_last_error;
 
@@ -64,7 +72,18 @@ int apsu_he_create_raw(uint64_t n, const uint64_t *coeff_modulus, int k, uint64_
     });
 }
 
-int apsu_he_destroy(apsu_he_ctx *ctx) { return guarded([&] { delete ctx; }); }
+int apsu_he_destroy(apsu_he_ctx *ctx)
+{
+    return guarded([&] {
+        if (!ctx) return;
+        {
+            std::lock_guard<std::mutex> g(g_registry_mu);
+            for (apsu_he_powers *p : ctx->live_powers) { p->ctx = nullptr; p->p.reset(); }
+            ctx->live_powers.clear();
+        }
+        delete ctx;
+    });
+}
 
 int apsu_he_get_info(const apsu_he_ctx *ctx, apsu_he_info *out)
 {
@@ -221,40 +240,40 @@ int apsu_he_compute_powers(apsu_he_ctx *c, const uint32_t *bundle_indices, int n
     return guarded([&] {
         REQUIRE(c && bundle_indices && src && out, "null argument");
         auto p = new apsu_he_powers;
-        p->eng = c->eng.get();
         try { p->p = c->eng->compute_powers(bundle_indices, nb, src, on_device != 0, rk ? rk->rk.get() : nullptr); }
         catch (...) { delete p; throw; }
+        {
+            std::lock_guard<std::mutex> g(g_registry_mu);
+            p->ctx = c;
+            c->live_powers.insert(p);
+        }
         *out = p;
     });
 }
-/* buffers go back to the context's pool (the context must outlive its powers objects) */
+/* buffers go back to the pool of the context if it is still alive; after apsu_he_destroy only the handle is left */
 int apsu_he_powers_free(apsu_he_powers *p)
-{ return guarded([&] { if (p) { if (p->eng) p->eng->recycle_powers(std::move(p->p)); delete p; } }); }
+{
+    return guarded([&] {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(g_registry_mu);
+            if (p->ctx) {
+                p->ctx->live_powers.erase(p);
+                p->ctx->eng->recycle_powers(std::move(p->p));
+                p->ctx = nullptr;
+            }
+        }
+        delete p;
+    });
+}
 
 int apsu_he_powers_download(apsu_he_ctx *c, const apsu_he_powers *p, uint32_t bundle_idx, uint32_t power, uint64_t *out,
                             size_t capacity_words, int *chain_idx, int *is_ntt)
 {
     return guarded([&] {
         REQUIRE(c && p && out, "null argument");
-        const Powers &pw = *p->p;
-        const PSUParams *psu = c->eng->psu();
-        REQUIRE(psu, "context has no PSUParams");
-        int b = pw.slot_of(bundle_idx);
-        REQUIRE(b >= 0, "bundle index not present");
-        const uint32_t ps = psu->query_params.ps_low_degree;
-        const size_t n = c->eng->he().n;
-        const bool low = !ps || power <= ps;
-        const int lvl = low ? pw.low_level : pw.high_level;
-        uint32_t idx;
-        if (low) { REQUIRE(power >= 1 && power <= pw.n_low, "power not available"); idx = power - 1; }
-        else { REQUIRE(power % (ps + 1) == 0 && power / (ps + 1) <= pw.n_high, "power not available"); idx = power / (ps + 1) - 1; }
-        const size_t words = (size_t)2 * (lvl + 1) * n;
-        REQUIRE(capacity_words >= words, "output buffer too small");
-        c->eng->sync();
-        const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * words;
-        if (hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
-        if (chain_idx) *chain_idx = lvl;
-        if (is_ntt) *is_ntt = low ? 1 : 0;
+        REQUIRE(p->p, "the powers object outlived its context");
+        c->eng->download_power(*p->p, bundle_idx, power, out, capacity_words, chain_idx, is_ntt);
     });
 }
 
@@ -263,6 +282,7 @@ int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, i
 {
     return guarded([&] {
         REQUIRE(c && bundles && powers && masks && out && count >= 0, "null argument");
+        REQUIRE(powers->p, "the powers object outlived its context");
         std::vector<const Bundle *> bs(count);
         for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); bs[i] = bundles[i]->b.get(); }
         c->eng->eval_bundles(bs.data(), count, *powers->p, rk ? rk->rk.get() : nullptr, masks, masks_on_device != 0, out,

@@ -23,6 +23,20 @@ void throw_hip(hipError_t e, const char *file, int line)
 
 namespace { struct ArenaOverflow { size_t need; }; }
 
+// Every public entry point serialises on the context and runs with the context's device current: HIP's current
+// device is per host thread, and the reference calls the Evaluator from a thread pool (receiver_osn.cpp:334-364),
+// so a worker thread may arrive with another device selected (several contexts on different GPUs in one process).
+struct Engine::Enter {
+    std::lock_guard<std::mutex> lock;
+    int prev = -1;
+    explicit Enter(Engine *e) : lock(e->mu_)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != e->device_) { prev = cur; HIP_CHECK(hipSetDevice(e->device_)); }
+    }
+    ~Enter() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 void DevBuf::alloc(size_t bytes)
 {
     release();
@@ -55,6 +69,12 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     if (e != hipSuccess || ndev == 0)
         throw HipError("no HIP device available: the query-evaluation engine has no CPU fallback");
     if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+    // the NTT keeps one limb in a workgroup's LDS: n = 2^logn coefficients with a compiled pass plan (ntt_core.h)
+    if (plan_passes(hp_.logn) == 0)
+        throw std::invalid_argument("poly_modulus_degree " + std::to_string(hp_.n) +
+                                    " is not supported by the GPU engine (supported: 64, 256, 1024, 2048, 4096, 8192)");
+    struct Restore { int prev = -1; ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore;
+    { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != device) restore.prev = cur; }
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     {   // the second stream carries short latency-bound chains that must make progress next to a grid-filling kernel
@@ -219,6 +239,10 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
 
 Engine::~Engine()
 {
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device_ && hipSetDevice(device_) == hipSuccess;
+    struct Back { bool on; int dev; ~Back() { if (on) (void)hipSetDevice(dev); } } back{ switched, cur };
+    powers_pool_.clear();
     if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
     if (parked_.st) { (void)hipStreamSynchronize(parked_.st); (void)hipStreamDestroy(parked_.st); }
     if (ev_main_) (void)hipEventDestroy(ev_main_);
@@ -245,7 +269,7 @@ void Engine::switch_lane(int lane)
 // ---- profiling: one HIP event pair per launch on the engine's stream, resolved at the next sync
 void Engine::profile_enable(int mode)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipStreamSynchronize(parked_.st));
     prof_collect();
@@ -255,7 +279,7 @@ void Engine::profile_enable(int mode)
 
 void Engine::profile_read(ProfStats *out, bool reset)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipStreamSynchronize(parked_.st));
     prof_collect();
@@ -411,7 +435,7 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
 
 void Engine::recycle_powers(std::unique_ptr<Powers> p)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!p) return;
     // keep the most recently released buffers: a context that changes its batch shape must not be left with a pool
     // full of buffers of the old shape (every call would then allocate and free ~100 MB)
@@ -469,7 +493,7 @@ void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
 
 void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
@@ -484,7 +508,7 @@ void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
 
 void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
@@ -499,7 +523,7 @@ void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
 
 void Engine::multiply_plain_ntt(const u64 *ct, const u64 *pt_ntt, u64 *out, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
@@ -522,7 +546,7 @@ static bool is_monomial(const u64 *pt, size_t count)
 
 void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
@@ -542,7 +566,7 @@ void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, i
 // dyadic product, INTT.  SEAL's monomial shortcut (no lift) is honoured.
 void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 *out, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
@@ -566,7 +590,7 @@ void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 
 
 void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t w = (size_t)polys * (chain_idx + 1) * hp_.n;
@@ -582,7 +606,7 @@ void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
 
 void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
@@ -601,7 +625,7 @@ void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
 
 void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1;
@@ -628,7 +652,7 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
 
 void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     if (!hp_.using_keyswitching) throw std::logic_error("parameters do not support key switching");
@@ -644,7 +668,7 @@ void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
 
 void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     check_level(chain_idx);
     if (chain_idx == 0) throw std::invalid_argument("end of modulus switching chain reached");
@@ -660,7 +684,7 @@ void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
 
 void Engine::clear_irrelevant_bits(u64 *ct, int polys)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     const size_t w = (size_t)polys * hp_.n;
     WITH_ARENA({
@@ -675,7 +699,7 @@ void Engine::clear_irrelevant_bits(u64 *ct, int polys)
 // ============================================================================ tier 2: uploads
 std::unique_ptr<RelinKeys> Engine::upload_relin_keys(const u64 *rk_host)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!hp_.using_keyswitching) throw std::logic_error("parameters do not support key switching");
     auto rk = std::make_unique<RelinKeys>();
     const size_t w = (size_t)(hp_.K - 1) * 2 * hp_.K * hp_.n;
@@ -703,7 +727,7 @@ static void bundle_shape(const PSUParams &psu, const HeParams &hp, uint32_t degr
 std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
                                               const u64 *const *coeff_ptrs, const unsigned char *is_ntt)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!n_coeffs) throw std::invalid_argument("batched_coeffs is empty");
@@ -965,10 +989,15 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
 std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
                                                const RelinKeys *rk)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (nb <= 0) throw std::invalid_argument("no bundle indices given");
     if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
+    // one coefficient prime = no key switching: the reference then leaves every product at size 3 (receiver_osn.cpp:427-432)
+    // and multiplies size-3 ciphertexts further; this engine holds size-2 powers, so that case is refused, not truncated.
+    // Every shipped single-prime parameter set sends all powers as sources (depth 0).
+    if (!hp_.using_keyswitching && dag_.depth() > 0)
+        throw std::logic_error("ComputePowers needs ciphertext products but the parameters do not support relinearization");
     const Sched &s = sched_;
     const size_t n = hp_.n;
     job_seq_base_ = 0;                                       // job-cache slots 0..255: ComputePowers
@@ -989,6 +1018,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         }
     }
     const bool recycled = (bool)pw;
+    // a pooled buffer whose high half was produced on the second stream and never consumed: the main stream must not
+    // overwrite it before those kernels have finished
+    if (recycled && pw->high_async && pw->high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw->high_ready, 0));
     if (!pw) pw = std::make_unique<Powers>();
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
@@ -1055,6 +1087,33 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
 }
 
 
+void Engine::download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
+                            int *is_ntt)
+{
+    Enter g(this);
+    if (!has_psu_) throw std::invalid_argument("context has no PSUParams");
+    const int b = pw.slot_of(bundle_idx);
+    if (b < 0) throw std::invalid_argument("bundle index not present");
+    const uint32_t ps = psu_.query_params.ps_low_degree;
+    const bool low = !ps || power <= ps;
+    const int lvl = low ? pw.low_level : pw.high_level;
+    uint32_t idx;
+    if (low) {
+        if (power < 1 || power > pw.n_low) throw std::invalid_argument("power not available");
+        idx = power - 1;
+    } else {
+        if (power % (ps + 1) != 0 || power / (ps + 1) > pw.n_high) throw std::invalid_argument("power not available");
+        idx = power / (ps + 1) - 1;
+    }
+    const size_t words = (size_t)2 * (lvl + 1) * hp_.n;
+    if (capacity_words < words) throw std::invalid_argument("output buffer too small");
+    sync();
+    const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * words;
+    HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
+    if (chain_idx) *chain_idx = lvl;
+    if (is_ntt) *is_ntt = low ? 1 : 0;
+}
+
 // ============================================================================ tier 2: BinBundle construction
 // raw = the batched polynomial's coefficient-form plaintexts [degree+1][n] mod t on the device.  Applies the
 // layout rule of the BatchedPlaintextPolyn ctor (bin_bundle.cpp:385-420): NTT-form coefficients are lifted
@@ -1095,7 +1154,7 @@ void Engine::finish_bundle(Bundle &b, const u64 *raw)
 
 std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (degree > psu_.table_params.max_items_per_bin) throw std::invalid_argument("degree exceeds max_items_per_bin");
@@ -1117,7 +1176,7 @@ std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cach
 std::unique_ptr<Bundle> Engine::build_bundle(uint32_t bundle_idx, uint32_t cache_idx, const u64 *roots, const uint32_t *counts,
                                              uint32_t bins, uint32_t stride)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     TIER1_SLOTS();
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
@@ -1182,7 +1241,7 @@ size_t Engine::bundle_image_size(const Bundle &b) const { return sizeof(ImageHea
 
 size_t Engine::save_bundle(const Bundle &b, unsigned char *buf, size_t capacity)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     const size_t total = bundle_image_size(b);
     if (capacity < total) throw std::invalid_argument("image buffer too small");
@@ -1210,7 +1269,7 @@ size_t Engine::save_bundle(const Bundle &b, unsigned char *buf, size_t capacity)
 
 std::unique_ptr<Bundle> Engine::load_bundle(const unsigned char *buf, size_t size)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     ImageHeader hd;
     if (size < sizeof(hd)) throw std::invalid_argument("BinBundle image is truncated");
@@ -1243,7 +1302,7 @@ std::unique_ptr<Bundle> Engine::load_bundle(const unsigned char *buf, size_t siz
 
 size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     sync();
     const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
     const size_t n = hp_.n;
@@ -1276,7 +1335,7 @@ static uint32_t plain_modulus_len(u64 t)
 
 void Engine::mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
     if (!count) return;
@@ -1302,7 +1361,7 @@ void Engine::mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values
 
 void Engine::decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_device, uint32_t count, u64 *values_host, u64 *blocks_host)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
     if (!count) return;
@@ -1350,7 +1409,7 @@ void Engine::decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_devi
 void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
                           const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device)
 {
-    std::lock_guard<std::mutex> g(mu_);
+    Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (count <= 0) return;
     const size_t n = hp_.n;
@@ -1376,7 +1435,12 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             if (b.degree && b.pt_level != low) throw std::logic_error("plaintext level does not match the powers");
         }
     }
-    if (any_ps && hp_.using_keyswitching && !rk) throw std::invalid_argument("relinearization keys are required");
+    // Without key switching the reference leaves eval_patstock's result at size 3 (bin_bundle.cpp:238-240,308-310); this
+    // ABI returns size-2 results (2*n words), so that combination is refused instead of silently dropping c2.  No
+    // shipped parameter set reaches it: every single-prime set has ps_low_degree 0.
+    if (any_ps && !hp_.using_keyswitching)
+        throw std::logic_error("eval_patstock without key switching yields a size-3 ciphertext, which this interface does not return");
+    if (any_ps && !rk) throw std::invalid_argument("relinearization keys are required");
 
     // powers are stored bundle-index major ([idx][power][2][L][n]): one index's powers are contiguous
     auto low_ptr = [&](uint32_t power, int b) { return pw.low.u() + (((size_t)b * pw.n_low + (power - 1)) * 2) * Ll * n; };
@@ -1551,8 +1615,11 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 int max_terms = 0;
                 for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
                 static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
+                // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
+                u64 q_widest = 0;
+                for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
                 const bool summed = !force_per_term && Lh <= 4 &&
-                                    (unsigned __int128)max_terms * hlevel(high).q[0] < ((unsigned __int128)1 << 63);
+                                    (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
                 if (summed) {
                     const size_t nBskh = Eh - Lh;
                     u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));

@@ -146,6 +146,10 @@ public:
     void profile_read(ProfStats *out, bool reset);
     // two-stream ComputePowers: -1 = default policy (on for one or two bundle indices), 0 = off, 1 = on
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
+    // test hook: copy one computed power to the host (serialised with the other calls on this context)
+    void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
+                        int *is_ntt);
+    int device() const { return device_; }
 
 private:
     // arena (bump allocator reset per top-level operation)
@@ -231,6 +235,7 @@ private:
     void prof_end();
     void prof_collect();
 
+    struct Enter;                     // lock + current-device guard taken by every public entry point
     friend struct EngineAccess;
     friend struct ProfScope;
 };

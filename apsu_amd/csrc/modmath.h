@@ -6,7 +6,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__ __forceinline__
 #else

@@ -239,6 +239,8 @@ class RefContext:
         nodes = np.array(dag_nodes, dtype=np.uint32)
         rkp = _p(rk) if rk is not None else None
         rc = lib().ref_compute_powers(self.h, ptrs, _vp(nodes), len(dag_nodes), rkp, C.c_uint32(ps_low_degree))
+        if rc == -3:
+            raise RuntimeError("ComputePowers needs ciphertext products but the parameters do not support relinearization")
         assert rc == 0
         high, low = self.clamp(1), self.clamp(2)
         out = {}
@@ -271,6 +273,8 @@ class RefContext:
             raise ValueError("not enough ciphertext powers available")
         if rc == -2:
             raise ValueError("ps_low_degree must be greater than 1 and less than the size of batched_coeffs")
+        if rc == -3:
+            raise RuntimeError("eval_patstock without key switching leaves a size-3 result (bin_bundle.cpp:238-240,308-310): not supported")
         return out
 
     def plain_chain_idx(self, ps_low_degree):

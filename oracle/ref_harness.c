@@ -182,7 +182,10 @@ void ref_batch_decode(const ref_ctx *c, const uint64_t *pt, uint64_t *values)
 }
 
 /* receiver/apsu/receiver_osn.cpp:53-73.  The reference computes the masks with `1 << len` on an int and shifts
- * uint64_t accumulators, which wrap; the odd-felt branch shifts the upper half by len/2 - 1 (sic). */
+ * uint64_t accumulators, which wrap; the odd-felt branch shifts the upper half by len/2 - 1 (sic).
+ * The masks are formed here with 64-bit shifts: identical to the reference's `int` arithmetic for every plain
+ * modulus below 2^31 (len <= 31), which covers all 36 shipped parameter sets (t < 2^27); for larger t the
+ * reference's `1 << len` is undefined behaviour on int and no value is pinned. */
 void ref_vec_to_oc_block(const uint64_t *in, size_t felts_per_item, uint64_t plain_modulus, uint64_t out[2])
 {
     uint32_t len = 1;

@@ -95,6 +95,9 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
     int first = c->first_chain_idx;
     int max_depth = 0;
     for (int i = 0; i < n_nodes; i++) if ((int)nodes[i].depth > max_depth) max_depth = (int)nodes[i].depth;
+    /* no key switching (one coefficient prime): the reference would carry size-3 products on (:427-432); the powers
+       here are size 2, so products are refused rather than truncated (no shipped parameter set needs them) */
+    if (max_depth > 0 && !c->using_keyswitching) return -3;
     /* parallel_apply visits a node once both parents are done; any topological order gives
        the same values.  Visit by depth. */
     /* the reference runs one task per DAG node on its thread pool (powers.h:158-278); nodes of equal depth
@@ -107,7 +110,7 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
             uint64_t *prod = powers[nd->power];
             if (nd->p1 == nd->p2) ref_square(c, powers[nd->p1], prod, first);            /* :422 */
             else ref_multiply(c, powers[nd->p1], powers[nd->p2], prod, first);           /* :424 */
-            if (c->using_keyswitching) ref_relinearize(c, prod, rk, first);              /* :431 */
+            ref_relinearize(c, prod, rk, first);                                         /* :431 */
         }
     }
     int high = ref_clamp_chain_idx(c, 1), low = ref_clamp_chain_idx(c, 2);                /* :451-454 */
@@ -177,6 +180,11 @@ int ref_eval_patstock(const ref_ctx *c, uint64_t *const *powers, int n_powers,
     if (n_powers < (n_coeffs > 2 ? n_coeffs : 2)) return -1;                              /* :204-206 */
     size_t degree = (size_t)n_coeffs - 1;
     if (ps_low_degree <= 1 || ps_low_degree >= degree) return -2;                         /* :209-213 */
+    /* Without key switching (one coefficient prime) the reference skips relinearize_inplace (:308-310) and its
+       result stays a size-3 ciphertext.  This restatement and the engine's ABI carry size-2 results (2*n words),
+       so that case is refused explicitly instead of dropping c2.  No shipped parameter set reaches it (every
+       single-prime set has ps_low_degree 0). */
+    if (!c->using_keyswitching) return -3;
     int high = ref_clamp_chain_idx(c, 1);                                                 /* :220 */
     int low = ref_plain_chain_idx(c, ps_low_degree);      /* level of low powers & NTT plaintexts */
     size_t n = c->n;
@@ -204,7 +212,7 @@ int ref_eval_patstock(const ref_ctx *c, uint64_t *const *powers, int n_powers,
         ref_multiply(c, temp_in, powers[i * h], prod, high);                              /* :272,301 */
         ref_add(c, result, prod, 3, high);                                                /* :273,303 */
     }
-    if (c->using_keyswitching) ref_relinearize(c, result, rk, high);                      /* :308-310 */
+    ref_relinearize(c, result, rk, high);                                                 /* :308-310 */
 
     for (size_t j = 1; j < h; j++) {                                                      /* :314-324 */
         const uint64_t *co = load_coeff(scratch, coeffs[j], ptw);

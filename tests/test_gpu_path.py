@@ -262,3 +262,96 @@ def test_fallback_paths_match():
         env = dict(os.environ, **{switch: value})
         r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, switch + "=" + value + "\n" + r.stdout + r.stderr
+
+
+def test_powers_outlive_their_context():
+    """apsu_he_powers_free after apsu_he_destroy (the Python binding's garbage collector does this routinely): the
+    context orphans its live powers handles, so the late free neither touches the destroyed context nor leaks"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [5]})
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pws = [G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk) for _ in range(3)]
+    pws[0] = None                                            # one goes back to the pool while the context is alive
+    G.close()
+    with pytest.raises(ValueError):                          # its buffers went with the context
+        pws[1].download(0, 1)
+    del pws                                                  # frees after destroy
+    G2 = apsu_amd.HeContext(js)                              # the library is still healthy
+    rk2 = G2.upload_relin_keys(S.rk)
+    pw = G2.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk2)
+    opw = common.oracle_powers(S)
+    assert (pw.download(0, 1)[0] == opw[0][1]).all()
+    G2.close()
+
+
+def test_single_prime_with_products_is_refused_not_truncated():
+    """K = 1 (no key switching): the reference would carry size-3 ciphertexts (receiver_osn.cpp:427-432,
+    bin_bundle.cpp:238-240,308-310); this interface returns size-2 results, so those combinations raise"""
+    js = common.toy_json(n=64, coeff_bits=(60,), plain_bits=14, ps_low=2, max_items=7, query_powers=(1, 2, 3, 6))
+    S = common.make_scenario(js, {0: [7]})
+    G = apsu_amd.HeContext(js)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], None)       # depth 0: every target is a source
+    b = S.bundles[0]
+    gb = G.upload_bundle(0, 0, b["coeffs"], b["flags"])
+    with pytest.raises(apsu_amd.ApsuHeError):                                  # eval_patstock would leave size 3
+        G.eval_bundles([gb], pw, None, [b["mask"]])
+    with pytest.raises(RuntimeError):
+        common.oracle_eval(S, common.oracle_powers(S), b)
+    G.close()
+    js2 = common.toy_json(n=64, coeff_bits=(60,), plain_bits=14, ps_low=0, max_items=4, query_powers=(1, 2))
+    S2 = common.make_scenario(js2, {0: []})
+    G2 = apsu_amd.HeContext(js2)
+    with pytest.raises(apsu_amd.ApsuHeError):                                  # products without relinearization
+        G2.compute_powers([0], [[S2.src[0][e] for e in S2.sources]], None)
+    with pytest.raises(RuntimeError):
+        common.oracle_powers(S2)
+    G2.close()
+
+
+def test_summed_finish_guard_uses_the_widest_limb():
+    """30-bit first prime next to 60-bit ones with 16 products per BinBundle: 16 * q_1 >= 2^64, so the summed-Bsk finish
+    (integer sums of per-term residues of EVERY limb) must not be taken; compared with the oracle's per-term order"""
+    js = common.toy_json(n=64, coeff_bits=(30, 60, 60, 40), plain_bits=14, ps_low=2, max_items=50, query_powers=(1, 3))
+    S = common.make_scenario(js, {0: [50, 49]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+    for p in S.targets:
+        assert (pw.download(0, p)[0] == opw[0][p]).all()
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    out = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
+    for i, b in enumerate(S.bundles):
+        assert (out[i] == common.oracle_eval(S, opw, b)).all()
+    G.close()
+
+
+def test_calls_from_a_thread_on_another_device():
+    """HIP's current device is per host thread: a worker thread of the reference's pool may have another device
+    current than the context's (several contexts on different GPUs in one process).  Needs two GPUs."""
+    import threading
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js, device=1)
+    res = {}
+
+    def worker():
+        torch.cuda.set_device(0)                             # this thread's current device is NOT the context's
+        rk = G.upload_relin_keys(S.rk)
+        pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+        b = S.bundles[0]
+        gb = G.upload_bundle(0, 0, b["coeffs"], b["flags"])
+        res["out"] = G.eval_bundles([gb], pw, rk, [b["mask"]])
+        res["dev"] = torch.cuda.current_device()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert res["dev"] == 0
+    assert (res["out"][0] == common.oracle_eval(S, opw, S.bundles[0])).all()
+    G.close()
