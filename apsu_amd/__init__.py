@@ -10,8 +10,10 @@ from .engine import (  # noqa: F401
     ApsuHeError,
     Bundle,
     HeContext,
+    MultiContext,
     Powers,
     RelinKeys,
     lib_path,
     load_library,
+    partition_bundles,
 )

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "engine.h"
+#include "multi.h"
 
 using namespace apsu_he;
 
@@ -21,6 +22,7 @@ struct apsu_he_ctx { std::unique_ptr<Engine> eng; std::unordered_set<apsu_he_pow
 struct apsu_he_relin { std::unique_ptr<RelinKeys> rk; };
 struct apsu_he_bundle { std::unique_ptr<Bundle> b; };
 struct apsu_he_powers { std::unique_ptr<Powers> p; apsu_he_ctx *ctx = nullptr; };
+struct apsu_he_multi { std::unique_ptr<MultiEngine> m; };
 static std::mutex g_registry_mu;      // guards every ctx::live_powers and powers::ctx (lock order: registry, then Engine)
 
 static thread_local std::string g_last_error;
@@ -223,6 +225,8 @@ int apsu_he_bundle_load(apsu_he_ctx *c, const uint8_t *buf, uint64_t size, apsu_
 }
 int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_two_stream(mode); }); }
+int apsu_he_set_eval_pipeline(apsu_he_ctx *c, int groups)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_eval_pipeline(groups); }); }
 int apsu_he_mask_generate(apsu_he_ctx *c, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks)
 { return guarded([&] { REQUIRE(c && (masks_dev || !count), "null argument"); c->eng->mask_generate(seed, count, masks_dev, values, blocks); }); }
 int apsu_he_decrypt_decode(apsu_he_ctx *c, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
@@ -287,6 +291,62 @@ int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, i
         for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); bs[i] = bundles[i]->b.get(); }
         c->eng->eval_bundles(bs.data(), count, *powers->p, rk ? rk->rk.get() : nullptr, masks, masks_on_device != 0, out,
                              out_on_device != 0);
+    });
+}
+
+// ---- several GPUs behind one handle (multi.h)
+int apsu_he_partition_bundles(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
+                              const uint32_t *degree, int count, int *device_slot)
+{
+    return guarded([&] {
+        REQUIRE(count >= 0 && (count == 0 || (bundle_idx && cache_idx && degree && device_slot)), "null argument");
+        std::vector<ShardUnit> u(count);
+        for (int i = 0; i < count; i++) u[i] = ShardUnit{ bundle_idx[i], cache_idx[i], degree[i] };
+        auto r = partition_units(u, bundle_idx_count, n_devices);
+        for (int i = 0; i < count; i++) device_slot[i] = r[i];
+    });
+}
+
+int apsu_he_multi_create(const char *json, const int *devices, int n_devices, apsu_he_multi **out)
+{
+    return guarded([&] {
+        REQUIRE(json && devices && out && n_devices > 0, "null argument");
+        PSUParams p = PSUParams::Load(json);
+        HeParams hp = HeParams::FromPSUParams(p);
+        auto m = new apsu_he_multi;
+        try { m->m = std::make_unique<MultiEngine>(hp, p, std::vector<int>(devices, devices + n_devices)); } catch (...) { delete m; throw; }
+        *out = m;
+    });
+}
+int apsu_he_multi_destroy(apsu_he_multi *m) { return guarded([&] { delete m; }); }
+int apsu_he_multi_device_count(const apsu_he_multi *m, int *n_devices)
+{ return guarded([&] { REQUIRE(m && n_devices, "null argument"); *n_devices = m->m->device_count(); }); }
+int apsu_he_multi_relin_upload(apsu_he_multi *m, const uint64_t *ksk)
+{ return guarded([&] { REQUIRE(m && ksk, "null argument"); m->m->upload_relin_keys(ksk); }); }
+int apsu_he_multi_db_upload_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                   const uint64_t *const *coeff_ptrs, const uint8_t *is_ntt, int *bundle_id)
+{
+    return guarded([&] {
+        REQUIRE(m && coeff_ptrs && is_ntt && bundle_id, "null argument");
+        REQUIRE(device_slot >= 0 && device_slot < m->m->device_count(), "device slot out of range");
+        *bundle_id = m->m->upload_bundle(device_slot, bundle_idx, cache_idx, n_coeffs, coeff_ptrs, is_ntt);
+    });
+}
+int apsu_he_multi_db_random_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree,
+                                   uint64_t seed, int *bundle_id)
+{
+    return guarded([&] {
+        REQUIRE(m && bundle_id, "null argument");
+        REQUIRE(device_slot >= 0 && device_slot < m->m->device_count(), "device slot out of range");
+        *bundle_id = m->m->random_bundle(device_slot, bundle_idx, cache_idx, degree, seed);
+    });
+}
+int apsu_he_multi_db_clear(apsu_he_multi *m) { return guarded([&] { REQUIRE(m, "null argument"); m->m->clear_bundles(); }); }
+int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts, int out_device_slot)
+{
+    return guarded([&] {
+        REQUIRE(m && src_cts && masks && out_cts, "null argument");
+        m->m->eval_all(src_cts, masks, out_cts, out_device_slot);
     });
 }
 

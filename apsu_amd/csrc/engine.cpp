@@ -82,6 +82,9 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
+        // the MAC stream carries the grid-filling, HBM-bound database scans of a pipelined evaluation: lowest priority,
+        // so the main stream's VALU-bound kernels are dispatched first whenever both have workgroups ready
+        HIP_CHECK(hipStreamCreateWithPriority(&st_mac_, hipStreamNonBlocking, least));
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
 
@@ -108,7 +111,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].ninv_q = hp_.ntt[m].ninv_q;
             tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
-            tabs[m].pad = 0;
+            ntt_fold_params(tabs[m].q, tabs[m].fold_k, tabs[m].fold_c);
+            tabs[m].fold_pad = 0;
             tabs[m].fwd = base + ((size_t)m * 3 + 0) * n;
             tabs[m].dit = base + ((size_t)m * 3 + 1) * n;
             tabs[m].scale = base + ((size_t)m * 3 + 2) * n;
@@ -245,6 +249,8 @@ Engine::~Engine()
     powers_pool_.clear();
     if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
     if (parked_.st) { (void)hipStreamSynchronize(parked_.st); (void)hipStreamDestroy(parked_.st); }
+    if (st_mac_) { (void)hipStreamSynchronize(st_mac_); (void)hipStreamDestroy(st_mac_); }
+    for (hipEvent_t e : mac_done_) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
 }
@@ -253,6 +259,7 @@ void Engine::sync()
 {
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipStreamSynchronize(parked_.st));
+    HIP_CHECK(hipStreamSynchronize(st_mac_));
     if (prof_on_) prof_collect();
 }
 
@@ -1501,16 +1508,6 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
 
             // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
             if (!ps_ids.empty()) {
-                const int Bs = (int)ps_ids.size();
-                // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
-                std::vector<int> nin(Bs), in_off(Bs);
-                int NI = 0;
-                for (int x = 0; x < Bs; x++) {
-                    const Bundle &b = *bundles[c0 + ps_ids[x]];
-                    nin[x] = (int)b.H - (b.r == 0 ? 1 : 0);
-                    in_off[x] = NI;
-                    NI += nin[x];
-                }
                 // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
                 // the sum (note N1).  With one dropped limb the sum of the rounded terms is
                 //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
@@ -1519,193 +1516,274 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
                 const bool need_vlast = i0_fast && low > high;
 
-                // Every dyadic multiply-accumulate of the evaluation reads only the query powers and the database, so
-                // all of them run as ONE launch, and their results share ONE inverse-NTT launch:
-                //   inner [NI][2][Ll]   sum_j C^j (.) a_{i*h+j}                                  :258-264
-                //   ssum  [Bs][2][Lh]   sum_j C^j (.) a_j on the limbs that survive the switch  (i = 0 block, fast form)
-                //   vlast [Bs*l][2][1]  C^j (.) a_j on the dropped limb, per term               (i = 0 block, fast form)
-                //   term  [Bs*l][2][Ll] C^j (.) a_j, per term                                   (i = 0 block, general form)
-                //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
-                const size_t w_inner = (size_t)NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
-                const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
-                // high powers still in flight on the second stream (split ComputePowers): everything that needs only the
-                // low powers goes first, the cf products wait for them
-                const bool late_high = pw.high_async && pw.high_ready;
-                const size_t w_cf = (size_t)Bs * 2 * Lh * n;
-                u64 *inner = ws(w_inner + w_ssum + w_vlast + w_term + (late_high ? 0 : w_cf));
-                u64 *ssum = inner + w_inner, *vlast = ssum + w_ssum, *term = vlast + w_vlast, *cf = late_high ? nullptr : term + w_term;
-                std::vector<MacStream> ms;
-                std::vector<int> imap;                                  // modulus of every limb polynomial of the merged block
-                auto map_push = [&](size_t polys, int first_limb, int limbs) {
-                    for (size_t p = 0; p < polys; p++) for (int j = 0; j < limbs; j++) imap.push_back(first_limb + j);
+                // Pipelining: the dyadic multiply-accumulate streams the database (HBM-bound) and needs only the low
+                // powers; everything behind it is VALU-bound (inverse NTTs, BEHZ products, key switch).  The BinBundles are
+                // cut into groups; group g+1's multiply-accumulate runs on the low-priority MAC stream while the main
+                // stream finishes group g.  Same kernels, same operands, same results; event profiling (whose timings
+                // are only meaningful without concurrency) uses one stream.
+                struct PsGroup {
+                    std::vector<int> ids;                               // positions in this chunk
+                    std::vector<int> nin, in_off;                       // inner polynomials per BinBundle, prefix offsets
+                    int NI = 0;
+                    u64 *inner = nullptr, *ssum = nullptr, *vlast = nullptr, *term = nullptr, *cf = nullptr;
+                    std::vector<int> imap;                              // modulus of every limb polynomial of the merged block
+                    const MacJob *mac_jobs = nullptr;
+                    int n_mac = 0;
+                    uint64_t units = 0;
                 };
-                for (int x = 0; x < Bs; x++) {
-                    const Bundle &b = *bundles[c0 + ps_ids[x]];
-                    const int bs = bslot[c0 + ps_ids[x]];
-                    for (int i = 1; i <= nin[x]; i++) {
-                        const u32 cnt = (u32)i < b.H ? l : b.r;
-                        ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
-                                                inner + ((size_t)in_off[x] + i - 1) * 2 * Ll * n, cnt,
-                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                std::vector<PsGroup> groups;
+                {
+                    std::vector<int> order = ps_ids;
+                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
+                    static const int pipe_env = [] { const char *v = std::getenv("APSU_HE_EVAL_PIPE"); return v ? atoi(v) : -1; }();
+                    int want = eval_pipe_mode_ >= 0 ? eval_pipe_mode_ : pipe_env;
+                    if (want < 0) want = 4;                             // default policy
+                    if (prof_on_ || want < 1) want = 1;
+                    // a group should still fill the machine: at least two BinBundles each
+                    const int G = std::max(1, std::min<int>(want, (int)order.size() / 2));
+                    uint64_t total = 0;
+                    for (int id : order) total += bundles[c0 + id]->degree + 1;
+                    groups.resize(G);
+                    uint64_t run = 0;
+                    for (int id : order) {
+                        int g = (int)std::min<uint64_t>((uint64_t)G - 1, run * G / std::max<uint64_t>(1, total));
+                        groups[g].ids.push_back(id);
+                        run += bundles[c0 + id]->degree + 1;
                     }
+                    groups.erase(std::remove_if(groups.begin(), groups.end(), [](const PsGroup &g) { return g.ids.empty(); }), groups.end());
                 }
-                map_push((size_t)NI * 2, 0, (int)Ll);
-                if (i0_fast) {
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + ps_ids[x]];
-                        ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + ps_ids[x]]), ssum + (size_t)x * 2 * Lh * n, l,
-                                                (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh });
-                    }
-                    map_push((size_t)Bs * 2, 0, (int)Lh);
-                }
-                if (need_vlast || !i0_fast) {
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + ps_ids[x]];
-                        const int bs = bslot[c0 + ps_ids[x]];
-                        for (u32 j = 1; j <= l; j++) {
-                            if (i0_fast)
-                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                        vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
-                                                        (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1 });
-                            else
-                                ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                        term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
-                                                        (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
-                        }
-                    }
-                    if (i0_fast) map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
-                    else map_push((size_t)Bs * l * 2, 0, (int)Ll);
-                }
-                auto cf_streams = [&](std::vector<MacStream> &out) {
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + ps_ids[x]];
-                        out.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + ps_ids[x]]), cf + (size_t)x * 2 * Lh * n, b.H, (u32)(Lh * n),
+                const bool piped = groups.size() > 1;
+                // high powers still in flight on the second stream (split ComputePowers), or pipelined groups: everything
+                // that needs only the low powers goes first, the cf products (which read the high powers) come later
+                const bool async_high = pw.high_async && pw.high_ready;
+                const bool late_high = async_high || piped;
+                auto cf_streams = [&](const PsGroup &g, std::vector<MacStream> &out) {
+                    for (size_t x = 0; x < g.ids.size(); x++) {
+                        const Bundle &b = *bundles[c0 + g.ids[x]];
+                        out.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H, (u32)(Lh * n),
                                                  (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh });
                     }
                 };
-                if (!late_high) { cf_streams(ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
-                // the level-`low` constants serve every limb: levels share their leading primes
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(low), (int)Ll, upload_jobs(mj), n, (int)mj.size(), st_); }
-                d_ntt(inner, imap.size(), upload_jobs(imap), (int)imap.size(), true);                       // :268,297,320,333
 
-                // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
-                // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
-                u64 *ext = ws((size_t)NI * 2 * Eh * n);
-                bool fused_drop = false;
-                if (low == high + 1) {
-                    PROF(P_BEHZ_EXT, 0);
-                    fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_);
-                }
-                if (!fused_drop) {
-                    u64 *innerh = inner;
-                    for (int lv = low; lv > high; lv--) {
-                        u64 *nxt = ws((size_t)NI * 2 * lv * n);
-                        { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
-                        innerh = nxt;
-                    }
-                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
-                }
-                d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
-                if (late_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
-                u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
-                // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
-                // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
-                // kernel and finished once per BinBundle (see behz_finish_coeff).  Bit-identical, 6 instead of 15
-                // inverse transforms per term at L = 2.
-                int max_terms = 0;
-                for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
-                static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
-                // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
-                u64 q_widest = 0;
-                for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
-                const bool summed = !force_per_term && Lh <= 4 &&
-                                    (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
-                if (summed) {
-                    const size_t nBskh = Eh - Lh;
-                    u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
-                    u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
-                    if (late_high) {                                    // the cf sums join this inverse-NTT launch
-                        cf = bsum + (size_t)Bs * 3 * nBskh * n;
-                        std::vector<MacStream> cs;
-                        cf_streams(cs);
-                        auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
-                    }
-                    std::vector<TensorSumJob> tj;
-                    std::vector<FinishSumJob> fj;
-                    std::vector<int> dmap;
+                // ---- phase A: workspace and the job array of every group's multiply-accumulate
+                for (PsGroup &g : groups) {
+                    const int Bs = (int)g.ids.size();
+                    // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
+                    g.nin.resize(Bs); g.in_off.resize(Bs);
                     for (int x = 0; x < Bs; x++) {
-                        if (!nin[x]) { HIP_CHECK(hipMemsetAsync(result + (size_t)x * 3 * Lh * n, 0, 3 * Lh * n * sizeof(u64), st_)); continue; }
-                        const size_t job = (size_t)in_off[x];
-                        tj.push_back(TensorSumJob{ ext + job * 2 * Eh * n, hext_ptr(1, bslot[c0 + ps_ids[x]]), dq + job * 3 * Lh * n,
-                                                   bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
-                        fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                        const Bundle &b = *bundles[c0 + g.ids[x]];
+                        g.nin[x] = (int)b.H - (b.r == 0 ? 1 : 0);
+                        g.in_off[x] = g.NI;
+                        g.NI += g.nin[x];
                     }
-                    for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
-                    for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i));
-                    if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
-                    { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
-                    d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
-                    { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
-                } else {
-                if (late_high) {
-                    cf = ws(w_cf);
-                    std::vector<MacStream> cs;
-                    cf_streams(cs);
-                    { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
-                    d_ntt_ct(cf, (size_t)Bs * 2, high, true);
-                }
-                u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
-                // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
-                // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
-                u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
-                std::vector<TensorJob> tj;
-                std::vector<FinishJob> fj;
-                std::vector<SumJob> sj;
-                for (int x = 0; x < Bs; x++) {
-                    const int bs = bslot[c0 + ps_ids[x]];
-                    for (int i = 1; i <= nin[x]; i++) {
-                        const size_t job = (size_t)in_off[x] + i - 1;
-                        tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
-                        fj.push_back(FinishJob{ dbuf + job * 3 * Eh * n, tbuf + job * 3 * Lh * n, 1, 0 });
+                    // Every dyadic multiply-accumulate of the evaluation reads only the query powers and the database, so
+                    // all of a group run as ONE launch, and their results share ONE inverse-NTT launch:
+                    //   inner [NI][2][Ll]   sum_j C^j (.) a_{i*h+j}                                  :258-264
+                    //   ssum  [Bs][2][Lh]   sum_j C^j (.) a_j on the limbs that survive the switch  (i = 0 block, fast form)
+                    //   vlast [Bs*l][2][1]  C^j (.) a_j on the dropped limb, per term               (i = 0 block, fast form)
+                    //   term  [Bs*l][2][Ll] C^j (.) a_j, per term                                   (i = 0 block, general form)
+                    //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
+                    const size_t w_inner = (size_t)g.NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
+                    const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
+                    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
+                    g.inner = ws(w_inner + w_ssum + w_vlast + w_term + (late_high ? 0 : w_cf));
+                    g.ssum = g.inner + w_inner; g.vlast = g.ssum + w_ssum; g.term = g.vlast + w_vlast;
+                    g.cf = late_high ? nullptr : g.term + w_term;
+                    std::vector<MacStream> ms;
+                    auto map_push = [&](size_t polys, int first_limb, int limbs) {
+                        for (size_t p = 0; p < polys; p++) for (int j = 0; j < limbs; j++) g.imap.push_back(first_limb + j);
+                    };
+                    for (int x = 0; x < Bs; x++) {
+                        const Bundle &b = *bundles[c0 + g.ids[x]];
+                        const int bs = bslot[c0 + g.ids[x]];
+                        for (int i = 1; i <= g.nin[x]; i++) {
+                            const u32 cnt = (u32)i < b.H ? l : b.r;
+                            ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
+                                                    g.inner + ((size_t)g.in_off[x] + i - 1) * 2 * Ll * n, cnt,
+                                                    (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                        }
                     }
-                    sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                    map_push((size_t)g.NI * 2, 0, (int)Ll);
+                    if (i0_fast) {
+                        for (int x = 0; x < Bs; x++) {
+                            const Bundle &b = *bundles[c0 + g.ids[x]];
+                            ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + g.ids[x]]), g.ssum + (size_t)x * 2 * Lh * n, l,
+                                                    (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh });
+                        }
+                        map_push((size_t)Bs * 2, 0, (int)Lh);
+                    }
+                    if (need_vlast || !i0_fast) {
+                        for (int x = 0; x < Bs; x++) {
+                            const Bundle &b = *bundles[c0 + g.ids[x]];
+                            const int bs = bslot[c0 + g.ids[x]];
+                            for (u32 j = 1; j <= l; j++) {
+                                if (i0_fast)
+                                    ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
+                                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1 });
+                                else
+                                    ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
+                                                            g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
+                                                            (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                            }
+                        }
+                        if (i0_fast) map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
+                        else map_push((size_t)Bs * l * 2, 0, (int)Ll);
+                    }
+                    if (!late_high) { cf_streams(g, ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
+                    auto mj = group_mac(ms);
+                    g.mac_jobs = upload_jobs(mj);
+                    g.n_mac = (int)mj.size();
+                    g.units = mac_units(mj);
                 }
-                { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
-                d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
-                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
-                { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
-                }
-                if (hp_.using_keyswitching) d_relinearize(result, 3 * Lh * n, Bs, *rk, high);              // :308-310
 
-                // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
-                u64 *i0 = nullptr;
-                if (i0_fast && low == high) {
-                    i0 = ssum;
-                } else if (i0_fast) {
-                    i0 = ws((size_t)Bs * 2 * Lh * n);
-                    std::vector<I0Job> ij;
+                // ---- the multiply-accumulates: in stream order on the MAC stream (pipelined) or on the main stream
+                // (the level-`low` constants serve every limb: levels share their leading primes)
+                if (piped) {
+                    if (mac_done_.size() < groups.size()) {
+                        const size_t old = mac_done_.size();
+                        mac_done_.resize(groups.size(), nullptr);
+                        for (size_t i = old; i < mac_done_.size(); i++) HIP_CHECK(hipEventCreateWithFlags(&mac_done_[i], hipEventDisableTiming));
+                    }
+                    // the MAC stream starts behind the low powers and the job arrays (main-stream order)
+                    HIP_CHECK(hipEventRecord(ev_main_, st_));
+                    HIP_CHECK(hipStreamWaitEvent(st_mac_, ev_main_, 0));
+                    for (size_t gi = 0; gi < groups.size(); gi++) {
+                        launch_mac(dlevel(low), (int)Ll, groups[gi].mac_jobs, n, groups[gi].n_mac, st_mac_);
+                        HIP_CHECK(hipEventRecord(mac_done_[gi], st_mac_));
+                    }
+                }
+
+                // ---- phase B per group: everything behind the multiply-accumulate
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    PsGroup &g = groups[gi];
+                    const int Bs = (int)g.ids.size(), NI = g.NI;
+                    const std::vector<int> &nin = g.nin, &in_off = g.in_off;
+                    u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
+                    if (piped) HIP_CHECK(hipStreamWaitEvent(st_, mac_done_[gi], 0));
+                    else { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_); }
+                    d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
+
+                    // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
+                    // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
+                    u64 *ext = ws((size_t)NI * 2 * Eh * n);
+                    bool fused_drop = false;
+                    if (low == high + 1) {
+                        PROF(P_BEHZ_EXT, 0);
+                        fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_);
+                    }
+                    if (!fused_drop) {
+                        u64 *innerh = inner;
+                        for (int lv = low; lv > high; lv--) {
+                            u64 *nxt = ws((size_t)NI * 2 * lv * n);
+                            { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
+                            innerh = nxt;
+                        }
+                        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+                    }
+                    d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
+                    if (async_high && gi == 0) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
+                    u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
+                    // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
+                    // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
+                    // kernel and finished once per BinBundle (see behz_finish_coeff).  Bit-identical, 6 instead of 15
+                    // inverse transforms per term at L = 2.
+                    int max_terms = 0;
+                    for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
+                    static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
+                    // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
+                    u64 q_widest = 0;
+                    for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
+                    const bool summed = !force_per_term && Lh <= 4 &&
+                                        (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
+                    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
+                    if (summed) {
+                        const size_t nBskh = Eh - Lh;
+                        u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
+                        u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
+                        if (late_high) {                                    // the cf sums join this inverse-NTT launch
+                            g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
+                            std::vector<MacStream> cs;
+                            cf_streams(g, cs);
+                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
+                        }
+                        std::vector<TensorSumJob> tj;
+                        std::vector<FinishSumJob> fj;
+                        std::vector<int> dmap;
+                        for (int x = 0; x < Bs; x++) {
+                            if (!nin[x]) { HIP_CHECK(hipMemsetAsync(result + (size_t)x * 3 * Lh * n, 0, 3 * Lh * n * sizeof(u64), st_)); continue; }
+                            const size_t job = (size_t)in_off[x];
+                            tj.push_back(TensorSumJob{ ext + job * 2 * Eh * n, hext_ptr(1, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n,
+                                                       bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
+                            fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                        }
+                        for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
+                        for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i));
+                        if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
+                        { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
+                        d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
+                        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
+                    } else {
+                        if (late_high) {
+                            g.cf = ws(w_cf);
+                            std::vector<MacStream> cs;
+                            cf_streams(g, cs);
+                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
+                            d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
+                        }
+                        u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
+                        // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
+                        // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
+                        u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
+                        std::vector<TensorJob> tj;
+                        std::vector<FinishJob> fj;
+                        std::vector<SumJob> sj;
+                        for (int x = 0; x < Bs; x++) {
+                            const int bs = bslot[c0 + g.ids[x]];
+                            for (int i = 1; i <= nin[x]; i++) {
+                                const size_t job = (size_t)in_off[x] + i - 1;
+                                tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
+                                fj.push_back(FinishJob{ dbuf + job * 3 * Eh * n, tbuf + job * 3 * Lh * n, 1, 0 });
+                            }
+                            sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+                        }
+                        if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
+                        d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
+                        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
+                        { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
+                    }
+                    d_relinearize(result, 3 * Lh * n, Bs, *rk, high);                                          // :308-310
+
+                    // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
+                    u64 *i0 = nullptr;
+                    if (i0_fast && low == high) {
+                        i0 = ssum;
+                    } else if (i0_fast) {
+                        i0 = ws((size_t)Bs * 2 * Lh * n);
+                        std::vector<I0Job> ij;
+                        for (int x = 0; x < Bs; x++)
+                            ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
+                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
+                    } else {
+                        u64 *termh = term;
+                        for (int lv = low; lv > high; lv--) {
+                            u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
+                            { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
+                            termh = nxt;
+                        }
+                        i0 = ws((size_t)Bs * 2 * Lh * n);
+                        HIP_CHECK(hipMemsetAsync(i0, 0, (size_t)Bs * 2 * Lh * n * sizeof(u64), st_));
+                        { PROF(P_OTHER, 0); launch_add_many(dlevel(high), i0, 2 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
+                    }
+
+                    // :340-343 the two exact addends, :345 add_plain(a_0), :346 add_plain(mask), :354-356 mod switch to the last
+                    // level, :357 clear bits — one pass over the result
+                    std::vector<EpiJob> ej;
                     for (int x = 0; x < Bs; x++)
-                        ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
-                    { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
-                } else {
-                    u64 *termh = term;
-                    for (int lv = low; lv > high; lv--) {
-                        u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
-                        { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
-                        termh = nxt;
-                    }
-                    i0 = ws((size_t)Bs * 2 * Lh * n);
-                    HIP_CHECK(hipMemsetAsync(i0, 0, (size_t)Bs * 2 * Lh * n * sizeof(u64), st_));
-                    { PROF(P_OTHER, 0); launch_add_many(dlevel(high), i0, 2 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
+                        ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
+                                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res + (size_t)g.ids[x] * 2 * n });
+                    { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
                 }
-
-                // :340-343 the two exact addends, :345 add_plain(a_0), :346 add_plain(mask), :354-356 mod switch to the last
-                // level, :357 clear bits — one pass over the result
-                std::vector<EpiJob> ej;
-                for (int x = 0; x < Bs; x++)
-                    ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, cf + (size_t)x * 2 * Lh * n,
-                                         bundles[c0 + ps_ids[x]]->a0.u(), mask_ptr(ps_ids[x]), res + (size_t)ps_ids[x] * 2 * n });
-                { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
             }
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             sync();

@@ -146,6 +146,9 @@ public:
     void profile_read(ProfStats *out, bool reset);
     // two-stream ComputePowers: -1 = default policy (on for one or two bundle indices), 0 = off, 1 = on
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
+    // pipelined evaluation: -1 = default policy, 0 or 1 = one stream, n > 1 = up to n groups of BinBundles whose database
+    // scans run on the MAC stream next to the previous group's VALU-bound tail
+    void set_eval_pipeline(int groups) { std::lock_guard<std::mutex> g(mu_); eval_pipe_mode_ = groups < 0 ? -1 : groups; }
     // test hook: copy one computed power to the host (serialised with the other calls on this context)
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
                         int *is_ntt);
@@ -192,6 +195,9 @@ private:
     int cur_lane_ = 0, overflow_lane_ = 0;
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
+    hipStream_t st_mac_ = nullptr;    // low-priority stream of the pipelined evaluation's database scans
+    std::vector<hipEvent_t> mac_done_;
+    int eval_pipe_mode_ = -1;         // -1 default policy, 0/1 off, n > 1: groups
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
     // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the

@@ -60,12 +60,24 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
             dit[k] = { t.dit[k], t.dit_q[k] }; sc[k] = { t.scale[k], t.scale_q[k] };
         }
         NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), dit.data(), sc.data(),
-                      ntt_is_narrow(q, logn) ? 1 : 0, 0 };
+                      ntt_is_narrow(q, logn) ? 1 : 0, 0, 0, 0 };
+        ntt_fold_params(q, tab.fold_k, tab.fold_c);
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
         switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// ntt_reduce_any (the fold / Barrett final reduction of the NTT kernels) on explicit values; returns fold_k
+int emu_reduce_any(uint64_t q, const uint64_t *x, uint64_t *out, int count)
+{
+    ModulusInfo m(q);
+    NttTable tab{};
+    tab.q = q; tab.r1 = m.ratio[1];
+    ntt_fold_params(q, tab.fold_k, tab.fold_c);
+    for (int i = 0; i < count; i++) out[i] = ntt_reduce_any(x[i], tab);
+    return (int)tab.fold_k;
 }
 
 // PSUParams::Load + HeParams: returns derived numbers for comparison with the oracle

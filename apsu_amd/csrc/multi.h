@@ -1,0 +1,73 @@
+// Several GPUs of one node behind one handle: the in-process counterpart of Receiver::RunQuery's fan-out of BinBundle
+// tasks (receiver/apsu/receiver_osn.cpp:320-364).  One Engine per device, one persistent host thread per device;
+// BinBundles are the sharded unit: devices are assigned to bundle indices first, an index's BinBundles
+// are split over its devices by cost ~ degree (longest-processing-time greedy); every device computes the powers of
+// its own indices only, and the only data exchange of a query is the final gather of the fixed-size results.
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "engine.h"
+#include "sharding.h"
+
+namespace apsu_he {
+
+class MultiEngine {
+public:
+    MultiEngine(const HeParams &hp, const PSUParams &psu, const std::vector<int> &devices);
+    ~MultiEngine();
+    MultiEngine(const MultiEngine &) = delete;
+    MultiEngine &operator=(const MultiEngine &) = delete;
+
+    int device_count() const { return (int)devs_.size(); }
+    Engine &engine(int slot) { return *devs_.at(slot)->eng; }
+    const PSUParams &psu() const { return psu_; }
+    const HeParams &he() const { return hp_; }
+
+    void upload_relin_keys(const u64 *ksk);                      // replicated on every device
+    // DB placement: the bundle's id is its registration order (= its row in eval_all's output)
+    int upload_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs, const u64 *const *coeff_ptrs,
+                      const unsigned char *is_ntt);
+    int random_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed);
+    int bundle_count() const { return (int)where_.size(); }
+    int bundle_device(int id) const { return where_.at(id).first; }
+    void clear_bundles();
+
+    // One query.  src_cts[b * source_count + s]: host ciphertexts of every bundle index (each device reads its own);
+    // masks[id]: n words mod t (host); out: bundle_count * 2n words, row = bundle id — host memory when
+    // out_slot < 0, else device memory on devices[out_slot] (gathered with peer copies over xGMI).
+    void eval_all(const u64 *const *src_cts, const u64 *const *masks, u64 *out, int out_slot);
+
+private:
+    struct Dev {
+        int device = 0;
+        std::unique_ptr<Engine> eng;
+        std::unique_ptr<RelinKeys> rk;
+        std::vector<std::unique_ptr<Bundle>> bundles;
+        std::vector<int> ids;                                     // global id of bundles[i]
+        DevBuf out;                                               // [bundles][2n] results of this device
+        void *host_out = nullptr;                                 // pinned staging of the same size
+        size_t host_out_bytes = 0;
+        // worker
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has_job = false, done = false, quit = false;
+        std::exception_ptr error;
+    };
+    void run_all(const std::function<void(Dev &)> &fn);
+    static void worker(Dev *d);
+
+    HeParams hp_;
+    PSUParams psu_;
+    std::vector<std::unique_ptr<Dev>> devs_;
+    std::vector<std::pair<int, int>> where_;                      // id -> (slot, local position)
+    std::mutex mu_;                                               // one query / placement call at a time
+};
+
+} // namespace apsu_he

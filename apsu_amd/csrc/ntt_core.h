@@ -43,10 +43,40 @@ struct NttTable {
     const TwPair *dit;                 // dit[g + j] = psi^(-j*n/g), j < g, g = 1,2,4,..,n/2
     const TwPair *scale;               // scale[j] = n^-1 * psi^-j
     int narrow;                        // (4*logn+1)*q < 2^64
-    int pad;
+    // q = 2^k - c with a small c (every prime SEAL's search returns is of this shape: it scans downwards from 2^k in
+    // steps of 2n).  Then any 64-bit x reduces with ONE narrow multiply: x = (x >> k) * c + (x mod 2^k)  (mod q), which is
+    // below 2q when (2^(64-k) + 2) * c <= 2^k.  fold_k = 0: not available (small or unstructured moduli), Barrett is used.
+    u32 fold_k, fold_c, fold_pad;
 };
 
 HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
+
+// fold parameters of q (k = 0 when the fold reduction does not apply)
+HD void ntt_fold_params(u64 q, u32 &k, u32 &c)
+{
+    int bits = 0;
+    while (bits < 64 && (q >> bits)) bits++;
+    k = 0; c = 0;
+    if (bits < 33 || bits > 62) return;
+    const u64 cc = ((u64)1 << bits) - q;
+    if (cc >> 32) return;
+    if ((unsigned __int128)((((u64)1) << (64 - bits)) + 2) * cc > ((unsigned __int128)1 << bits)) return;
+    k = (u32)bits; c = (u32)cc;
+}
+
+// canonical residue of ANY 64-bit x
+HD u64 ntt_reduce_any(u64 x, const NttTable &tab)
+{
+    if (tab.fold_k) {                                            // wave-uniform
+        const u32 sh = tab.fold_k - 32;
+        const u32 hi = (u32)(x >> 32);
+        const u64 low = ((u64)(hi & ((1u << sh) - 1)) << 32) | (u32)x;
+        const u64 v = (u64)(hi >> sh) * tab.fold_c + low;        // < 2q
+        return v >= tab.q ? v - tab.q : v;
+    }
+    const u64 v = x - mulhi64(x, tab.r1) * tab.q;
+    return v >= tab.q ? v - tab.q : v;
+}
 
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
 // makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).
@@ -156,10 +186,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const u64 v = r[g][j] - mulhi64(r[g][j], tab.r1) * q;
-                r[g][j] = csub(v, q);
-            }
+            for (int j = 0; j < R; j++) r[g][j] = ntt_reduce_any(r[g][j], tab);
     }
 
 #pragma unroll
@@ -211,7 +238,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 if (INV) {
                     const u64x2 sv = ldg16(reinterpret_cast<const u64 *>(tab.scale + idx(g, j)));
                     v = mul_shoup(v, sv[0], sv[1], q);
-                } else { v = v - mulhi64(v, tab.r1) * q; v = csub(v, q); }       // any 64-bit v
+                } else v = ntt_reduce_any(v, tab);
                 r[g][j] = v;
             }
     }
@@ -251,8 +278,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 template <bool NARROW>
 HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 {
-    v = v - mulhi64(v, tab.r1) * tab.q;                           // any 64-bit v (wide moduli leave values up to 2^64 - 1)
-    return csub(v, tab.q);
+    return ntt_reduce_any(v, tab);                                // any 64-bit v (wide moduli leave values up to 2^64 - 1)
 }
 
 // ---- pass schedule (stage counts per pass, summing to LOGN), resolved at compile time ----

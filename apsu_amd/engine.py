@@ -327,6 +327,10 @@ class HeContext:
         """-1 default policy, 0 off, 1 on: ComputePowers' high-power chain on a second stream"""
         _check(load_library().apsu_he_set_two_stream(self.h, int(mode)))
 
+    def set_eval_pipeline(self, groups):
+        """-1 default policy, 0/1 off, n > 1: up to n BinBundle groups whose database scans overlap the previous group's tail"""
+        _check(load_library().apsu_he_set_eval_pipeline(self.h, int(groups)))
+
     def mask_generate(self, seed, count, masks_dev, want_values=True, want_blocks=True):
         """N4: `count` random masks (receiver_osn.cpp:217-284).  masks_dev: device pointer to count*n words receiving the
         encoded plaintexts.  -> (values [count][n] or None, blocks [count][items_per_bundle][2] (low, high) or None)"""
@@ -388,4 +392,80 @@ class HeContext:
         _check(load_library().apsu_he_eval_bundles(self.h, hs, count, powers.h, rk.h if rk is not None else None,
                                                    _ptr_array(list(masks)), 1 if masks_on_device else 0, outp,
                                                    1 if out_on_device else 0))
+        return out
+
+
+def partition_bundles(units, bundle_idx_count, n_devices):
+    """apsu_he_partition_bundles: units [(bundle_idx, cache_idx, degree)] -> device slot per unit (no GPU needed)"""
+    cnt = len(units)
+    b = np.array([u[0] for u in units], dtype=np.uint32)
+    c = np.array([u[1] for u in units], dtype=np.uint32)
+    d = np.array([u[2] for u in units], dtype=np.uint32)
+    out = np.zeros(max(cnt, 1), dtype=np.int32)
+    _check(load_library().apsu_he_partition_bundles(C.c_uint32(bundle_idx_count), int(n_devices), C.c_void_p(b.ctypes.data),
+                                                    C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data), cnt,
+                                                    C.c_void_p(out.ctypes.data)))
+    return [int(x) for x in out[:cnt]]
+
+
+class MultiContext:
+    """Several GPUs of one node behind one handle (include/apsu_he.h: apsu_he_multi_*, apsu_he_eval_all): the
+    in-process counterpart of Receiver::RunQuery's fan-out (receiver/apsu/receiver_osn.cpp:320-364)."""
+
+    def __init__(self, psu_params_json, devices):
+        L = load_library()
+        if os.path.exists(psu_params_json):
+            with open(psu_params_json) as f:
+                psu_params_json = f.read()
+        dv = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(L.apsu_he_multi_create(psu_params_json.encode(), dv, len(devices), C.byref(h)))
+        self.h = h
+        self.devices = list(devices)
+        self.n_bundles = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().apsu_he_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_relin_keys(self, rk):
+        _check(load_library().apsu_he_multi_relin_upload(self.h, _p(np.ascontiguousarray(rk))))
+
+    def upload_bundle(self, slot, bundle_idx, cache_idx, coeffs, is_ntt):
+        flags = (C.c_uint8 * len(coeffs))(*[1 if f else 0 for f in is_ntt])
+        keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in coeffs]
+        bid = C.c_int()
+        _check(load_library().apsu_he_multi_db_upload_bundle(self.h, int(slot), bundle_idx, cache_idx, len(keep), _ptr_array(keep),
+                                                             flags, C.byref(bid)))
+        self.n_bundles = max(self.n_bundles, bid.value + 1)
+        return bid.value
+
+    def random_bundle(self, slot, bundle_idx, cache_idx, degree, seed):
+        bid = C.c_int()
+        _check(load_library().apsu_he_multi_db_random_bundle(self.h, int(slot), bundle_idx, cache_idx, degree, C.c_uint64(seed),
+                                                             C.byref(bid)))
+        self.n_bundles = max(self.n_bundles, bid.value + 1)
+        return bid.value
+
+    def clear_bundles(self):
+        _check(load_library().apsu_he_multi_db_clear(self.h))
+        self.n_bundles = 0
+
+    def eval_all(self, sources, masks, n, out_device_slot=-1, out_ptr=None):
+        """sources: flat list [bundle_idx][source] of host cts; masks: per bundle id.  -> [n_bundles][2][1][n] (host) or
+        writes to the device pointer out_ptr on devices[out_device_slot]"""
+        if out_device_slot < 0:
+            out = np.zeros((self.n_bundles, 2, 1, n), dtype=np.uint64)
+            outp = _p(out)
+        else:
+            out = None
+            outp = C.c_void_p(int(out_ptr))
+        _check(load_library().apsu_he_eval_all(self.h, _ptr_array(list(sources)), _ptr_array(list(masks)), outp, int(out_device_slot)))
         return out

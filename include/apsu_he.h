@@ -178,11 +178,48 @@ int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles,
                          const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out_cts,
                          int out_on_device);
 
+/* ---- several GPUs of one node behind one handle ------------------------------------------------------------------
+ * The in-process counterpart of Receiver::RunQuery's fan-out (receiver/apsu/receiver_osn.cpp:320-364: ComputePowers per
+ * bundle index, then one ProcessBinBundleCache task per BinBundle on the thread pool).  One engine and one host thread per
+ * device; the BinBundle is the sharded unit: devices are assigned to bundle indices first (a device then needs the
+ * powers of few indices only), an index's BinBundles are split over its devices by cost ~ degree.  A query's only data
+ * exchange is the final gather of the fixed-size results.  Devices may repeat (e.g. {0, 0}) to rehearse
+ * the multi-device path on one GPU.  (bench.py's one-process-per-GPU launch uses the same partition rule and RCCL.) */
+typedef struct apsu_he_multi apsu_he_multi;
+/* the partition rule alone (no GPU needed): device slot of each BinBundle (bundle_idx, cache_idx, degree) */
+int apsu_he_partition_bundles(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
+                              const uint32_t *degree, int count, int *device_slot);
+int apsu_he_multi_create(const char *psu_params_json, const int *devices, int n_devices, apsu_he_multi **out);
+int apsu_he_multi_destroy(apsu_he_multi *m);
+int apsu_he_multi_device_count(const apsu_he_multi *m, int *n_devices);
+/* the query's RelinKeys, replicated on every device (layout as apsu_he_relin_upload) */
+int apsu_he_multi_relin_upload(apsu_he_multi *m, const uint64_t *ksk);
+/* DB placement (ReceiverDB::generate_caches, receiver_db.cpp:808-820): as apsu_he_db_upload_bundle / _random_bundle on the
+ * device in `device_slot` (take it from apsu_he_partition_bundles).  *bundle_id = registration order = the BinBundle's
+ * row in apsu_he_eval_all's masks and output. */
+int apsu_he_multi_db_upload_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                   const uint64_t *const *coeff_ptrs, const uint8_t *is_ntt, int *bundle_id);
+int apsu_he_multi_db_random_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree,
+                                   uint64_t seed, int *bundle_id);
+int apsu_he_multi_db_clear(apsu_he_multi *m);
+/* One query on all devices (receiver_osn.cpp:304-364): src_cts[b * source_power_count + s] = host ciphertext of source
+ * power s (ascending) of bundle index b, for EVERY bundle index (each device uploads the ones it needs); masks[id] = n
+ * words mod t (host).  out_cts: bundle count * 2n words, row = bundle id; host memory when out_device_slot < 0, else
+ * device memory on that device (rows gathered with peer copies over xGMI). */
+int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts,
+                     int out_device_slot);
+
 /* Scheduling option: ComputePowers may walk the high-power half of the PowersDag on a second HIP stream, next to the
  * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on for calls
  * with one or two bundle indices), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1 sets the default for
  * contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
 int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
+
+/* Scheduling option of apsu_he_eval_bundles: the BinBundles of a call are cut into up to `groups` groups; a group's
+ * database scan (the dyadic multiply-accumulate, HBM-bound, needs only the low powers) runs on a low-priority stream
+ * while the main stream finishes the previous group's VALU-bound tail (inverse NTTs, ct x ct products, key switch).
+ * Same kernels, operands and results.  groups: -1 = default policy, 0 or 1 = off; APSU_HE_EVAL_PIPE sets the default. */
+int apsu_he_set_eval_pipeline(apsu_he_ctx *ctx, int groups);
 
 /* ---- measurement hooks (replace the reference's STOPWATCH timers, receiver_osn.cpp:167,403,504) ----
  * Per-kernel-class device time from HIP events recorded on the engine's stream around each launch.

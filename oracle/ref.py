@@ -268,7 +268,7 @@ class RefContext:
     def eval_patstock(self, powers, coeffs, ps_low_degree, rk, mask):
         out = np.empty((2, 1, self.n), dtype=np.uint64)
         rc = lib().ref_eval_patstock(self.h, self._ptr_array(powers), len(powers), self._ptr_array(coeffs),
-                                     len(coeffs), C.c_uint32(ps_low_degree), _p(rk), _p(mask), _p(out))
+                                     len(coeffs), C.c_uint32(ps_low_degree), _p(rk) if rk is not None else None, _p(mask), _p(out))
         if rc == -1:
             raise ValueError("not enough ciphertext powers available")
         if rc == -2:

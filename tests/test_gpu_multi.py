@@ -1,0 +1,71 @@
+"""GPU tier: several devices behind one handle (apsu_he_multi_*, apsu_he_eval_all) — the in-process counterpart of
+Receiver::RunQuery's fan-out (receiver/apsu/receiver_osn.cpp:320-364).  Runs with one device ({0}), with the same device
+twice ({0, 0}: the multi-device code path — partition, per-device powers, gather — on one GPU), and with two distinct
+GPUs when the box has them; every result must equal the single-context evaluation bit for bit."""
+import numpy as np
+import pytest
+
+import apsu_amd
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def device_sets():
+    import torch
+    sets = [[0], [0, 0], [0, 0, 0]]
+    if torch.cuda.device_count() >= 2:
+        sets += [[0, 1], [1, 0]]
+    return sets
+
+
+@pytest.mark.parametrize("cfg", ["toy", "1M-1024-com"])
+def test_eval_all_equals_single_context(cfg):
+    import torch
+    if cfg == "toy":
+        js, degrees = common.toy_json(), {0: [11, 10, 3, 8], 1: [7, 2, 11]}
+    else:
+        js, degrees = common.param_json("1M-1024-com"), {0: [124, 30], 1: [124, 5, 77]}
+    S = common.make_scenario(js, degrees)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    want = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
+    opw = common.oracle_powers(S)
+    for i, b in enumerate(S.bundles):
+        assert (want[i] == common.oracle_eval(S, opw, b)).all()
+    nidx = S.p["bundle_idx_count"]
+    # sources for EVERY bundle index (indices without BinBundles are never read)
+    flat = []
+    for b in range(nidx):
+        for e in S.sources:
+            flat.append(S.src[b][e] if b in S.src else S.src[S.bundle_indices[0]][e])
+    units = [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+    for devs in device_sets():
+        M = apsu_amd.MultiContext(js, devs)
+        M.upload_relin_keys(S.rk)
+        slots = apsu_amd.partition_bundles(units, nidx, len(devs))
+        ids = [M.upload_bundle(slots[i], b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for i, b in enumerate(S.bundles)]
+        assert ids == list(range(len(S.bundles)))
+        masks = [b["mask"] for b in S.bundles]
+        for _ in range(2):                                        # twice: pooled buffers, steady state
+            got = M.eval_all(flat, masks, G.n)
+            assert (got == want).all(), devs
+        # gathered onto the first device
+        out_d = torch.zeros((len(ids), 2, G.n), dtype=torch.int64, device="cuda:%d" % devs[0])
+        M.eval_all(flat, masks, G.n, out_device_slot=0, out_ptr=out_d.data_ptr())
+        torch.cuda.synchronize()
+        assert (out_d.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all(), devs
+        M.close()
+    G.close()
+
+
+def test_multi_rejects_bad_devices_and_slots():
+    js = common.toy_json()
+    with pytest.raises(ValueError):
+        apsu_amd.MultiContext(js, [99])
+    M = apsu_amd.MultiContext(js, [0])
+    with pytest.raises(ValueError):
+        M.random_bundle(3, 0, 0, 5, 1)
+    M.close()

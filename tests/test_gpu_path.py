@@ -288,7 +288,7 @@ def test_powers_outlive_their_context():
 def test_single_prime_with_products_is_refused_not_truncated():
     """K = 1 (no key switching): the reference would carry size-3 ciphertexts (receiver_osn.cpp:427-432,
     bin_bundle.cpp:238-240,308-310); this interface returns size-2 results, so those combinations raise"""
-    js = common.toy_json(n=64, coeff_bits=(60,), plain_bits=14, ps_low=2, max_items=7, query_powers=(1, 2, 3, 6))
+    js = common.toy_json(n=64, coeff_bits=(60,), plain_bits=17, ps_low=2, max_items=7, query_powers=(1, 2, 3, 6))
     S = common.make_scenario(js, {0: [7]})
     G = apsu_amd.HeContext(js)
     pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], None)       # depth 0: every target is a source
@@ -299,7 +299,7 @@ def test_single_prime_with_products_is_refused_not_truncated():
     with pytest.raises(RuntimeError):
         common.oracle_eval(S, common.oracle_powers(S), b)
     G.close()
-    js2 = common.toy_json(n=64, coeff_bits=(60,), plain_bits=14, ps_low=0, max_items=4, query_powers=(1, 2))
+    js2 = common.toy_json(n=64, coeff_bits=(60,), plain_bits=17, ps_low=0, max_items=4, query_powers=(1, 2))
     S2 = common.make_scenario(js2, {0: []})
     G2 = apsu_amd.HeContext(js2)
     with pytest.raises(apsu_amd.ApsuHeError):                                  # products without relinearization
@@ -312,7 +312,7 @@ def test_single_prime_with_products_is_refused_not_truncated():
 def test_summed_finish_guard_uses_the_widest_limb():
     """30-bit first prime next to 60-bit ones with 16 products per BinBundle: 16 * q_1 >= 2^64, so the summed-Bsk finish
     (integer sums of per-term residues of EVERY limb) must not be taken; compared with the oracle's per-term order"""
-    js = common.toy_json(n=64, coeff_bits=(30, 60, 60, 40), plain_bits=14, ps_low=2, max_items=50, query_powers=(1, 3))
+    js = common.toy_json(n=64, coeff_bits=(30, 60, 60, 40), plain_bits=17, ps_low=2, max_items=50, query_powers=(1, 3))
     S = common.make_scenario(js, {0: [50, 49]})
     opw = common.oracle_powers(S)
     G = apsu_amd.HeContext(js)

@@ -215,3 +215,59 @@ def test_product_does_not_reference_oracle():
                     assert not re.search(r"^\s*(import|from|#include)|cdll|dlopen|-lapsu_he_ref", low), (f, line)
     ldd = subprocess.check_output(["ldd", os.path.join(ROOT, "apsu_amd", "libapsu_he_gpu.so")]).decode()
     assert "apsu_he_ref" not in ldd
+
+
+def test_partition_rule_of_the_c_abi_matches_the_bench_sharding():
+    """apsu_he_partition_bundles (C++, used by apsu_he_eval_all's callers) and apsu_amd/sharding.py (used by the
+    one-process-per-GPU bench) are the same rule"""
+    import apsu_amd
+    from apsu_amd.sharding import partition
+    rng = np.random.default_rng(7)
+    cases = [([(b, ci, 1303 if ci < 6 else 170) for b in range(4) for ci in range(7)], 4)]
+    for _ in range(40):
+        nb = int(rng.integers(1, 9))
+        units = [(int(rng.integers(0, nb)), ci, int(rng.integers(0, 4000))) for ci in range(int(rng.integers(0, 60)))]
+        cases.append((units, nb))
+    for units, nb in cases:
+        for world in (1, 2, 3, 4, 8):
+            slots = apsu_amd.partition_bundles(units, nb, world)
+            assign = partition(units, nb, world)
+            want = {}
+            for r, us in assign.items():
+                for u in us:
+                    want.setdefault(u, []).append(r)
+            # duplicates of an identical unit may swap places; compare as multisets per unit
+            got = {}
+            for u, s in zip(units, slots):
+                got.setdefault(u, []).append(s)
+            assert {k: sorted(v) for k, v in got.items()} == {k: sorted(v) for k, v in want.items()}, (nb, world)
+    with pytest.raises(ValueError):
+        apsu_amd.partition_bundles([(5, 0, 1)], 4, 2)
+
+
+def test_ntt_final_reduction_fold_and_barrett(emu):
+    """ntt_reduce_any: x mod q for ANY 64-bit x.  Primes of the shape 2^k - c (all of SEAL's coefficient and BEHZ primes
+    of 33 bits and more) take the one-multiply fold, the others Barrett; both against Python integers, extremes included"""
+    primes = set()
+    for name in ALL_PARAM_FILES:
+        Cx = ref.RefContext.from_params(ref.load_params(common.param_json(name)))
+        primes.update(Cx.q)
+        primes.update([Cx.m_sk, Cx.gamma] + list(Cx.B))
+        primes.add(Cx.t)
+    rng = np.random.default_rng(11)
+    folded = 0
+    for q in sorted(primes):
+        k = q.bit_length()
+        xs = [0, 1, q - 1, q, q + 1, 2 * q - 1, 2 * q, (1 << 64) - 1, (1 << 63), (1 << k) - 1, 1 << k, (1 << 64) - q, (1 << 32) - 1, 1 << 32]
+        xs += [int(v) for v in rng.integers(0, 1 << 63, 200, dtype=np.uint64)]
+        xs += [int(v) | (1 << 63) for v in rng.integers(0, 1 << 63, 200, dtype=np.uint64)]
+        x = np.array([v & ((1 << 64) - 1) for v in xs], dtype=np.uint64)
+        out = np.zeros_like(x)
+        fk = emu.emu_reduce_any(C.c_uint64(q), x.ctypes.data_as(u64p), out.ctypes.data_as(u64p), len(x))
+        assert [int(v) for v in out] == [int(v) % q for v in x], hex(q)
+        if fk:
+            folded += 1
+            assert fk == k
+    assert folded >= 10                                           # the 48..61-bit primes do take the fold
+    assert emu.emu_reduce_any(C.c_uint64(0xfffffffff70001), x.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 1) == 56
+    assert emu.emu_reduce_any(C.c_uint64(0x3e4001), x.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 1) == 0
