@@ -2,12 +2,14 @@
 // codes the way the reference's callers expect to see SEAL's exceptions.
 #include "../../include/apsu_he.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "engine.h"
 #include "multi.h"
+#include "wire.h"
 
 using namespace apsu_he;
 
@@ -347,6 +349,175 @@ int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uin
     return guarded([&] {
         REQUIRE(m && src_cts && masks && out_cts, "null argument");
         m->m->eval_all(src_cts, masks, out_cts, out_device_slot);
+    });
+}
+
+// ---- N3: network framing (wire.h); host only
+struct apsu_he_wire_query { wire::QueryRequest q; };
+static int wire_out(std::vector<uint8_t> &&v, uint8_t **out, size_t *out_size)
+{
+    uint8_t *p = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    if (!p) throw std::bad_alloc();
+    if (!v.empty()) std::memcpy(p, v.data(), v.size());
+    *out = p; *out_size = v.size();
+    return 0;
+}
+int apsu_he_wire_buffer_free(uint8_t *p) { std::free(p); return APSU_HE_OK; }
+int apsu_he_wire_build_header(uint32_t version, uint32_t type, uint8_t **out, size_t *out_size)
+{ return guarded([&] { REQUIRE(out && out_size, "null argument"); wire_out(wire::build_header(wire::Header{ version, type }), out, out_size); }); }
+int apsu_he_wire_parse_header(const uint8_t *buf, size_t size, uint32_t *version, uint32_t *type)
+{
+    return guarded([&] {
+        REQUIRE(buf && version && type, "null argument");
+        const wire::Header h = wire::parse_header(buf, size);
+        *version = h.version; *type = h.type;
+    });
+}
+int apsu_he_wire_build_query_request(uint8_t compression_type, const uint8_t *relin_keys, size_t relin_keys_size, uint32_t n_parts,
+                                     const uint32_t *exponents, const uint32_t *cts_per_part, const uint8_t *const *ct_data,
+                                     const size_t *ct_sizes, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(out && out_size && (n_parts == 0 || (exponents && cts_per_part)), "null argument");
+        wire::QueryRequest q;
+        q.compression_type = compression_type;
+        q.has_relin_keys = relin_keys != nullptr;
+        q.relin_keys = wire::Span{ relin_keys, relin_keys_size };
+        size_t k = 0;
+        for (uint32_t i = 0; i < n_parts; i++) {
+            wire::QueryPart part;
+            part.exponent = exponents[i];
+            for (uint32_t j = 0; j < cts_per_part[i]; j++, k++) {
+                REQUIRE(ct_data && ct_sizes && (ct_data[k] || !ct_sizes[k]), "null ciphertext");
+                part.cts.push_back(wire::Span{ ct_data[k], ct_sizes[k] });
+            }
+            q.parts.push_back(std::move(part));
+        }
+        wire_out(wire::build_query_request(q), out, out_size);
+    });
+}
+int apsu_he_wire_parse_query_request(const uint8_t *buf, size_t size, apsu_he_wire_query **out)
+{
+    return guarded([&] {
+        REQUIRE(buf && out, "null argument");
+        auto m = new apsu_he_wire_query;
+        try { m->q = wire::parse_query_request(buf, size); } catch (...) { delete m; throw; }
+        *out = m;
+    });
+}
+int apsu_he_wire_query_free(apsu_he_wire_query *m) { return guarded([&] { delete m; }); }
+int apsu_he_wire_query_info(const apsu_he_wire_query *m, uint8_t *compression_type, int *has_relin_keys, const uint8_t **relin_keys,
+                            size_t *relin_keys_size, uint32_t *n_parts)
+{
+    return guarded([&] {
+        REQUIRE(m, "null argument");
+        if (compression_type) *compression_type = m->q.compression_type;
+        if (has_relin_keys) *has_relin_keys = m->q.has_relin_keys ? 1 : 0;
+        if (relin_keys) *relin_keys = m->q.relin_keys.p;
+        if (relin_keys_size) *relin_keys_size = m->q.relin_keys.n;
+        if (n_parts) *n_parts = (uint32_t)m->q.parts.size();
+    });
+}
+int apsu_he_wire_query_part(const apsu_he_wire_query *m, uint32_t part, uint32_t *exponent, uint32_t *n_cts)
+{
+    return guarded([&] {
+        REQUIRE(m && part < m->q.parts.size(), "part out of range");
+        if (exponent) *exponent = m->q.parts[part].exponent;
+        if (n_cts) *n_cts = (uint32_t)m->q.parts[part].cts.size();
+    });
+}
+int apsu_he_wire_query_ct(const apsu_he_wire_query *m, uint32_t part, uint32_t ct, const uint8_t **data, size_t *size)
+{
+    return guarded([&] {
+        REQUIRE(m && data && size && part < m->q.parts.size() && ct < m->q.parts[part].cts.size(), "index out of range");
+        *data = m->q.parts[part].cts[ct].p; *size = m->q.parts[part].cts[ct].n;
+    });
+}
+int apsu_he_wire_build_query_response(uint32_t package_count, uint32_t alpha_max_cache_count, uint8_t **out, size_t *out_size)
+{ return guarded([&] { REQUIRE(out && out_size, "null argument"); wire_out(wire::build_query_response(wire::QueryResponse{ package_count, alpha_max_cache_count }), out, out_size); }); }
+int apsu_he_wire_parse_query_response(const uint8_t *buf, size_t size, uint32_t *package_count, uint32_t *alpha_max_cache_count)
+{
+    return guarded([&] {
+        REQUIRE(buf && package_count && alpha_max_cache_count, "null argument");
+        const wire::QueryResponse r = wire::parse_query_response(buf, size);
+        *package_count = r.package_count; *alpha_max_cache_count = r.alpha_max_cache_count;
+    });
+}
+int apsu_he_wire_build_result_package(uint32_t bundle_idx, uint32_t cache_idx, const uint8_t *psu_result, size_t psu_result_size,
+                                      uint32_t label_byte_count, uint32_t nonce_byte_count, uint32_t n_labels,
+                                      const uint8_t *const *label_data, const size_t *label_sizes, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(out && out_size && (psu_result || !psu_result_size), "null argument");
+        wire::ResultPackage p;
+        p.bundle_idx = bundle_idx; p.cache_idx = cache_idx; p.psu_result = wire::Span{ psu_result, psu_result_size };
+        p.label_byte_count = label_byte_count; p.nonce_byte_count = nonce_byte_count;
+        for (uint32_t i = 0; i < n_labels; i++) {
+            REQUIRE(label_data && label_sizes, "null label");
+            p.label_result.push_back(wire::Span{ label_data[i], label_sizes[i] });
+        }
+        wire_out(wire::build_result_package(p), out, out_size);
+    });
+}
+int apsu_he_wire_parse_result_package(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint32_t *cache_idx, const uint8_t **psu_result,
+                                      size_t *psu_result_size, uint32_t *label_byte_count, uint32_t *nonce_byte_count, uint32_t *n_labels)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        const wire::ResultPackage p = wire::parse_result_package(buf, size);
+        if (bundle_idx) *bundle_idx = p.bundle_idx;
+        if (cache_idx) *cache_idx = p.cache_idx;
+        if (psu_result) *psu_result = p.psu_result.p;
+        if (psu_result_size) *psu_result_size = p.psu_result.n;
+        if (label_byte_count) *label_byte_count = p.label_byte_count;
+        if (nonce_byte_count) *nonce_byte_count = p.nonce_byte_count;
+        if (n_labels) *n_labels = (uint32_t)p.label_result.size();
+    });
+}
+int apsu_he_wire_result_label(const uint8_t *buf, size_t size, uint32_t index, const uint8_t **data, size_t *data_size)
+{
+    return guarded([&] {
+        REQUIRE(buf && data && data_size, "null argument");
+        const wire::ResultPackage p = wire::parse_result_package(buf, size);
+        REQUIRE(index < p.label_result.size(), "label index out of range");
+        *data = p.label_result[index].p; *data_size = p.label_result[index].n;
+    });
+}
+int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
+                              uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,
+                              int version_major, int version_minor, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(parms_id && data && out && out_size, "null argument");
+        wire::SealCt ct;
+        for (int i = 0; i < 4; i++) ct.parms_id[i] = parms_id[i];
+        ct.is_ntt_form = is_ntt_form ? 1 : 0; ct.size = ct_size; ct.poly_modulus_degree = poly_modulus_degree;
+        ct.coeff_modulus_size = coeff_modulus_size; ct.correction_factor = correction_factor; ct.scale = scale; ct.data = data;
+        wire_out(wire::seal_envelope_save(ct, (uint8_t)version_major, (uint8_t)version_minor), out, out_size);
+    });
+}
+int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id[4], int *is_ntt_form, uint64_t *ct_size,
+                              uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, uint64_t *correction_factor, double *scale,
+                              uint64_t *data, size_t data_capacity_words, int *version_major, int *version_minor)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        uint8_t maj = 0, mn = 0;
+        const wire::SealCt ct = wire::seal_envelope_load(buf, size, &maj, &mn);
+        const uint64_t words = ct.size * ct.coeff_modulus_size * ct.poly_modulus_degree;
+        if (parms_id) for (int i = 0; i < 4; i++) parms_id[i] = ct.parms_id[i];
+        if (is_ntt_form) *is_ntt_form = ct.is_ntt_form;
+        if (ct_size) *ct_size = ct.size;
+        if (poly_modulus_degree) *poly_modulus_degree = ct.poly_modulus_degree;
+        if (coeff_modulus_size) *coeff_modulus_size = ct.coeff_modulus_size;
+        if (correction_factor) *correction_factor = ct.correction_factor;
+        if (scale) *scale = ct.scale;
+        if (version_major) *version_major = maj;
+        if (version_minor) *version_minor = mn;
+        if (data) {
+            REQUIRE(data_capacity_words >= words, "output buffer too small");
+            std::memcpy(data, ct.data, words * sizeof(uint64_t));
+        }
     });
 }
 

@@ -82,9 +82,14 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
-        // the MAC stream carries the grid-filling, HBM-bound database scans of a pipelined evaluation: lowest priority,
-        // so the main stream's VALU-bound kernels are dispatched first whenever both have workgroups ready
-        HIP_CHECK(hipStreamCreateWithPriority(&st_mac_, hipStreamNonBlocking, least));
+        // the MAC stream carries the grid-filling, HBM-bound database scans of a pipelined evaluation
+        // (APSU_HE_MAC_PRIO = low | normal | high selects its dispatch priority for experiments; default low)
+        int mac_prio = least;
+        if (const char *v = std::getenv("APSU_HE_MAC_PRIO")) {
+            if (v[0] == 'h') mac_prio = greatest;
+            else if (v[0] == 'n') mac_prio = (least + greatest) / 2;
+        }
+        HIP_CHECK(hipStreamCreateWithPriority(&st_mac_, hipStreamNonBlocking, mac_prio));
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
 
@@ -1537,7 +1542,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
                     static const int pipe_env = [] { const char *v = std::getenv("APSU_HE_EVAL_PIPE"); return v ? atoi(v) : -1; }();
                     int want = eval_pipe_mode_ >= 0 ? eval_pipe_mode_ : pipe_env;
-                    if (want < 0) want = 4;                             // default policy
+                    if (want < 0) want = 1;                             // default policy: one stream (measured slower when on)
                     if (prof_on_ || want < 1) want = 1;
                     // a group should still fill the machine: at least two BinBundles each
                     const int G = std::max(1, std::min<int>(want, (int)order.size() / 2));

@@ -290,14 +290,19 @@ def main():
         ctx.profile_enable(0)
         result["roofline"]["process_avg_launch_us"] = round(proc_ntt["ms"] * 1e3 / max(1, proc_ntt["launches"]), 2)
         result["roofline"]["process_launches"] = proc_ntt["launches"]
+        # `traffic` (HBM bytes per launch from the PMC counters) cannot be measured inside this process: it comes from separate
+        # rocprofv3 --pmc passes of this same command.  The line carries the figure of the latest committed pass, labelled so.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_ntt_traffic.json")) as f:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_ntt_traffic.json"))
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
                 tr = json.load(f)
             if tr.get("n") == n:
                 per_launch = result["roofline"]["limb_transforms_per_step"] / max(1e-9, result["roofline"]["launches_per_step"])
                 result["roofline"]["traffic"] = int(tr["hbm_bytes_per_limb"] * per_launch)
-                result["roofline"]["traffic_source"] = "profiles/r01_ntt_traffic.json (rocprofv3 PMC passes, FETCH_SIZE x2 corrected)"
-        except OSError:
+                result["roofline"]["traffic_carried_from"] = ("profiles/%s: FETCH_SIZE / WRITE_SIZE rocprofv3 --pmc passes of this bench "
+                                                              "command (FETCH_SIZE x2, gfx950), bytes per limb transform x limb "
+                                                              "transforms per launch of this run; not measured in this run" % cands[-1])
+        except (OSError, IndexError, KeyError, ValueError):
             pass
 
     # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
@@ -317,9 +322,13 @@ def main():
 
 
 def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host, unit_pos, out_dev, n, t):
-    """Times the CPU restatement (oracle/, the reference's op order, 1 thread) on a bounded sample
-    of the SAME workload: ComputePowers for one bundle index + eval of one full BinBundle, and
-    checks the GPU result of that BinBundle bit-for-bit."""
+    """The reference CPU path, MEASURED on this box's host cores over the WHOLE query (no extrapolation):
+    the CPU restatement (oracle/) executes the reference's call sequence with the reference's task granularity —
+    ComputePowers per bundle index in sequence, one task per PowersDag node inside it (receiver_osn.cpp:320-328,
+    powers.h:158-278), then one task per BinBundle on a pool of T threads (receiver_osn.cpp:334-364, the CLI's `-t`).
+    Timed at T = every host core of this process (nproc stated) and at T = 1; every BinBundle's GPU result is compared
+    bit for bit with the CPU's.  The synthetic DB is rebuilt on the host beforehand (not timed)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import ref
     p = ref.load_params(params_json)
     C = ref.RefContext.from_params(p)
@@ -327,66 +336,66 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
     targets = ref.create_powers_set(ps, p["max_items_per_bin"])
     _, nodes = ref.powers_dag(p["query_powers"], targets)
     sources = sorted(p["query_powers"])
-    # sample: every bundle index of this rank (up to 4) once through ComputePowers, and the first BinBundle of each
-    idx_list = sorted({u[0] for u in mine})[:4]
     pci = C.plain_chain_idx(ps)
-    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    powers_ms_all, bundle_ms_all, powers_ms_t, bit_exact, deg0 = [], [], None, True, None
-    for b0 in idx_list:
-        pos = next(i for i, u in enumerate(mine) if u[0] == b0)
-        _, ci0, deg = mine[pos]
-        srcs = {e: np.ascontiguousarray(src_host[b0, s]) for s, e in enumerate(sources)}
-        ref.set_threads(1)
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    idx_list = sorted({u[0] for u in mine})
+
+    # ---- host replica of the synthetic BinBundles (DB build: not timed); ctypes calls release the GIL
+    t_db = time.perf_counter()
+    ref.set_threads(1)
+
+    def make_coeff(args):
+        seed, d = args
+        raw = splitmix_values(seed, d, n, t)
+        return C.plain_lift_ntt(raw, pci) if ref.coeff_is_ntt(ps, d) else raw
+
+    db = {}
+    with ThreadPoolExecutor(nproc) as ex:
+        for (b0, ci0, deg) in mine:
+            seed = SEED0 + 1000003 * b0 + 7919 * ci0
+            db[(b0, ci0)] = list(ex.map(make_coeff, [(seed, d) for d in range(deg + 1)], chunksize=16))
+    t_db = time.perf_counter() - t_db
+
+    def run_query(T):
+        ref.set_threads(T)
         t0 = time.perf_counter()
-        pw = C.compute_powers(srcs, nodes, rk_host, ps)
-        powers_ms_all.append((time.perf_counter() - t0) * 1e3)
-        # the reference's thread pool (-t): one task per DAG node; BinBundles are one task each (receiver_osn.cpp:334-364)
-        if powers_ms_t is None:
-            powers_ms_t = powers_ms_all[0]
-            if threads > 1:
-                ref.set_threads(threads)
-                t0 = time.perf_counter()
-                C.compute_powers(srcs, nodes, rk_host, ps)
-                powers_ms_t = (time.perf_counter() - t0) * 1e3
-                ref.set_threads(1)
-        # host replica of the synthetic BinBundle (DB build: not timed)
-        seed = SEED0 + 1000003 * b0 + 7919 * ci0
-        coeffs = []
-        for d in range(deg + 1):
-            raw = splitmix_values(seed, d, n, t)
-            coeffs.append(C.plain_lift_ntt(raw, pci) if ref.coeff_is_ntt(ps, d) else raw)
-        plist = [None] * (p["max_items_per_bin"] + 1)
-        for k, v in pw.items():
-            plist[k] = v
-        mask = np.ascontiguousarray(mask_host[unit_pos[(b0, ci0)]])
-        t0 = time.perf_counter()
-        if ps > 1 and ps < deg:
-            exp = C.eval_patstock(plist, coeffs, ps, rk_host, mask)
-        else:
-            exp = C.eval(plist, coeffs, plist[1].shape[1] - 1, mask)
-        ms = (time.perf_counter() - t0) * 1e3
-        if deg0 is None or deg == deg0:
-            deg0 = deg if deg0 is None else deg0
-            bundle_ms_all.append(ms)
-        got = out_dev[pos].cpu().numpy().view(np.uint64).reshape(2, 1, n)
-        bit_exact = bit_exact and bool((got == exp).all())
-    powers_ms = sum(powers_ms_all) / len(powers_ms_all)
-    bundle_ms = sum(bundle_ms_all) / len(bundle_ms_all)
-    # extrapolate to the whole query: powers once per bundle index, bundles by degree
-    nb = len({u[0] for u in units})
-    full = powers_ms * nb + sum(bundle_ms * (u[2] / deg0) for u in units)
-    return {"value": round(full, 1), "unit": "ms", "cores": 1, "kind": "port",
-            "sample": "ComputePowers for %d of %d bundle indices (%.0f ms each) + eval of %d BinBundles of degree %d (%.0f ms each), "
-                      "%.1f s of CPU work; whole query extrapolated = %d x powers + sum over %d BinBundles scaled by degree; CPU "
-                      "restatement of SEAL (oracle/), not Microsoft SEAL"
-                      % (len(idx_list), nb, powers_ms, len(bundle_ms_all), deg0, bundle_ms,
-                         (sum(powers_ms_all) + sum(bundle_ms_all)) / 1e3, nb, len(units)),
-            "powers_ms_per_bundle_idx": round(powers_ms, 1), "bundle_ms": round(bundle_ms, 1),
-            "threads_probe": {"threads": threads, "powers_ms_per_bundle_idx": round(powers_ms_t, 1),
-                              "query_ms_estimate": round(powers_ms_t * nb + -(-len(units) // threads) * bundle_ms, 1),
-                              "note": "ComputePowers measured with one OpenMP task per DAG node; BinBundle tasks are independent "
-                                      "single-thread jobs, so their wall time is ceil(#BinBundles / threads) x bundle_ms (estimate)"},
-            "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(idx_list)}
+        plists = {}
+        for b0 in idx_list:                                            # :320-328, sequential over bundle indices
+            srcs = {e: np.ascontiguousarray(src_host[b0, s]) for s, e in enumerate(sources)}
+            pw = C.compute_powers(srcs, nodes, rk_host, ps)            # T threads over the DAG nodes of a level
+            plist = [None] * (p["max_items_per_bin"] + 1)
+            for k, v in pw.items():
+                plist[k] = v
+            plists[b0] = plist
+        t_pw = time.perf_counter() - t0
+        ref.set_threads(1)                                             # BinBundle tasks are single-threaded jobs
+
+        def eval_one(u):
+            b0, ci0, deg = u
+            plist, coeffs = plists[b0], db[(b0, ci0)]
+            mask = np.ascontiguousarray(mask_host[unit_pos[(b0, ci0)]])
+            if ps > 1 and ps < deg:
+                return C.eval_patstock(plist, coeffs, ps, rk_host, mask)
+            return C.eval(plist, coeffs, plist[1].shape[1] - 1, mask)
+
+        with ThreadPoolExecutor(T) as ex:                              # :334-364, one task per BinBundle
+            res = list(ex.map(eval_one, mine))
+        return (time.perf_counter() - t0) * 1e3, t_pw * 1e3, res
+
+    ms_all, pw_all, res = run_query(nproc)
+    gpu = out_dev[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
+    bit_exact = all(bool((gpu[i] == res[i]).all()) for i in range(len(mine)))
+    ms_one, pw_one, _ = run_query(1) if nproc > 1 else (ms_all, pw_all, None)
+    return {"value": round(ms_all, 1), "unit": "ms", "cores": nproc, "kind": "port",
+            "sample": "the whole query, measured: ComputePowers for %d bundle indices + %d BinBundles (%d of degree %d), thread pool "
+                      "of %d = every host core of this process; CPU restatement of SEAL (oracle/, plain C, no AVX / lazy NTT), "
+                      "not Microsoft SEAL" % (len(idx_list), len(mine), sum(1 for u in mine if u[2] == max(x[2] for x in mine)),
+                                                max(x[2] for x in mine), nproc),
+            "compute_powers_ms": round(pw_all, 1),
+            "single_thread": {"value": round(ms_one, 1), "unit": "ms", "cores": 1, "compute_powers_ms": round(pw_one, 1),
+                              "note": "the same whole query on one thread, measured"},
+            "host_db_build_s": round(t_db, 1),
+            "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(mine)}
 
 
 if __name__ == "__main__":

@@ -221,6 +221,57 @@ int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
  * Same kernels, operands and results.  groups: -1 = default policy, 0 or 1 = off; APSU_HE_EVAL_PIPE sets the default. */
 int apsu_he_set_eval_pipeline(apsu_he_ctx *ctx, int groups);
 
+/* ---- "next" row N3: the network framing around the path, without flatc / flatbuffers / SEAL -----------------
+ * What the reference pins is the FlatBuffers framing of its messages; these functions read and write it:
+ *   ReceiverOperationHeader                   common/apsu/network/rop_header.fbs ; receiver_operation.cpp:27-87
+ *   ReceiverOperation{QueryRequest}           common/apsu/network/rop.fbs        ; receiver_operation.cpp:180-350
+ *   ReceiverOperationResponse{QueryResponse}  common/apsu/network/rop_response.fbs
+ *   ResultPackage                             common/apsu/network/result_package.fbs ; result_package.cpp:29-150
+ * All buffers are size-prefixed (FinishSizePrefixed), exactly what ZMQChannel / StreamChannel carry.  The byte vectors
+ * inside (Ciphertext.data, QueryRequest.relin_keys) are SEAL's own serialisation (seal_object.h:161-219); the reference
+ * does not pin that format, so they are passed through as opaque byte ranges.  Parsers verify every offset, length and
+ * alignment before use (like flatbuffers::Verifier) and fail with the reference's messages; returned pointers point INTO
+ * the caller's buffer.  Builders return a malloc'ed buffer to release with apsu_he_wire_buffer_free.
+ * ReceiverOperationType: 0 unknown, 1 parms, 2 oprf, 3 query, 4 response. */
+typedef struct apsu_he_wire_query apsu_he_wire_query;
+int apsu_he_wire_buffer_free(uint8_t *p);
+int apsu_he_wire_build_header(uint32_t version, uint32_t type, uint8_t **out, size_t *out_size);
+int apsu_he_wire_parse_header(const uint8_t *buf, size_t size, uint32_t *version, uint32_t *type);
+/* ReceiverOperationQuery::save (receiver_operation.cpp:180-247): part i holds cts_per_part[i] ciphertext blobs, taken in
+ * order from ct_data / ct_sizes; relin_keys NULL = field absent. */
+int apsu_he_wire_build_query_request(uint8_t compression_type, const uint8_t *relin_keys, size_t relin_keys_size, uint32_t n_parts,
+                                     const uint32_t *exponents, const uint32_t *cts_per_part, const uint8_t *const *ct_data,
+                                     const size_t *ct_sizes, uint8_t **out, size_t *out_size);
+/* ReceiverOperationQuery::load (receiver_operation.cpp:249-350): "unexpected operation type", "unsupported compression
+ * mode", "invalid query data" (duplicate exponent) as in the reference */
+int apsu_he_wire_parse_query_request(const uint8_t *buf, size_t size, apsu_he_wire_query **out);
+int apsu_he_wire_query_free(apsu_he_wire_query *q);
+int apsu_he_wire_query_info(const apsu_he_wire_query *q, uint8_t *compression_type, int *has_relin_keys, const uint8_t **relin_keys,
+                            size_t *relin_keys_size, uint32_t *n_parts);
+int apsu_he_wire_query_part(const apsu_he_wire_query *q, uint32_t part, uint32_t *exponent, uint32_t *n_cts);
+int apsu_he_wire_query_ct(const apsu_he_wire_query *q, uint32_t part, uint32_t ct, const uint8_t **data, size_t *size);
+int apsu_he_wire_build_query_response(uint32_t package_count, uint32_t alpha_max_cache_count, uint8_t **out, size_t *out_size);
+int apsu_he_wire_parse_query_response(const uint8_t *buf, size_t size, uint32_t *package_count, uint32_t *alpha_max_cache_count);
+/* ResultPackage::save / load (result_package.cpp:29-150) */
+int apsu_he_wire_build_result_package(uint32_t bundle_idx, uint32_t cache_idx, const uint8_t *psu_result, size_t psu_result_size,
+                                      uint32_t label_byte_count, uint32_t nonce_byte_count, uint32_t n_labels,
+                                      const uint8_t *const *label_data, const size_t *label_sizes, uint8_t **out, size_t *out_size);
+int apsu_he_wire_parse_result_package(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint32_t *cache_idx,
+                                      const uint8_t **psu_result, size_t *psu_result_size, uint32_t *label_byte_count,
+                                      uint32_t *nonce_byte_count, uint32_t *n_labels);
+int apsu_he_wire_result_label(const uint8_t *buf, size_t size, uint32_t index, const uint8_t **data, size_t *data_size);
+/* UNPINNED — SEAL's uncompressed (compr_mode::none) Ciphertext envelope restated from memory of upstream SEAL
+ * (SURVEY App. B11): 16-byte header {0xA15E, 0x10, version, compr_mode, reserved, total size}, parms_id (4 words, opaque
+ * here: SEAL derives it by hashing the encryption parameters), is_ntt_form, size, poly_modulus_degree,
+ * coeff_modulus_size, correction_factor (SEAL >= 4), scale, then the coefficient array as a nested object.  Nothing in the
+ * reference or this image can confirm it; seeded and compressed ciphertexts are rejected. */
+int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
+                              uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,
+                              int version_major, int version_minor, uint8_t **out, size_t *out_size);
+int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id[4], int *is_ntt_form, uint64_t *ct_size,
+                              uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, uint64_t *correction_factor, double *scale,
+                              uint64_t *data, size_t data_capacity_words, int *version_major, int *version_minor);
+
 /* ---- measurement hooks (replace the reference's STOPWATCH timers, receiver_osn.cpp:167,403,504) ----
  * Per-kernel-class device time from HIP events recorded on the engine's stream around each launch.
  * Classes (index): 0 ntt_fwd, 1 ntt_inv, 2 dyadic_mac, 3 behz_ext, 4 behz_tensor, 5 behz_finish,
