@@ -117,7 +117,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
             ntt_fold_params(tabs[m].q, tabs[m].fold_k, tabs[m].fold_c);
-            tabs[m].fold_pad = 0;
+            tabs[m].wide_d4 = ntt_wide_d4(tabs[m].q, tabs[m].narrow != 0);
             tabs[m].fwd = base + ((size_t)m * 3 + 0) * n;
             tabs[m].dit = base + ((size_t)m * 3 + 1) * n;
             tabs[m].scale = base + ((size_t)m * 3 + 2) * n;
@@ -1050,15 +1050,13 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
 
     struct LaneGuard { Engine *e; ~LaneGuard() { e->switch_lane(0); } } lane_guard{ this };
     // Two-stream walk: the high-power half of the DAG runs on the second stream next to the low-power half and to the
-    // BinBundle inner products.  Measured per rank on 16M-4096 (tools/rank_cost.py): 0.95 -> 0.86 ms with one bundle
-    // index and 3-4 BinBundles, 1.18 -> 1.11 with 7, 1.97 -> 1.91 with two indices, 3.84 -> 3.61 with all four.  Default:
-    // on for one or two bundle indices (the shards of a multi-GPU run, where launches do not fill the machine), off for
-    // larger batches, where per-kernel timings are the evidence and stop being additive under concurrency (DESIGN.md
-    // section 5); APSU_HE_SPLIT=0/1 forces it.  Event profiling always takes the one-stream walk: a launch bracketed
-    // by events next to another stream's kernels measures the sharing, not the kernel.
+    // BinBundle inner products.  Measured on 16M-4096 (tools/pipe_sweep.py, tools/rank_cost.py): 3.84 ->
+    // 3.65 ms for the whole query (four bundle indices), 0.95 -> 0.86 ms per rank with one bundle index.  Default: on
+    // whenever the PowersDag splits; APSU_HE_SPLIT=0/1 or apsu_he_set_two_stream force it.  Event profiling always takes
+    // the one-stream walk: a launch bracketed by events next to another stream's kernels measures the sharing, not the kernel.
     static const int split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
     const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : split_env;                  // API override, then environment
-    const bool split = split_ok_ && on_device && !prof_on_ && (split_mode < 0 ? nb <= 2 : split_mode == 1);   // host inputs end with a sync anyway
+    const bool split = split_ok_ && on_device && !prof_on_ && (split_mode < 0 || split_mode == 1);   // host inputs end with a sync anyway
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
     WITH_ARENA({

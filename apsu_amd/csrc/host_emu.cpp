@@ -15,28 +15,29 @@
 
 using namespace apsu_he;
 
-template <int LOGN, bool INV, bool NARROW, int PASS> static void emu_pass(u64 *lds, u64 *glob, int T, const NttTable &tab)
+template <int LOGN, bool INV, int MODE, int PASS> static void emu_pass(u64 *lds, u64 *glob, int T, const NttTable &tab)
 {
     if constexpr (PASS < plan_passes(LOGN)) {
         // in-place global reads/writes of a pass touch disjoint 16-coefficient sets per work item, so
         // stepping the threads sequentially is equivalent to the barrier-separated parallel execution
-        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, NARROW, PASS>(lds, glob, tid, T, tab);
-        emu_pass<LOGN, INV, NARROW, PASS + 1>(lds, glob, T, tab);
+        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, MODE, PASS>(lds, glob, tid, T, tab);
+        emu_pass<LOGN, INV, MODE, PASS + 1>(lds, glob, T, tab);
     }
 }
 
-template <int LOGN, bool INV, bool NARROW> static void emu_ntt_n(u64 *data, const NttTable &tab, int T)
+template <int LOGN, bool INV, int MODE> static void emu_ntt_n(u64 *data, const NttTable &tab, int T)
 {
     constexpr int N = 1 << LOGN;
     std::vector<u64> lds(lds_slots(N));
-    emu_pass<LOGN, INV, NARROW, 0>(lds.data(), data, T, tab);
-    if (!INV) for (int e = 0; e < N; e++) data[e] = ntt_fwd_finish<NARROW>(lds[lds_slot(e)], tab);
+    emu_pass<LOGN, INV, MODE, 0>(lds.data(), data, T, tab);
+    if (!INV) for (int e = 0; e < N; e++) data[e] = ntt_fwd_finish<MODE>(lds[lds_slot(e)], tab);
 }
 
 template <int LOGN, bool INV> static void emu_ntt(u64 *data, const NttTable &tab, int T)
 {
-    if (tab.narrow) emu_ntt_n<LOGN, INV, true>(data, tab, T);
-    else emu_ntt_n<LOGN, INV, false>(data, tab, T);
+    if (tab.narrow) emu_ntt_n<LOGN, INV, NTT_NARROW>(data, tab, T);
+    else if (tab.wide_d4) emu_ntt_n<LOGN, INV, NTT_WIDE_NEAR>(data, tab, T);
+    else emu_ntt_n<LOGN, INV, NTT_WIDE>(data, tab, T);
 }
 
 static thread_local std::string g_err;
@@ -62,6 +63,7 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
         NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), dit.data(), sc.data(),
                       ntt_is_narrow(q, logn) ? 1 : 0, 0, 0, 0 };
         ntt_fold_params(q, tab.fold_k, tab.fold_c);
+        tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
         switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE

@@ -18,24 +18,24 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, bool NARROW, int T, bool RED = false>
+template <int LOGN, bool INV, int MODE, int T, bool RED = false>
 __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr)
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
     // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
     //  line is consumed by the wave's eight consecutive loads, so no LDS staging pass is needed)
-    if constexpr (RED) ntt_pass<LOGN, INV, NARROW, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
-    else ntt_pass<LOGN, INV, NARROW, 0>(lds, p, tid, T, tab);
-    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 1>(lds, p, tid, T, tab); }
-    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 2>(lds, p, tid, T, tab); }
-    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, NARROW, 3>(lds, p, tid, T, tab); }
+    if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
+    else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
+    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1>(lds, p, tid, T, tab); }
+    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2>(lds, p, tid, T, tab); }
+    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 3>(lds, p, tid, T, tab); }
     if (!INV) {                                  // forward: the last pass left 16 contiguous coefficients per lane in LDS
         __syncthreads();
         for (int e = 2 * tid; e < N; e += 2 * T) {
             u64x2 v = *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
-            v[0] = ntt_fwd_finish<NARROW>(v[0], tab);
-            v[1] = ntt_fwd_finish<NARROW>(v[1], tab);
+            v[0] = ntt_fwd_finish<MODE>(v[0], tab);
+            v[1] = ntt_fwd_finish<MODE>(v[1], tab);
             *reinterpret_cast<u64x2 *>(p + e) = v;
         }
     }
@@ -51,8 +51,9 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     const size_t g = blockIdx.x;
     const NttTable tab = tabs[modmap[g % (size_t)period]];
     u64 *p = data + g * N;
-    if (tab.narrow) ntt_body<LOGN, INV, true, T>(lds, p, tab, tid);       // wave-uniform branch
-    else ntt_body<LOGN, INV, false, T>(lds, p, tab, tid);
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);       // wave-uniform branches
+    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
+    else ntt_body<LOGN, INV, NTT_WIDE, T>(lds, p, tab, tid);
 }
 
 // Forward NTT of gathered limbs: limb g is read from src[g] (residues of another modulus, reduced on load) and written
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restric
     const size_t g = blockIdx.x;
     const NttTable tab = tabs[modmap[g % (size_t)period]];
     u64 *p = data + g * N;
-    if (tab.narrow) ntt_body<LOGN, false, true, T, true>(lds, p, tab, tid, src[g]);
-    else ntt_body<LOGN, false, false, T, true>(lds, p, tab, tid, src[g]);
+    if (tab.narrow) ntt_body<LOGN, false, NTT_NARROW, T, true>(lds, p, tab, tid, src[g]);
+    else if (tab.wide_d4) ntt_body<LOGN, false, NTT_WIDE_NEAR, T, true>(lds, p, tab, tid, src[g]);
+    else ntt_body<LOGN, false, NTT_WIDE, T, true>(lds, p, tab, tid, src[g]);
 }
 
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,

@@ -46,7 +46,8 @@ struct NttTable {
     // q = 2^k - c with a small c (every prime SEAL's search returns is of this shape: it scans downwards from 2^k in
     // steps of 2n).  Then any 64-bit x reduces with ONE narrow multiply: x = (x >> k) * c + (x mod 2^k)  (mod q), which is
     // below 2q when (2^(64-k) + 2) * c <= 2^k.  fold_k = 0: not available (small or unstructured moduli), Barrett is used.
-    u32 fold_k, fold_c, fold_pad;
+    u32 fold_k, fold_c;
+    u32 wide_d4;                       // 2^63 - 4q when that fits 32 bits (wide moduli next to 2^61), else 0
 };
 
 HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
@@ -62,6 +63,16 @@ HD void ntt_fold_params(u64 q, u32 &k, u32 &c)
     if (cc >> 32) return;
     if ((unsigned __int128)((((u64)1) << (64 - bits)) + 2) * cc > ((unsigned __int128)1 << bits)) return;
     k = (u32)bits; c = (u32)cc;
+}
+
+// 2^63 - 4q if it is a positive 32-bit number (see csub_top_near), else 0
+HD u32 ntt_wide_d4(u64 q, bool narrow)
+{
+    if (narrow || (q >> 61)) return 0;
+    const u64 q4 = q << 2;
+    if (q4 >= ((u64)1 << 63)) return 0;
+    const u64 d = ((u64)1 << 63) - q4;
+    return (d >> 32) ? 0 : (u32)d;
 }
 
 // canonical residue of ANY 64-bit x
@@ -121,13 +132,25 @@ HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
 // below max(2^63, 2^64 - 4q), so a following x + v (v < 4q) and x - v + 4q still fit 64 bits; no comparison with 4q
 // is needed.  n4 = 2^64 - 4q.
 HD u64 csub_top(u64 x, u64 n4) { return x + ((u64)((int64_t)x >> 63) & n4); }
+// The same when 2^63 - 4q fits 32 bits (every 61-bit prime SEAL's search returns: q = 2^61 - c, 4c < 2^24):
+// x - 4q = (x with bit 63 cleared) + (2^63 - 4q), one shift, one mask and one multiply-add instead of a 64-bit masked add.
+HD u64 csub_top_near(u64 x, u32 d4)
+{
+    const u32 hi = (u32)(x >> 32);
+    const u64 low = ((u64)(hi & 0x7fffffffu) << 32) | (u32)x;
+    return (u64)(hi >> 31) * d4 + low;
+}
 
 enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
+// narrow: no range control at all; wide: subtract 4q when the top bit is set; wide-near: the same for q next to 2^61
+enum NttMode { NTT_NARROW = 0, NTT_WIDE = 1, NTT_WIDE_NEAR = 2 };
+HD int ntt_mode(const NttTable &tab) { return tab.narrow ? NTT_NARROW : (tab.wide_d4 ? NTT_WIDE_NEAR : NTT_WIDE); }
 
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
-template <int LOGN, int S, int K, bool INV, bool NARROW, int IN, int OUT, bool RED = false>
+// MODE: range discipline of the modulus (wave-uniform per limb): see NTT_NARROW / NTT_WIDE / NTT_WIDE_NEAR
+template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false>
 HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 {
     constexpr int R = 1 << K;                  // radix
@@ -138,6 +161,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
     constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);      // every lane of a wave shares the twiddles
     const TwPair *__restrict__ W = tab.fwd;
     const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2, n4 = (u64)0 - q4;
+    const u32 d4 = tab.wide_d4;                // wave-uniform
 
     int block, c0;
     if (COLS) { block = w / CG; c0 = (w % CG) * G; }
@@ -209,7 +233,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                         const int gap = COLS ? (bit << LOWBITS) : bit;
                         const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
-                        if (!NARROW) x = csub_top(x, n4);
+                        if (MODE == NTT_WIDE) x = csub_top(x, n4);
+                    if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
                         bfly_lazy4(x, y, tv[0], tv[1], nq, q4);
                     }
                     continue;
@@ -222,7 +247,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 for (int gg = 0; gg < G; gg++) {
                     if (!COLS && gg != g) continue;
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
-                    if (!NARROW) x = csub_top(x, n4);
+                    if (MODE == NTT_WIDE) x = csub_top(x, n4);
+                    if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
                     bfly_lazy4(x, y, t.w, t.wq, nq, q4);
                 }
             }
@@ -275,7 +301,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 }
 
 // Final range fix-up when the last pass leaves its result in LDS (forward transform).
-template <bool NARROW>
+template <int MODE>
 HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 {
     return ntt_reduce_any(v, tab);                                // any 64-bit v (wide moduli leave values up to 2^64 - 1)
@@ -310,7 +336,7 @@ constexpr int plan_s(int logn, int p)
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
-template <int LOGN, bool INV, bool NARROW, int PASS, bool RED = false>
+template <int LOGN, bool INV, int MODE, int PASS, bool RED = false>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
 {
     constexpr int P = plan_passes(LOGN);
@@ -319,5 +345,5 @@ HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
     constexpr int S = plan_s(LOGN, p);
     constexpr int IN = (PASS == 0) ? IO_GLOBAL : IO_LDS;          // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, NARROW, IN, OUT, RED>(lds, glob, w, tab);
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED>(lds, glob, w, tab);
 }

@@ -205,12 +205,12 @@ def main():
         fence()
         prof_all = take_profile()
         ctx.profile_enable(2)
-    # the same query with ComputePowers' high-power chain forced onto the second stream (untimed extra steps; `value`
-    # above is the default policy, which keeps large batches on one stream so that per-kernel timings stay additive)
+    # the same query with ComputePowers forced onto ONE stream (untimed extra steps; `value` above is the default policy:
+    # the high-power chain of the PowersDag on a second stream)
     two_stream_ms = None
     if not args.no_profile:
         ctx.profile_enable(0)
-        ctx.set_two_stream(1)
+        ctx.set_two_stream(0)
         for _ in range(2):
             step()
         fence()
@@ -242,8 +242,8 @@ def main():
     }
 
     if two_stream_ms is not None and world == 1:
-        result["two_stream"] = {"ms_per_step": round(two_stream_ms, 4), "note": "APSU_HE_SPLIT=1 / apsu_he_set_two_stream(ctx, 1): "
-                                "same results, not the default for batches of more than two bundle indices (DESIGN.md section 5)"}
+        result["one_stream"] = {"ms_per_step": round(two_stream_ms, 4), "note": "APSU_HE_SPLIT=0 / apsu_he_set_two_stream(ctx, 0): "
+                                "ComputePowers on one stream (the mode the per-kernel event timings below are taken in); same results"}
     if prof is not None:
         steps = max(1, sampled)
         ntt_ms = prof["ntt_fwd"][0] + prof["ntt_inv"][0]
@@ -385,6 +385,12 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
     ms_all, pw_all, res = run_query(nproc)
     gpu = out_dev[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
     bit_exact = all(bool((gpu[i] == res[i]).all()) for i in range(len(mine)))
+    # the reference's own scripts use -t 1/2/4/8 (tools/auto_test.py:194); ComputePowers has at most a few dozen independent
+    # nodes per level, so a pool of every core is not necessarily the fastest setting: also measured at 8 and 32 threads
+    sweep = {}
+    for T in (8, 32):
+        if T < nproc:
+            sweep[T] = run_query(T)[:2]
     ms_one, pw_one, _ = run_query(1) if nproc > 1 else (ms_all, pw_all, None)
     return {"value": round(ms_all, 1), "unit": "ms", "cores": nproc, "kind": "port",
             "sample": "the whole query, measured: ComputePowers for %d bundle indices + %d BinBundles (%d of degree %d), thread pool "
@@ -394,6 +400,7 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
             "compute_powers_ms": round(pw_all, 1),
             "single_thread": {"value": round(ms_one, 1), "unit": "ms", "cores": 1, "compute_powers_ms": round(pw_one, 1),
                               "note": "the same whole query on one thread, measured"},
+            "thread_sweep": {str(T): {"value": round(v[0], 1), "compute_powers_ms": round(v[1], 1)} for T, v in sweep.items()},
             "host_db_build_s": round(t_db, 1),
             "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(mine)}
 

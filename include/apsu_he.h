@@ -210,8 +210,8 @@ int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uin
                      int out_device_slot);
 
 /* Scheduling option: ComputePowers may walk the high-power half of the PowersDag on a second HIP stream, next to the
- * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on for calls
- * with one or two bundle indices), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1 sets the default for
+ * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on
+ * whenever the PowersDag splits into independent halves and the inputs are device resident), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1 sets the default for
  * contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
 int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
 

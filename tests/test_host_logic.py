@@ -178,6 +178,54 @@ def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
         assert (a == x).all()
 
 
+@pytest.mark.parametrize("n", [64, 256, 1024, 8192])
+def test_ntt_workgroup_emulation_61_bit_primes(emu, n):
+    """61-bit primes (the BEHZ auxiliary base; the oracle's coefficient primes stop at 60 bits): the pass functions in
+    their wide-near range mode.  inverse(forward(x)) = x, and the transform turns negacyclic convolution into a pointwise
+    product (checked against Python integers)."""
+    logn = n.bit_length() - 1
+    def is_prime(x):
+        d, r = x - 1, 0
+        while d % 2 == 0:
+            d //= 2; r += 1
+        for w in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+            y = pow(w, d, x)
+            if y in (1, x - 1):
+                continue
+            for _ in range(r - 1):
+                y = y * y % x
+                if y == x - 1:
+                    break
+            else:
+                return False
+        return True
+    # get_primes(2n, 61, .) scans downwards from 2^61; the first few hits are the context's own auxiliary primes, so
+    # take the eighth (same shape 2^61 - c, c small)
+    q, found = ((1 << 61) - 1) // (2 * n) * (2 * n) + 1, 0
+    while True:
+        if is_prime(q):
+            found += 1
+            if found == 8:
+                break
+        q -= 2 * n
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, q, n, dtype=np.uint64); b = rng.integers(0, q, n, dtype=np.uint64)
+    a[:3] = [0, q - 1, 1]
+    fa, fb = a.copy(), b.copy()
+    for v in (fa, fb):
+        assert emu.emu_ntt_limb(logn, 0, C.c_uint64(q), v.ctypes.data_as(u64p), 512 if n >= 8192 else 64) == 0, emu.emu_last_error()
+        assert int(v.max()) < q
+    back = fa.copy()
+    assert emu.emu_ntt_limb(logn, 1, C.c_uint64(q), back.ctypes.data_as(u64p), 64) == 0
+    assert (back == a).all()
+    prod = np.array([int(x) * int(y) % q for x, y in zip(fa, fb)], dtype=np.uint64)
+    assert emu.emu_ntt_limb(logn, 1, C.c_uint64(q), prod.ctypes.data_as(u64p), 64) == 0
+    ai, bi = [int(v) for v in a], [int(v) for v in b]
+    for k in (range(n) if n <= 256 else [int(v) for v in rng.integers(0, n, 8)]):      # negacyclic product by definition
+        want = (sum(ai[i] * bi[k - i] for i in range(k + 1)) - sum(ai[i] * bi[k + n - i] for i in range(k + 1, n))) % q
+        assert int(prod[k]) == want
+
+
 def test_c_abi_exports_every_declared_symbol():
     """the shared library loads and exports exactly the functions include/apsu_he.h declares"""
     import apsu_amd
