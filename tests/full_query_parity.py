@@ -37,13 +37,16 @@ print("GPU: %d bundle indices, %d BinBundles in %.1f s (incl. DB generation)" % 
 targets = ref.create_powers_set(ps, p["max_items_per_bin"])
 _, nodes = ref.powers_dag(p["query_powers"], targets)
 sources = sorted(p["query_powers"])
-threads = max(1, min(16, len(os.sched_getaffinity(0))))
-ref.set_threads(threads)
+from concurrent.futures import ThreadPoolExecutor
+threads = max(1, min(64, len(os.sched_getaffinity(0))))
 pci = C.plain_chain_idx(ps)
 bad = 0
 t0 = time.time()
+pool = ThreadPoolExecutor(threads)                        # ctypes calls into the oracle release the GIL
 for b in idxs:
+    ref.set_threads(threads)
     opw = C.compute_powers({e: np.ascontiguousarray(src[b, s]) for s, e in enumerate(sources)}, nodes, rkh, ps)
+    ref.set_threads(1)
     for power in targets:
         ct, _, _ = pw.download(b, power)
         if not (ct == opw[power]).all():
@@ -51,9 +54,9 @@ for b in idxs:
     plist = [None] * (p["max_items_per_bin"] + 1)
     for k, v in opw.items():
         plist[k] = v
-    for i, (bb, ci, deg) in enumerate(units):
-        if bb != b:
-            continue
+
+    def check(i):
+        bb, ci, deg = units[i]
         seed = SEED0 + 1000003 * bb + 7919 * ci
         coeffs = []
         for d in range(deg + 1):
@@ -61,7 +64,10 @@ for b in idxs:
             coeffs.append(C.plain_lift_ntt(raw, pci) if ref.coeff_is_ntt(ps, d) else raw)
         mask = np.ascontiguousarray(masks[i])
         exp = C.eval_patstock(plist, coeffs, ps, rkh, mask) if (ps > 1 and ps < deg) else C.eval(plist, coeffs, plist[1].shape[1] - 1, mask)
-        ok = bool((out[i] == exp).all())
+        return i, bool((out[i] == exp).all())
+
+    for i, ok in pool.map(check, [i for i, u in enumerate(units) if u[0] == b]):
+        bb, ci, deg = units[i]
         bad += 0 if ok else 1
         print("bundle idx %d cache %d degree %d: %s" % (bb, ci, deg, "bit-exact" if ok else "MISMATCH"), flush=True)
 print("oracle (%d threads for ComputePowers): %.1f s" % (threads, time.time() - t0))
