@@ -1,8 +1,9 @@
 /* Pure-C host of the drop-in boundary (include/apsu_he.h): no Python, no torch.
  *   gcc -O2 -Iinclude examples/c_abi_demo.c -Lapsu_amd -lapsu_he_gpu -Wl,-rpath,$PWD/apsu_amd -o c_abi_demo
  *   ./c_abi_demo tests/params/1M-1024-com.json
- * Runs the tier-1 NTT round trip and the tier-2 path (ComputePowers + eval_bundles on a synthetic BinBundle with a
- * mask drawn by apsu_he_mask_generate), and prints FNV-1a checksums of every result.  tests/test_gpu_c_host.py builds
+ * Runs the tier-1 NTT round trip, the tier-2 path (ComputePowers + eval_bundles on a synthetic BinBundle with a
+ * mask drawn by apsu_he_mask_generate), the multi-device handle (apsu_he_multi_* / apsu_he_eval_all on devices {0, 0}:
+ * two engines on one GPU) and the N3 framing of a ResultPackage, and prints FNV-1a checksums of every result.  tests/test_gpu_c_host.py builds
  * it, runs it, and compares the checksums with the same calls made through the Python binding. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -96,6 +97,43 @@ int main(int argc, char **argv)
     const uint64_t *ml[1] = { mask_dev };
     CHECK(apsu_he_eval_bundles(ctx, bl, 1, pw, rk, ml, 1, out, 0));
     printf("result %016llx\n", (unsigned long long)fnv(out, 2 * n * 8));
+
+    /* several devices behind one handle: the same BinBundle on slot 1 of {0, 0}, every bundle index's sources on the host */
+    {
+        int devices[2] = { 0, 0 }, id = -1, slot[1];
+        uint32_t bi[1] = { 0 }, ci[1] = { 0 }, dg[1] = { info.max_items_per_bin - 1 };
+        CHECK(apsu_he_partition_bundles(info.bundle_idx_count, 2, bi, ci, dg, 1, slot));
+        apsu_he_multi *m = NULL;
+        CHECK(apsu_he_multi_create(json, devices, 2, &m));
+        if (info.using_keyswitching) {
+            size_t words = (size_t)(K - 1) * 2 * K * n;
+            uint64_t *ksk = (uint64_t *)malloc(words * 8);
+            for (size_t i = 0; i < words; i++) ksk[i] = mix(1000003 + i) % info.coeff_modulus[(i / n) % K];
+            CHECK(apsu_he_multi_relin_upload(m, ksk));
+            free(ksk);
+        }
+        CHECK(apsu_he_multi_db_random_bundle(m, 1 - slot[0], 0, 0, info.max_items_per_bin - 1, 4242, &id));
+        const uint64_t **all_src = (const uint64_t **)malloc((size_t)info.bundle_idx_count * ns * sizeof(*all_src));
+        for (uint32_t b = 0; b < info.bundle_idx_count; b++)
+            for (uint32_t s2 = 0; s2 < ns; s2++) all_src[(size_t)b * ns + s2] = srcp[s2];
+        uint64_t *mask_host = (uint64_t *)malloc(n * 8), *out2 = (uint64_t *)malloc(2 * n * 8);
+        if (hipMemcpy(mask_host, mask_dev, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        const uint64_t *mh[1] = { mask_host };
+        CHECK(apsu_he_eval_all(m, all_src, mh, out2, -1));
+        printf("multi %s (bundle id %d)\n", memcmp(out, out2, 2 * n * 8) == 0 ? "ok" : "MISMATCH", id);
+        CHECK(apsu_he_multi_destroy(m));
+        free(all_src); free(mask_host); free(out2);
+    }
+
+    /* N3: the result as a ResultPackage message (result_package.fbs), parsed back */
+    {
+        uint8_t *msg = NULL; size_t msg_n = 0;
+        CHECK(apsu_he_wire_build_result_package(0, 3, (const uint8_t *)out, 2 * n * 8, 0, 0, 0, NULL, NULL, &msg, &msg_n));
+        uint32_t b2 = 9, c2 = 9, nl = 9; const uint8_t *blob = NULL; size_t blob_n = 0;
+        CHECK(apsu_he_wire_parse_result_package(msg, msg_n, &b2, &c2, &blob, &blob_n, NULL, NULL, &nl));
+        printf("wire %s (%zu bytes)\n", (b2 == 0 && c2 == 3 && nl == 0 && blob_n == 2 * n * 8 && memcmp(blob, out, blob_n) == 0) ? "ok" : "MISMATCH", msg_n);
+        CHECK(apsu_he_wire_buffer_free(msg));
+    }
 
     /* error behaviour: too few powers for a bundle index that was not computed */
     apsu_he_bundle *other = NULL;

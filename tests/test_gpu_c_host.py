@@ -43,6 +43,7 @@ def test_c_program_matches_python_binding(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines() if " " in l)
     assert lines["roundtrip"] == "ok" and lines["missing-powers"].startswith("status -1") and "done" in r.stdout
+    assert lines["multi"].startswith("ok") and lines["wire"].startswith("ok"), r.stdout
 
     # the same inputs through the Python binding
     G = apsu_amd.HeContext(open(params).read())
