@@ -18,20 +18,15 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, int MODE, int T, bool RED = false, bool STAGE = false>
+template <int LOGN, bool INV, int MODE, int T, bool RED = false>
 __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr)
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
-    // The first inverse pass needs 16 CONTIGUOUS coefficients per lane.  Read straight from global memory that is a
-    // 128-byte lane stride: every line is consumed by the wave's eight consecutive loads, fine for throughput at full
-    // occupancy.  STAGE (small launches, where a lone workgroup's latency is what counts): coalesced loads into the
-    // LDS image first, then pass 0 reads LDS.
-    if constexpr (INV && STAGE) {
-        for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = ldg16(p + e);
-        __syncthreads();
-        ntt_pass<LOGN, INV, MODE, 0, false, IO_LDS>(lds, p, tid, T, tab);
-    } else if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
+    // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
+    //  line is consumed by the wave's eight consecutive loads.  Staging the limb through LDS with coalesced loads first was
+    //  measured again in round 2 for small launches: no gain, profiles/r02_ntt_latency.txt)
+    if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
     else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
     if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1>(lds, p, tid, T, tab); }
     if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2>(lds, p, tid, T, tab); }
@@ -47,7 +42,7 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     }
 }
 
-template <int LOGN, bool INV, int T, bool STAGE = false>
+template <int LOGN, bool INV, int T>
 __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
                                            const int *__restrict__ modmap, int period)
 {
@@ -57,9 +52,9 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     const size_t g = blockIdx.x;
     const NttTable tab = tabs[modmap[g % (size_t)period]];
     u64 *p = data + g * N;
-    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, false, STAGE>(lds, p, tab, tid);       // wave-uniform branches
-    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, false, STAGE>(lds, p, tab, tid);
-    else ntt_body<LOGN, INV, NTT_WIDE, T, false, STAGE>(lds, p, tab, tid);
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);       // wave-uniform branches
+    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
+    else ntt_body<LOGN, INV, NTT_WIDE, T>(lds, p, tab, tid);
 }
 
 // Forward NTT of gathered limbs: limb g is read from src[g] (residues of another modulus, reduced on load) and written
@@ -96,10 +91,7 @@ template <int LOGN, int T>
 static void launch_ntt_t(bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
                          hipStream_t st)
 {
-    // inverse launches of at most `stage_max` limbs (less than one workgroup per CU slot) stage the limb through LDS
-    static const size_t stage_max = [] { const char *e = std::getenv("APSU_HE_NTT_STAGE_MAX"); return e ? (size_t)atoll(e) : (size_t)0; }();
-    if (inverse && count <= stage_max) hipLaunchKernelGGL((k_ntt<LOGN, true, T, true>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
-    else if (inverse) hipLaunchKernelGGL((k_ntt<LOGN, true, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
+    if (inverse) hipLaunchKernelGGL((k_ntt<LOGN, true, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
     else hipLaunchKernelGGL((k_ntt<LOGN, false, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
 }
 

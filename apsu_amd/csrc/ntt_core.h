@@ -336,15 +336,14 @@ constexpr int plan_s(int logn, int p)
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
-// IN0: where pass 0 reads from (IO_LDS when the caller has staged the limb in LDS with coalesced loads first)
-template <int LOGN, bool INV, int MODE, int PASS, bool RED = false, int IN0 = IO_GLOBAL>
+template <int LOGN, bool INV, int MODE, int PASS, bool RED = false>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
 {
     constexpr int P = plan_passes(LOGN);
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
     constexpr int K = plan_k(LOGN, p);
     constexpr int S = plan_s(LOGN, p);
-    constexpr int IN = (PASS == 0) ? IN0 : IO_LDS;                // by default both directions read the limb straight from global memory
+    constexpr int IN = (PASS == 0) ? IO_GLOBAL : IO_LDS;          // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
     for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED>(lds, glob, w, tab);
 }

@@ -1,0 +1,36 @@
+"""GPU tier: bench.py's N > 1 code path (one process per rank, shard of the BinBundles per rank, two alternating result
+buffers, all_gather of the results) rehearsed on the one-GPU box: two ranks on GPU 0, gathered through gloo
+(APSU_BENCH_BACKEND=gloo; the driver's multi-GPU runs use the default "nccl" = RCCL, one GPU per rank).  Rank 0 checks that
+its own rows arrive unchanged and that every BinBundle's row was filled by some rank."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_bench_on_one_gpu():
+    env = dict(os.environ, APSU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "1M-1024-com", "--no-profile"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["gather_check"] == {"rank0_rows_match": True, "all_binbundle_rows_filled": True, "rows": 34}
+    assert d["config"]["binbundles_rank0"] == 17
