@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--config", default="16M-4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed steps")
-    ap.add_argument("--profile-every", type=int, default=5, help="bracket the NTT launches with HIP events in every n-th timed step")
+    ap.add_argument("--profile-every", type=int, default=10, help="bracket the NTT launches with HIP events in every n-th timed step")
     args = ap.parse_args()
 
     import torch

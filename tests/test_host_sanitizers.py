@@ -1,0 +1,24 @@
+"""CPU tier: the product's host code that parses untrusted or structured input, built with AddressSanitizer +
+UndefinedBehaviorSanitizer and driven through a fuzzing harness (tests/native/sanitize_harness.cpp): the N3 framing reader,
+the PSUParams JSON reader with the derived constants, the PowersDag and the partition rule.  (GPU AddressSanitizer is not
+available on this pool; the device side is covered by the bit-exact parity tests.)"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "apsu_amd", "csrc")
+
+
+def test_host_parsers_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "sanitize_harness")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "tests", "native", "sanitize_harness.cpp")] + \
+          [os.path.join(SRC, f) for f in ("wire.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-o", exe]
+    subprocess.check_call(cmd)
+    params = [os.path.join(ROOT, "tests", "params", f + ".json") for f in ("100K-1", "1M-1024-com", "1M-4096-32", "256M-4096")]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + params, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    assert r.stdout.strip().endswith("ok") and "malformed buffers rejected" in r.stdout
