@@ -22,20 +22,20 @@ public:
     };
 
     bool configure(std::set<uint32_t> source_powers, std::set<uint32_t> target_powers);
-    bool is_configured() const { return configured_; }
-    uint32_t depth() const { return depth_; }
-    uint32_t source_count() const { return source_count_; }
-    const std::set<uint32_t> &target_powers() const { return target_powers_; }
-    const std::map<uint32_t, PowersNode> &nodes() const { return nodes_; }
+    bool is_configured() const { return ready_; }
+    uint32_t depth() const { return max_depth_; }
+    uint32_t source_count() const { return n_sources_; }
+    const std::set<uint32_t> &target_powers() const { return targets_; }
+    const std::map<uint32_t, PowersNode> &nodes() const { return by_power_; }
     // nodes grouped by depth (index 0 = sources), ascending power inside a level
     std::vector<std::vector<PowersNode>> levels() const;
     void reset();
 
 private:
-    std::map<uint32_t, PowersNode> nodes_;
-    std::set<uint32_t> target_powers_;
-    bool configured_ = false;
-    uint32_t depth_ = 0, source_count_ = 0;
+    std::map<uint32_t, PowersNode> by_power_;
+    std::set<uint32_t> targets_;
+    bool ready_ = false;
+    uint32_t max_depth_ = 0, n_sources_ = 0;
 };
 
 } // namespace apsu_he
