@@ -355,3 +355,34 @@ def test_calls_from_a_thread_on_another_device():
     assert res["dev"] == 0
     assert (res["out"][0] == common.oracle_eval(S, opw, S.bundles[0])).all()
     G.close()
+
+
+def test_scheduling_options_do_not_change_bits():
+    """apsu_he_set_two_stream / apsu_he_set_eval_pipeline only move launches between streams: same kernels, same
+    operands, same results (every combination against the oracle-checked default)"""
+    import torch
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 77, 30, 124, 9], 1: [124, 5, 60]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    src = np.stack([np.stack([S.src[b][e] for e in S.sources]) for b in S.bundle_indices])
+    src_d = torch.from_numpy(src.view(np.int64)).cuda()
+    w = src[0, 0].size
+    ptrs = [[src_d.data_ptr() + ((bi * len(S.sources) + i) * w) * 8 for i in range(len(S.sources))] for bi in range(len(S.bundle_indices))]
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    want = None
+    for split in (0, 1):
+        for pipe in (1, 2, 4):
+            G.set_two_stream(split)
+            G.set_eval_pipeline(pipe)
+            for _ in range(2):
+                pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)   # device-resident inputs: the two-stream walk
+                out = G.eval_bundles(gb, pw, rk, masks)
+            if want is None:
+                want = out
+                for i, b in enumerate(S.bundles):
+                    assert (out[i] == common.oracle_eval(S, opw, b)).all()
+            assert (out == want).all(), (split, pipe)
+    G.close()
