@@ -118,8 +118,6 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
             ntt_fold_params(tabs[m].q, tabs[m].fold_k, tabs[m].fold_c);
             tabs[m].wide_d4 = ntt_wide_d4(tabs[m].q, tabs[m].narrow != 0);
-            tabs[m].fold_twist = ntt_fold_twist_ok(tabs[m].q, hp_.logn) ? 1 : 0;
-            tabs[m].fold_pad = 0;
             tabs[m].fwd = base + ((size_t)m * 3 + 0) * n;
             tabs[m].dit = base + ((size_t)m * 3 + 1) * n;
             tabs[m].scale = base + ((size_t)m * 3 + 2) * n;

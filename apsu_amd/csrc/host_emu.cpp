@@ -61,10 +61,9 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
             dit[k] = { t.dit[k], t.dit_q[k] }; sc[k] = { t.scale[k], t.scale_q[k] };
         }
         NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), dit.data(), sc.data(),
-                      ntt_is_narrow(q, logn) ? 1 : 0, 0, 0, 0, 0, 0 };
+                      ntt_is_narrow(q, logn) ? 1 : 0, 0, 0, 0 };
         ntt_fold_params(q, tab.fold_k, tab.fold_c);
         tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
-        tab.fold_twist = ntt_fold_twist_ok(q, logn) ? 1 : 0;
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
         switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE

@@ -48,7 +48,6 @@ struct NttTable {
     // below 2q when (2^(64-k) + 2) * c <= 2^k.  fold_k = 0: not available (small or unstructured moduli), Barrett is used.
     u32 fold_k, fold_c;
     u32 wide_d4;                       // 2^63 - 4q when that fits 32 bits (wide moduli next to 2^61), else 0
-    u32 fold_twist, fold_pad;          // mul_fold_canonical is valid for the inverse's twist (narrow modulus, bounds host-checked)
 };
 
 HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
@@ -64,46 +63,6 @@ HD void ntt_fold_params(u64 q, u32 &k, u32 &c)
     if (cc >> 32) return;
     if ((unsigned __int128)((((u64)1) << (64 - bits)) + 2) * cc > ((unsigned __int128)1 << bits)) return;
     k = (u32)bits; c = (u32)cc;
-}
-
-// x * w mod q, canonical, for q = 2^k - c (tab.fold_k != 0), w < q and x below the narrow transforms' lazy bound
-// ((4 log n + 1) q < 2^64, so (x >> 32) + (w >> 32) + 2 < 2^32 and the middle column of the schoolbook product cannot
-// overflow): the full 128-bit product, two folds of the part above bit k (P = Ph 2^k + Pl = Ph c + Pl mod q), one
-// conditional subtraction.  7 multiply-adds and no quotient word, against 10 multiplies for an exact Shoup product; used
-// for the inverse transform's final twist (n^-1 psi^-j), where the result must be canonical.
-HD u64 mul_fold_canonical(u64 x, u64 w, const NttTable &tab)
-{
-    const u32 ks = tab.fold_k - 32, mhi = (1u << ks) - 1, c = tab.fold_c;
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
-    const u64 a = (u64)x0 * w0;
-    const u64 mid = (u64)x1 * w0 + ((u64)x0 * w1 + (a >> 32));
-    const u64 top = (u64)x1 * w1 + (mid >> 32);
-    const u32 P0 = (u32)a, P1 = (u32)mid, P2 = (u32)top, P3 = (u32)(top >> 32);
-    // Ph = P >> k (two words), Pl = P mod 2^k
-    const u32 Ph0 = (u32)((((u64)P2 << 32) | P1) >> ks), Ph1 = (u32)((((u64)P3 << 32) | P2) >> ks);
-    const u64 Pl = ((u64)(P1 & mhi) << 32) | P0;
-    const u64 g = (u64)Ph0 * c + Pl;
-    const u64 e = (u64)Ph1 * c + (g >> 32);                      // F = Ph c + Pl = e 2^32 + (g mod 2^32)
-    const u32 Fh = (u32)(e >> ks);                               // F >> k
-    const u64 Fl = ((u64)((u32)e & mhi) << 32) | (u32)g;
-    const u64 v = (u64)Fh * c + Fl;                              // < 2q
-    return v >= tab.q ? v - tab.q : v;
-}
-
-// may the inverse transform's twist use mul_fold_canonical?  x < X = (4 logn + 1) q (narrow lazy bound), w < q
-HD bool ntt_fold_twist_ok(u64 q, int logn)
-{
-    u32 k, c;
-    ntt_fold_params(q, k, c);
-    if (!k || !ntt_is_narrow(q, logn)) return false;
-    const unsigned __int128 X = (unsigned __int128)q * (unsigned)(4 * logn + 1);          // < 2^64
-    const u64 ph1 = (u64)(X >> 32) + 1;                                                    // high word of Ph = (x w) >> k < X
-    if (ph1 + (q >> 32) + 3 >= ((u64)1 << 32)) return false;                               // middle column of the product
-    const unsigned __int128 e = (unsigned __int128)ph1 * c + ((unsigned __int128)1 << 32);
-    const unsigned __int128 fh = (e >> (k - 32)) + 1;
-    if (fh >> 32) return false;
-    const unsigned __int128 v = fh * c + ((unsigned __int128)1 << k);
-    return v < ((unsigned __int128)q << 1);
 }
 
 // 2^63 - 4q if it is a positive 32-bit number (see csub_top_near), else 0
@@ -304,8 +263,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
                 u64 v = r[g][j];
                 if (INV) {
                     const u64x2 sv = ldg16(reinterpret_cast<const u64 *>(tab.scale + idx(g, j)));
-                    if (MODE == NTT_NARROW && tab.fold_twist) v = mul_fold_canonical(v, sv[0], tab);  // wave-uniform
-                    else v = mul_shoup(v, sv[0], sv[1], q);
+                    v = mul_shoup(v, sv[0], sv[1], q);      // (a 2^k - c fold product here measured 7 % slower)
                 } else v = ntt_reduce_any(v, tab);
                 r[g][j] = v;
             }

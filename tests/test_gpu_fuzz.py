@@ -2,6 +2,7 @@
 level counts, plain modulus width, Paterson-Stockmeyer shape, query powers, ragged BinBundle degrees) — the GPU path must
 equal the oracle bit for bit on every one, whether or not the noise budget survives (parity is about the arithmetic)."""
 import json
+import os
 import random
 
 import numpy as np
@@ -42,7 +43,8 @@ def random_params(rng):
     }), max_items
 
 
-@pytest.mark.parametrize("seed", range(28))
+# APSU_FUZZ_SEEDS=n widens the sweep for one-off runs (profiles/r02_fuzz_extended.txt: 400 seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("APSU_FUZZ_SEEDS", "28"))))
 def test_random_parameter_sets(seed):
     rng = random.Random(1000 + seed)
     for _ in range(40):                                     # draw until the reference's own validation accepts the set
