@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_polyn_with_roots(const u64 *__restrict_
     }
 }
 
-// fallback for polynomials that do not fit a wave's registers (more than 6144 coefficients): one thread per bin,
+// fallback for polynomials beyond the largest wave-per-bin instance (more than 8192 coefficients): one thread per bin,
 // coefficients in global memory
 __global__ __launch_bounds__(EW_T) void k_polyn_with_roots_serial(const u64 *__restrict__ roots, const u32 *__restrict__ counts,
                                                                   u32 bins, u32 stride, Mod t, u64 *__restrict__ poly, size_t n)
@@ -440,7 +440,7 @@ void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 
     const u32 slots = max_deg / 64 + 1;
     const dim3 g((bins + 3) / 4), b(256);
 #define PW_CASE(S) if (slots <= S) { hipLaunchKernelGGL((k_polyn_with_roots<S>), g, b, 0, st, roots, counts, bins, stride, t, poly, n); KERNEL_CHECK(); return; }
-    PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(8) PW_CASE(16) PW_CASE(24) PW_CASE(32) PW_CASE(48) PW_CASE(64) PW_CASE(96)
+    PW_CASE(1) PW_CASE(2) PW_CASE(4) PW_CASE(8) PW_CASE(16) PW_CASE(24) PW_CASE(32) PW_CASE(48) PW_CASE(64) PW_CASE(96) PW_CASE(128)
 #undef PW_CASE
     hipLaunchKernelGGL(k_polyn_with_roots_serial, dim3((bins + EW_T - 1) / EW_T), dim3(EW_T), 0, st, roots, counts, bins, stride, t, poly, n);
     KERNEL_CHECK();

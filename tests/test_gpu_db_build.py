@@ -176,9 +176,10 @@ def test_bundle_image_roundtrip(tmp_path):
 
 def test_build_spans_several_register_slots_and_the_serial_fallback():
     # the wave-per-bin kernel keeps coefficient i in lane i % 64, slot i / 64: degrees that cross slot boundaries
-    # (63, 64, 65, 200), and a degree beyond its 6144-coefficient capacity that takes the thread-per-bin fallback
+    # (63, 64, 65, 200), a degree served by its largest instance (128 slots: up to 8191 coefficients, the 256M-1 parameter
+    # set has bins of up to 8099 items), and one beyond that capacity, which takes the thread-per-bin fallback
     rng = np.random.default_rng(11)
-    for max_items, counts in ((210, [63, 64, 65, 200, 0, 1, 129]), (6200, [6199, 70, 0])):
+    for max_items, counts in ((210, [63, 64, 65, 200, 0, 1, 129]), (6200, [6199, 70, 0]), (8100, [8099, 4000, 1]), (8300, [8299, 3])):
         js = common.toy_json(ps_low=0, max_items=max_items, query_powers=(1,))
         p = ref.load_params(js)
         C = ref.RefContext.from_params(p)
@@ -187,6 +188,6 @@ def test_build_spans_several_register_slots_and_the_serial_fallback():
         G = apsu_amd.HeContext(js)
         gb = G.build_bundle(0, 0, bins)
         assert gb.degree == max(counts)
-        for d in sorted({0, 1, 2, 62, 63, 64, 65, 128, 199, 200, max(counts) - 1, max(counts)} & set(range(max(counts) + 1))):
+        for d in sorted({0, 1, 2, 62, 63, 64, 65, 128, 199, 200, 4000, 6143, 6144, 8098, max(counts) - 1, max(counts)} & set(range(max(counts) + 1))):
             got, kind = G.bundle_coeff(gb, d)
             assert (got == coeffs[d]).all(), "max_items %d coefficient %d" % (max_items, d)
