@@ -72,7 +72,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     // the NTT keeps one limb in a workgroup's LDS: n = 2^logn coefficients with a compiled pass plan (ntt_core.h)
     if (plan_passes(hp_.logn) == 0)
         throw std::invalid_argument("poly_modulus_degree " + std::to_string(hp_.n) +
-                                    " is not supported by the GPU engine (supported: 64, 256, 1024, 2048, 4096, 8192)");
+                                    " is not supported by the GPU engine (supported: 64, 256, 1024, 2048, 4096, 8192, 16384)");
     struct Restore { int prev = -1; ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore;
     { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != device) restore.prev = cur; }
     HIP_CHECK(hipSetDevice(device));

@@ -65,7 +65,7 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
         ntt_fold_params(q, tab.fold_k, tab.fold_c);
         tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
 #define CASE(L) case L: if (inverse) emu_ntt<L, true>(data, tab, threads); else emu_ntt<L, false>(data, tab, threads); break;
-        switch (logn) { CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
+        switch (logn) { CASE(14) CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }

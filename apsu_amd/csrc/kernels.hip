@@ -80,7 +80,7 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
     if (!count) return;
 #define G_CASE(LN, T) case LN: hipLaunchKernelGGL((k_ntt_gather<LN, T>), dim3((unsigned)count), dim3(T), 0, st, src, data, tabs, modmap, period); break;
     switch (logn) {
-    G_CASE(13, 512) G_CASE(12, 256) G_CASE(11, 128) G_CASE(10, 64) G_CASE(8, 64) G_CASE(6, 64)
+    G_CASE(14, 1024) G_CASE(13, 512) G_CASE(12, 256) G_CASE(11, 128) G_CASE(10, 64) G_CASE(8, 64) G_CASE(6, 64)
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
 #undef G_CASE
@@ -100,6 +100,7 @@ void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable 
 {
     if (!count) return;
     switch (logn) {
+    case 14: launch_ntt_t<14, 1024>(inverse, data, count, tabs, modmap, period, st); break;
     case 13: launch_ntt_t<13, 512>(inverse, data, count, tabs, modmap, period, st); break;
     case 12: launch_ntt_t<12, 256>(inverse, data, count, tabs, modmap, period, st); break;
     case 11: launch_ntt_t<11, 128>(inverse, data, count, tabs, modmap, period, st); break;

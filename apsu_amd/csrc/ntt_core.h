@@ -310,11 +310,12 @@ HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 // ---- pass schedule (stage counts per pass, summing to LOGN), resolved at compile time ----
 constexpr int plan_passes(int logn)
 {
-    return logn == 13 ? 4 : logn == 12 ? 4 : logn == 11 ? 4 : logn == 10 ? 3 : logn == 8 ? 3 : logn == 6 ? 2 : 0;
+    return logn == 14 ? 4 : logn == 13 ? 4 : logn == 12 ? 4 : logn == 11 ? 4 : logn == 10 ? 3 : logn == 8 ? 3 : logn == 6 ? 2 : 0;
 }
 constexpr int plan_k(int logn, int p)
 {
     switch (logn) {
+    case 14: return p >= 2 ? 4 : 3;               // 3,3,4,4   (n = 16384: 144 KiB of LDS, one 1024-thread workgroup per CU)
     case 13: return p == 3 ? 4 : 3;               // 3,3,3,4
     case 12: return 3;                            // 3,3,3,3
     case 11: return p == 3 ? 2 : 3;               // 3,3,3,2

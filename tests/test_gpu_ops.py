@@ -19,6 +19,7 @@ FAMILIES = [
     (4096, [48, 36, 25], 0, 18),            # 1M-1024-com
     (8192, [56, 56, 56, 50], 0, 22),        # 16M-4096
     (8192, [50, 50, 50, 38, 30], 0, 26),    # 256M-4096
+    (16384, [58, 58, 50, 40], 0, 22),       # beyond the shipped sets: one 1024-thread workgroup per limb, 144 KiB of LDS
 ]
 
 
@@ -178,7 +179,7 @@ def test_ntt_large_batch_streams_correctly():
     G.close()
 
 
-@pytest.mark.parametrize("n", [2048, 8192])
+@pytest.mark.parametrize("n", [2048, 8192, 16384])
 def test_ntt_every_prime_width(n):
     # coefficient primes of every width the engine may meet, across the narrow / wide boundary of the lazy butterflies
     # ((4 log n + 1) q < 2^64 up to 58 bits at n = 8192): forward and inverse transforms against the oracle

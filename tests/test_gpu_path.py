@@ -60,6 +60,12 @@ def test_toy_wide_primes_many_low_powers_fallback_path():
                  {0: [40, 35], 1: [17]})
 
 
+def test_ring_size_16384():
+    # n = 16384 is outside the shipped parameter files (max 8192) but inside SEAL's range: whole path, small degrees
+    run_scenario(common.toy_json(n=16384, coeff_bits=(56, 56, 56, 50), plain_bits=22, ps_low=3, max_items=9, query_powers=(1, 4),
+                                 felts=5), {0: [9, 4], 1: [7]}, roots_frac=0.01)
+
+
 def test_config_100K_1():
     run_scenario(common.param_json("100K-1"), {0: [19, 7, 1]})
 

@@ -160,13 +160,13 @@ def test_psu_params_validation_mirrors_reference(emu):
 
 
 @pytest.mark.parametrize("n,bits", [(64, 40), (64, 60), (256, 50), (256, 60), (1024, 56), (1024, 60), (2048, 48), (2048, 60),
-                                    (4096, 36), (4096, 60), (8192, 56), (8192, 58), (8192, 60)])
+                                    (4096, 36), (4096, 60), (8192, 56), (8192, 58), (8192, 60), (16384, 56), (16384, 60)])
 def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
     """the kernel's pass functions (ntt_core.h), stepped on the CPU, equal the oracle's NTT bit for bit"""
     logn = n.bit_length() - 1
     c = ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20)
     q = c.q[0]
-    for seed, T in ((5, 64), (6, 512)):
+    for seed, T in ((5, 64), (6, 1024 if n == 16384 else 512)):
         x = ref.fill_uniform(seed, q, n)
         x[:4] = [0, q - 1, 1, q - 2]                      # range edges
         a = x.copy()
@@ -178,7 +178,7 @@ def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
         assert (a == x).all()
 
 
-@pytest.mark.parametrize("n", [64, 256, 1024, 8192])
+@pytest.mark.parametrize("n", [64, 256, 1024, 8192, 16384])
 def test_ntt_workgroup_emulation_61_bit_primes(emu, n):
     """61-bit primes (the BEHZ auxiliary base; the oracle's coefficient primes stop at 60 bits): the pass functions in
     their wide-near range mode.  inverse(forward(x)) = x, and the transform turns negacyclic convolution into a pointwise
