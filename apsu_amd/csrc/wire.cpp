@@ -77,15 +77,6 @@ void write_byte_vector(Writer &w, Span s)
     w.align(4);
 }
 
-// Ciphertext { data:[ubyte] (required) } at the current position
-void write_ciphertext(Writer &w, Span data)
-{
-    TableWriter t(w);
-    t.begin({ 4 });
-    t.link(0);
-    write_byte_vector(w, data);
-}
-
 // vector of Ciphertext tables at the current position
 void write_ciphertext_vector(Writer &w, const std::vector<Span> &cts)
 {
