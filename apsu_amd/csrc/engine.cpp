@@ -1056,7 +1056,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // the one-stream walk: a launch bracketed by events next to another stream's kernels measures the sharing, not the kernel.
     static const int split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
     const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : split_env;                  // API override, then environment
-    const bool split = split_ok_ && on_device && !prof_on_ && (split_mode < 0 || split_mode == 1);   // host inputs end with a sync anyway
+    const bool split = split_ok_ && !prof_on_ && (split_mode < 0 || split_mode == 1);   // (host inputs are uploaded per lane and end with a sync)
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
     WITH_ARENA({
