@@ -56,6 +56,13 @@ struct DevLevel {
     ShoupConst s_B_to_q[DMAXL][DMAXB];
     ShoupConst s_B_to_msk[DMAXB];
     ShoupConst s_prod_B_q[DMAXL], s_neg_prod_B_q[DMAXL];
+    // The unrolled finish kernels (L = nB <= 3) consume the output of an inverse NTT and start by multiplying it with a
+    // constant (t (Q/q_j)^-1 for the q limbs, t for the Bsk limbs).  For them the inverse transform leaves out its own final
+    // twist (n^-1 psi^-k, one exact Shoup product per coefficient) and writes the raw lazy value; the twist rides on the
+    // finish's constant instead: fin_q[j][k] = t (Q/q_j)^-1 n^-1 psi_j^-k mod q_j, fin_b[i][k] = t n^-1 psi_i^-k mod Bsk_i.
+    // Same residues, one modular product per coefficient less.  Null for levels that use the generic finish.
+    const ShoupConst *fin_q[DMAXL];
+    const ShoupConst *fin_b[DMAXB];
 };
 
 // Key-switching constants (App. B10); moduli indexed by key limb.
@@ -85,7 +92,9 @@ struct MacJob {
 
 // ---- launch wrappers (all asynchronous on `st`) --------------------------------------------
 // NTT over `count` consecutive limb polynomials of n coefficients; limb g uses
-// tabs[modmap[g % period]].
+// tabs[modmap[g % period] & NTT_MAP_MASK].  An inverse transform of a limb whose map entry carries NTT_MAP_RAW writes its
+// result WITHOUT the final twist n^-1 psi^-k and without the final reduction (consumers: the unrolled BEHZ finish kernels).
+constexpr int NTT_MAP_RAW = 1 << 30, NTT_MAP_MASK = NTT_MAP_RAW - 1;
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
                 int period, hipStream_t st);
 // forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n

@@ -200,13 +200,45 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 map_ksacc[(size_t)c * (DMAXL + 1) + I] = id;
             }
         }
+        // per-position constants of the unrolled finish kernels: their own constant times the inverse transform's twist
+        // (device.h: fin_q / fin_b), and the matching inverse-NTT maps
+        std::vector<int> map_ext_fin = map_ext;
+        {
+            std::vector<ShoupConst> fin;
+            std::vector<std::pair<int, int>> where;                   // (level, ext limb) of each table, in order
+            for (int c = 0; c < nl; c++) {
+                if (!fast_finish(c)) continue;
+                const LevelConstants &h = hp_.level[c];
+                const int L = h.L, nB = h.nB;
+                for (int e = 0; e < L + nB + 1; e++) {
+                    const int id = e < L ? e : hp_.bsk_id(nB, e - L);
+                    const NttTablesHost &tb = hp_.ntt[id];
+                    const u64 m = tb.mod.value;
+                    const u64 cst = e < L ? lv[c].t_inv_punct_q[e].w : lv[c].t_bsk[e - L].w;
+                    for (size_t k = 0; k < n; k++) fin.push_back(shoup_const(tb.mod.mul(cst, tb.scale[k]), m));
+                    where.push_back({ c, e });
+                    map_ext_fin[(size_t)c * DMAXE + e] |= NTT_MAP_RAW;
+                }
+            }
+            if (!fin.empty()) {
+                d_fin_.alloc(fin.size() * sizeof(ShoupConst));
+                HIP_CHECK(hipMemcpy(d_fin_.p(), fin.data(), fin.size() * sizeof(ShoupConst), hipMemcpyHostToDevice));
+                const ShoupConst *base = reinterpret_cast<const ShoupConst *>(d_fin_.p());
+                for (size_t i = 0; i < where.size(); i++) {
+                    DevLevel &d = lv[where[i].first];
+                    const int e = where[i].second;
+                    if (e < d.L) d.fin_q[e] = base + i * n;
+                    else d.fin_b[e - d.L] = base + i * n;
+                }
+            }
+        }
         d_levels_.alloc(lv.size() * sizeof(DevLevel));
         HIP_CHECK(hipMemcpy(d_levels_.p(), lv.data(), lv.size() * sizeof(DevLevel), hipMemcpyHostToDevice));
         auto up = [](DevBuf &b, const std::vector<int> &v) {
             b.alloc(v.size() * sizeof(int));
             HIP_CHECK(hipMemcpy(b.p(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
         };
-        up(d_map_ext_, map_ext); up(d_map_ks_, map_ks); up(d_map_ksacc_, map_ksacc);
+        up(d_map_ext_, map_ext); up(d_map_ext_fin_, map_ext_fin); up(d_map_ks_, map_ks); up(d_map_ksacc_, map_ksacc);
         std::vector<int> ident(DMAXL + DMAXB + 4);                     // identity over every modulus id (incl. plain modulus)
         for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
         up(d_map_ct_, ident);
@@ -654,7 +686,7 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
         u64 *d = ws((size_t)3 * E * n), *o = ws(3 * L * n);
         std::vector<TensorJob> tj{ TensorJob{ ext, square ? ext : ext + (size_t)2 * E * n, d } };
         { PROF(P_TENSOR, 0); launch_tensor(dlevel(chain_idx), upload_jobs(tj), n, 1, st_); }
-        d_ntt(d, (size_t)3 * E, map_ext(chain_idx), E, true);
+        d_ntt(d, (size_t)3 * E, map_ext_fin(chain_idx), E, true);        // the finish below applies the twist where it can
         std::vector<FinishJob> fj{ FinishJob{ d, o, 1, 0 } };
         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, upload_jobs(fj), false, n, 1, st_); }
         D2H(out3, o, 3 * L * n);
@@ -938,7 +970,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                     }
                 }
                 { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }                 // :422/:424
-                d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext(first), (int)Ef, true);
+                d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
                 { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 if (hp_.using_keyswitching && nn > 0) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
             }
@@ -1720,8 +1752,10 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                                        bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
                             fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                         }
-                        for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
-                        for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i));
+                        // (the finish applies the inverse transform's twist itself where it is the unrolled kernel: raw output)
+                        const int rawf = fast_finish(high) ? NTT_MAP_RAW : 0;
+                        for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j | rawf);
+                        for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i) | rawf);
                         if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
                         { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
                         d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
@@ -1751,7 +1785,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                         }
                         if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
-                        d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext(high), (int)Eh, true);
+                        d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
                         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                         { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
                     }

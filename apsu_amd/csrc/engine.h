@@ -166,6 +166,10 @@ private:
     const DevKey *dkey() const { return reinterpret_cast<const DevKey *>(d_key_.p()); }
     const int *map_ct() const { return reinterpret_cast<const int *>(d_map_ct_.p()); }
     const int *map_ext(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ext_.p()) + chain_idx * DMAXE; }
+    // the same map for the inverse transform in front of a finish kernel: NTT_MAP_RAW set where that level's finish takes
+    // the twist into its own constants (fast_finish), identical to map_ext otherwise
+    const int *map_ext_fin(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ext_fin_.p()) + chain_idx * DMAXE; }
+    bool fast_finish(int chain_idx) const { const LevelConstants &h = hp_.level[chain_idx]; return h.L == h.nB && h.L <= 3; }
     const int *map_ks(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ks_.p()) + chain_idx * (DMAXL + 1) * DMAXL; }
     const int *map_ksacc(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ksacc_.p()) + chain_idx * (DMAXL + 1); }
 
@@ -184,7 +188,7 @@ private:
     hipStream_t st_ = nullptr;
     std::mutex mu_;                   // ABI calls are serialised per context (thread-safe)
 
-    DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ks_, d_map_ksacc_;
+    DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ext_fin_, d_map_ks_, d_map_ksacc_, d_fin_;
     DevBuf arena_;
     size_t arena_off_ = 0;
     // Lanes: lane 0 = the main stream, lane 1 = a second stream with its own arena for work that is independent of

@@ -18,7 +18,7 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, int MODE, int T, bool RED = false>
+template <int LOGN, bool INV, int MODE, int T, bool RED = false, bool RAW = false>
 __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr)
 {
     constexpr int N = 1 << LOGN;
@@ -28,9 +28,10 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     //  measured again in round 2 for small launches: no gain, profiles/r02_ntt_latency.txt)
     if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
     else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
-    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1>(lds, p, tid, T, tab); }
-    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2>(lds, p, tid, T, tab); }
-    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 3>(lds, p, tid, T, tab); }
+    // (RAW only concerns the pass that leaves the inverse transform, the last one)
+    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1, false, RAW>(lds, p, tid, T, tab); }
+    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2, false, RAW>(lds, p, tid, T, tab); }
+    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 3, false, RAW>(lds, p, tid, T, tab); }
     if (!INV) {                                  // forward: the last pass left 16 contiguous coefficients per lane in LDS
         __syncthreads();
         for (int e = 2 * tid; e < N; e += 2 * T) {
@@ -50,9 +51,16 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
     const int tid = threadIdx.x;
     const size_t g = blockIdx.x;
-    const NttTable tab = tabs[modmap[g % (size_t)period]];
+    const int mv = modmap[g % (size_t)period];
+    const NttTable tab = tabs[mv & NTT_MAP_MASK];
     u64 *p = data + g * N;
-    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);       // wave-uniform branches
+    if (INV && (mv & NTT_MAP_RAW)) {                                            // wave-uniform branches
+        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, false, INV>(lds, p, tab, tid);
+        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, false, INV>(lds, p, tab, tid);
+        else ntt_body<LOGN, INV, NTT_WIDE, T, false, INV>(lds, p, tab, tid);
+        return;
+    }
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);
     else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
     else ntt_body<LOGN, INV, NTT_WIDE, T>(lds, p, tab, tid);
 }
@@ -879,18 +887,23 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict
 }
 
 // Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices (same values as behz_finish_coeff).
+// dq / dbsk come from an inverse NTT that left out its twist (NTT_MAP_RAW): raw lazy values, any 64-bit number; the twist
+// is part of the per-position constants fin_q / fin_b (kidx = coefficient index).
 template <int TL>
 __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ lv, const u64 *__restrict__ dq, size_t term_stride,
-                                                   int terms, const u64 *__restrict__ dbsk, size_t n, u64 *res)
+                                                   int terms, const u64 *__restrict__ dbsk, size_t n, u64 *res, size_t kidx)
 {
     constexpr int L = TL, nB = TL, nBsk = TL + 1;
     u64 xq[L];
 #pragma unroll
     for (int j = 0; j < L; j++) xq[j] = 0;
+    ShoupConst cq[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) { const u64x2 v = ldg16(reinterpret_cast<const u64 *>(lv->fin_q[j] + kidx)); cq[j] = ShoupConst{ v[0], v[1] }; }
     for (int it = 0; it < terms; it++) {
 #pragma unroll
         for (int j = 0; j < L; j++)                              // canonical: used as integers by the base conversion
-            xq[j] += mul_shoup(dq[it * term_stride + (size_t)j * n], lv->t_inv_punct_q[j].w, lv->t_inv_punct_q[j].wq, lv->q[j].q);
+            xq[j] += mul_shoup(dq[it * term_stride + (size_t)j * n], cq[j].w, cq[j].wq, lv->q[j].q);
     }
     u64 ys[nB];
     u64 fl_sk = 0;
@@ -900,7 +913,8 @@ __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ 
         u64 conv = 0;                                            // < 2 L m
 #pragma unroll
         for (int j = 0; j < L; j++) conv += lazy2(xq[j], lv->s_q_to_bsk[i][j], m);
-        const u64 xb = lazy2(dbsk[(size_t)i * n], lv->t_bsk[i], m);
+        const u64x2 cb = ldg16(reinterpret_cast<const u64 *>(lv->fin_b[i] + kidx));
+        const u64 xb = lazy2(dbsk[(size_t)i * n], ShoupConst{ cb[0], cb[1] }, m);
         const u64 diff = xb + ((u64)(2 * L) * m - conv);         // < (2L + 2) m <= 8 m < 2^64
         const u64 f = mul_shoup(diff, lv->s_fl[i].w, lv->s_fl[i].wq, m);      // i < nB: already times (B/b_i)^-1
         if (i < nB) ys[i] = f; else fl_sk = f;
@@ -938,7 +952,7 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish2(const DevLevel *__restric
     for (int i = 0; i < job.terms; i++) {
         u64 res[L];
         const u64 *dp = job.d + (((size_t)i * 3 + p) * (size_t)E) * n + k;
-        behz_finish_coeff2<TL>(lv, dp, 0, 1, dp + (size_t)L * n, n, res);
+        behz_finish_coeff2<TL>(lv, dp, 0, 1, dp + (size_t)L * n, n, res, k);
 #pragma unroll
         for (int j = 0; j < L; j++) sum[j] = addmod(sum[j], res[j], lv->q[j].q);
     }
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish_sum(const DevLevel *__rest
     const u64 *dq = job.dq + p * (size_t)L * n + k;
     const u64 *db = job.bs + p * (size_t)nBsk * n + k;
     u64 res[LMAX];
-    if constexpr (LAZY) behz_finish_coeff2<TL>(lv, dq, (size_t)3 * L * n, job.terms, db, n, res);
+    if constexpr (LAZY) behz_finish_coeff2<TL>(lv, dq, (size_t)3 * L * n, job.terms, db, n, res, k);
     else behz_finish_coeff<TL, TL>(lv, dq, (size_t)3 * L * n, job.terms, db, n, res);
     u64 *o = job.out + p * (size_t)L * n + k;
 #pragma unroll

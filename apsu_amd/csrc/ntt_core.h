@@ -150,7 +150,7 @@ HD int ntt_mode(const NttTable &tab) { return tab.narrow ? NTT_NARROW : (tab.wid
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
 // MODE: range discipline of the modulus (wave-uniform per limb): see NTT_NARROW / NTT_WIDE / NTT_WIDE_NEAR
-template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false>
+template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false, bool RAW = false>
 HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 {
     constexpr int R = 1 << K;                  // radix
@@ -255,7 +255,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
         }
     }
 
-    if (OUT == IO_GLOBAL) {                    // leaving the transform: canonical residues
+    if (OUT == IO_GLOBAL && !(INV && RAW)) {   // leaving the transform: canonical residues (RAW: the consumer applies the twist)
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
@@ -337,7 +337,7 @@ constexpr int plan_s(int logn, int p)
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
-template <int LOGN, bool INV, int MODE, int PASS, bool RED = false>
+template <int LOGN, bool INV, int MODE, int PASS, bool RED = false, bool RAW = false>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
 {
     constexpr int P = plan_passes(LOGN);
@@ -346,5 +346,5 @@ HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
     constexpr int S = plan_s(LOGN, p);
     constexpr int IN = (PASS == 0) ? IO_GLOBAL : IO_LDS;          // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED>(lds, glob, w, tab);
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW>(lds, glob, w, tab);
 }
