@@ -143,7 +143,12 @@ void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batc
 // The same for a sum of products sharing one output (eval_patstock's sum over i): a, b: [terms][2][E][n];
 // dq: [terms][3][L][n] per-term q limbs; bs: [3][nBsk][n] Bsk limbs summed over the terms
 struct TensorSumJob { const u64 *a, *b; u64 *dq, *bs; int terms; int pad; };
-void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, hipStream_t st);
+// e0: first ext limb handled (0: everything; L: only the Bsk sums, the per-term q limbs being formed by launch_intt_tensor)
+void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, int e0, hipStream_t st);
+// tensor product + inverse NTT in one launch: njobs products x 3 polys x `limbs` limbs (operand polys src_ps words apart,
+// output job.d[3][limbs][n], coefficient form), followed by n_plain limbs at `plain` transformed in place; modmap covers both
+void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st);
 struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
 void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)

@@ -124,6 +124,15 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
+        // APSU_HE_FUSE_TENSOR=1: tensor product formed by the inverse transform's load (k_intt_tensor) instead of its own
+        // kernel.  Same bits; measured level with the separate kernels at N = 1 and 1.5 % slower on the per-rank shards
+        // (profiles/r02_fuse_tensor.txt), so it is off by default.  Needs the 128-bit fold reduction for
+        // every coefficient and BEHZ modulus (true for all primes SEAL's search returns at 44..61 bits).
+        fuse_tensor_ = false;
+        if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) {
+            fuse_tensor_ = std::atoi(v) != 0;
+            for (int m = 0; m < hp_.plain_id() && m < nmod; m++) fuse_tensor_ = fuse_tensor_ && ntt_fold128_ok(tabs[m].fold_k, tabs[m].fold_c);
+        }
     }
     // level constants
     {
@@ -969,8 +978,13 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                         fj.push_back(FinishJob{ dd, slot_ptr(nd[0], b), 1, 0 });
                     }
                 }
-                { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }                 // :422/:424
-                d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
+                if (fuse_tensor_) {                                                                                              // :422/:424
+                    PROF(P_TENSOR, tj.size() * 3 * Ef);
+                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_);
+                } else {
+                    { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
+                    d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
+                }
                 { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 if (hp_.using_keyswitching && nn > 0) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
             }
@@ -1757,8 +1771,22 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j | rawf);
                         for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i) | rawf);
                         if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
-                        { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), st_); }
-                        d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
+                        if (fuse_tensor_) {
+                            // per-term q limbs: product formed by the inverse transform's load; the Bsk sums (and cf) join the launch
+                            std::vector<TensorJob> pj;
+                            for (int x = 0; x < Bs; x++)
+                                for (int i = 0; i < nin[x]; i++) {
+                                    const size_t job = (size_t)in_off[x] + i;
+                                    pj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(1 + i, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n });
+                                }
+                            { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
+                            PROF(P_TENSOR, dmap.size());
+                            launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
+                                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_);
+                        } else {
+                            { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
+                            d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
+                        }
                         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
                     } else {
                         if (late_high) {
@@ -1784,8 +1812,13 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             }
                             sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                         }
-                        if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
-                        d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
+                        if (fuse_tensor_ && tj.size() == (size_t)NI) {
+                            PROF(P_TENSOR, tj.size() * 3 * Eh);
+                            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_);
+                        } else {
+                            if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
+                            d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
+                        }
                         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                         { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
                     }

@@ -225,6 +225,7 @@ private:
         std::vector<std::array<int, 3>> nodes;           // per non-source slot: {slot, slot_p1, slot_p2}
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_, sched_low_, sched_high_;
+    bool fuse_tensor_ = false;        // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     int two_stream_mode_ = -1;
     void build_schedule();

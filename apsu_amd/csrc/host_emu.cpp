@@ -15,6 +15,29 @@
 
 using namespace apsu_he;
 
+// inverse transform whose first pass forms the dyadic tensor product while it loads (k_intt_tensor)
+template <int LOGN, int MODE, int PASS> static void emu_pass_tensor(u64 *lds, u64 *glob, int T, const NttTable &tab, const SrcTensor &ops)
+{
+    if constexpr (PASS < plan_passes(LOGN)) {
+        if constexpr (PASS == 0)           // as in ntt_body: products staged into the LDS image with coalesced loads
+            for (int tid = 0; tid < T; tid++)
+                for (int e = 2 * tid; e < (1 << LOGN); e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(ops, glob, e, tab);
+        for (int tid = 0; tid < T; tid++) {
+            if constexpr (PASS == 0) ntt_pass<LOGN, true, MODE, 0, false, false, SrcPlain, true>(lds, glob, tid, T, tab);
+            else ntt_pass<LOGN, true, MODE, PASS>(lds, glob, tid, T, tab);
+        }
+        emu_pass_tensor<LOGN, MODE, PASS + 1>(lds, glob, T, tab, ops);
+    }
+}
+
+template <int LOGN> static void emu_intt_tensor(u64 *out, const NttTable &tab, int T, const SrcTensor &ops)
+{
+    std::vector<u64> lds(lds_slots(1 << LOGN));
+    if (tab.narrow) emu_pass_tensor<LOGN, NTT_NARROW, 0>(lds.data(), out, T, tab, ops);
+    else if (tab.wide_d4) emu_pass_tensor<LOGN, NTT_WIDE_NEAR, 0>(lds.data(), out, T, tab, ops);
+    else emu_pass_tensor<LOGN, NTT_WIDE, 0>(lds.data(), out, T, tab, ops);
+}
+
 template <int LOGN, bool INV, int MODE, int PASS> static void emu_pass(u64 *lds, u64 *glob, int T, const NttTable &tab)
 {
     if constexpr (PASS < plan_passes(LOGN)) {
@@ -69,6 +92,43 @@ int emu_ntt_limb(int logn, int inverse, uint64_t q, uint64_t *data, int threads)
 #undef CASE
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// INTT(x0*y0 (+ x1*y1)) of one limb through the fused loader; x1 = y1 = NULL for a single product.  Returns -2 when the
+// modulus does not admit the 128-bit fold reduction (the engine then keeps the separate tensor kernel).
+int emu_intt_tensor_limb(int logn, uint64_t q, const uint64_t *x0, const uint64_t *y0, const uint64_t *x1, const uint64_t *y1,
+                         uint64_t *out, int threads)
+{
+    try {
+        size_t n = (size_t)1 << logn;
+        HeParams hp = HeParams::Create(n, { q }, 65537 < q ? 65537 : 3);
+        const NttTablesHost &t = hp.ntt[0];
+        std::vector<TwPair> fwd(n), dit(n), sc(n);
+        for (size_t k = 0; k < n; k++) {
+            fwd[k] = { t.fwd[k], t.fwd_q[k] };
+            dit[k] = { t.dit[k], t.dit_q[k] }; sc[k] = { t.scale[k], t.scale_q[k] };
+        }
+        NttTable tab{ q, t.ninv, t.ninv_q, t.mod.ratio[1], fwd.data(), dit.data(), sc.data(), ntt_is_narrow(q, logn) ? 1 : 0, 0, 0, 0 };
+        ntt_fold_params(q, tab.fold_k, tab.fold_c);
+        tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
+        if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return -2;
+        const SrcTensor ops{ x0, y0, x1, y1 };
+#define CASE(L) case L: emu_intt_tensor<L>(out, tab, threads, ops); break;
+        switch (logn) { CASE(14) CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
+#undef CASE
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// ntt_reduce128_fold on explicit (hi, lo) pairs; returns 0 when the modulus does not admit it
+int emu_reduce128(uint64_t q, const uint64_t *hi, const uint64_t *lo, uint64_t *out, int count)
+{
+    NttTable tab{};
+    tab.q = q;
+    ntt_fold_params(q, tab.fold_k, tab.fold_c);
+    if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return 0;
+    for (int i = 0; i < count; i++) out[i] = ntt_reduce128_fold(hi[i], lo[i], tab);
+    return (int)tab.fold_k;
 }
 
 // ntt_reduce_any (the fold / Barrett final reduction of the NTT kernels) on explicit values; returns fold_k

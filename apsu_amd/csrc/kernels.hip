@@ -6,6 +6,7 @@
 // butterflies and dyadic products (BASELINE.json north_star).
 #include "device.h"
 #include <cstdlib>
+#include <type_traits>
 
 #include <algorithm>
 
@@ -18,8 +19,9 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, int MODE, int T, bool RED = false, bool RAW = false>
-__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr)
+template <int LOGN, bool INV, int MODE, int T, bool RED = false, bool RAW = false, class SRC = SrcPlain>
+__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr,
+                                         const SRC &operands = SRC())
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
@@ -27,7 +29,14 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     //  line is consumed by the wave's eight consecutive loads.  Staging the limb through LDS with coalesced loads first was
     //  measured again in round 2 for small launches: no gain, profiles/r02_ntt_latency.txt)
     if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
-    else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
+    else if constexpr (!std::is_same<SRC, SrcPlain>::value) {
+        // computed input (tensor product on load): four operand streams read with the first pass's 128-byte lane stride
+        // thrash the vector L1 (measured: the fused launch 65 % slower than tensor + transform apart), so the products are
+        // formed with coalesced 16-byte loads into the LDS image and the first pass starts from there
+        for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
+        __syncthreads();
+        ntt_pass<LOGN, INV, MODE, 0, false, false, SrcPlain, true>(lds, p, tid, T, tab);
+    } else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
     // (RAW only concerns the pass that leaves the inverse transform, the last one)
     if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1, false, RAW>(lds, p, tid, T, tab); }
     if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2, false, RAW>(lds, p, tid, T, tab); }
@@ -92,6 +101,70 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
 #undef G_CASE
+    KERNEL_CHECK();
+}
+
+// Inverse NTT of dyadic tensor products (BEHZ steps 4 + 5 in one launch): workgroup g < n_tensor owns output limb
+// (job, poly p of 3, limb e of `limbs`) of product job = g / (3*limbs), forms d_p = a0*b0 | a0*b1 + a1*b0 | a1*b1 in limb e from
+// the NTT-form operands while it loads (SrcTensor) and writes the coefficient-form limb to job.d[p][e]: the tensor kernel,
+// its 3*E limb writes and the transform's re-read of them are gone.  Workgroups g >= n_tensor transform
+// plain[g - n_tensor] in place (limbs that join the same launch).  Operand polys are src_ps words apart.
+// Requires ntt_fold128_ok for every modulus in the map (the host checks; otherwise k_tensor + k_ntt run).
+template <int LOGN, int T>
+__global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
+                                                   u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
+                                                   const int *__restrict__ modmap, int period)
+{
+    constexpr int N = 1 << LOGN;
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const int mv = modmap[g % (size_t)period];
+    const NttTable tab = tabs[mv & NTT_MAP_MASK];
+    if (g >= n_tensor) {                                                        // wave-uniform
+        u64 *p = plain + (g - n_tensor) * N;
+        if (mv & NTT_MAP_RAW) {
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, true>(lds, p, tab, tid);
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, true>(lds, p, tab, tid);
+            else ntt_body<LOGN, true, NTT_WIDE, T, false, true>(lds, p, tab, tid);
+        } else {
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T>(lds, p, tab, tid);
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
+            else ntt_body<LOGN, true, NTT_WIDE, T>(lds, p, tab, tid);
+        }
+        return;
+    }
+    const size_t per = (size_t)3 * limbs, jb = g / per;
+    const int r = (int)(g - jb * per), pl = r / limbs, e = r - pl * limbs;
+    const TensorJob job = jobs[jb];
+    const u64 *a0 = job.a + (size_t)e * N, *a1 = a0 + src_ps, *b0 = job.b + (size_t)e * N, *b1 = b0 + src_ps;
+    SrcTensor ops;
+    if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr };
+    else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0 };
+    else ops = SrcTensor{ a1, b1, nullptr, nullptr };
+    u64 *p = job.d + (size_t)r * N;
+    if (mv & NTT_MAP_RAW) {
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+    } else {
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+    }
+}
+
+void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st)
+{
+    const size_t n_tensor = (size_t)njobs * 3 * limbs, count = n_tensor + n_plain;
+    if (!count) return;
+#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period); break;
+    switch (logn) {
+    T_CASE(14, 1024) T_CASE(13, 512) T_CASE(12, 256) T_CASE(11, 128) T_CASE(10, 64) T_CASE(8, 64) T_CASE(6, 64)
+    default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+#undef T_CASE
     KERNEL_CHECK();
 }
 
@@ -743,12 +816,13 @@ void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batc
 
 // Step (4) for a SUM of products (eval_patstock's sum over i): the q limbs of every term are kept (their canonical
 // coefficient-form residues are needed per term by the finish), the Bsk limbs are summed here in the NTT domain.
-__global__ __launch_bounds__(EW_T) void k_tensor_sum(const DevLevel *__restrict__ lv, const TensorSumJob *__restrict__ jobs, size_t n)
+// e0 = L: only the Bsk sums (the per-term q limbs are formed by k_intt_tensor on load).
+__global__ __launch_bounds__(EW_T) void k_tensor_sum(const DevLevel *__restrict__ lv, const TensorSumJob *__restrict__ jobs, size_t n, int e0)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
     const TensorSumJob job = jobs[blockIdx.z];
-    const int E = lv->E, L = lv->L, e = blockIdx.y;
+    const int E = lv->E, L = lv->L, e = blockIdx.y + e0;
     const size_t ps = (size_t)E * n, o = (size_t)e * n + k;
     const Mod m = lv->ext[e];
     if (e < L) {
@@ -787,10 +861,10 @@ __global__ __launch_bounds__(EW_T) void k_tensor_sum(const DevLevel *__restrict_
     }
 }
 
-void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, hipStream_t st)
+void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, int e0, hipStream_t st)
 {
-    if (!njobs) return;
-    hipLaunchKernelGGL(k_tensor_sum, dim3((unsigned)((n + EW_T - 1) / EW_T), E, njobs), dim3(EW_T), 0, st, lv, jobs, n);
+    if (!njobs || e0 >= E) return;
+    hipLaunchKernelGGL(k_tensor_sum, dim3((unsigned)((n + EW_T - 1) / EW_T), E - e0, njobs), dim3(EW_T), 0, st, lv, jobs, n, e0);
     KERNEL_CHECK();
 }
 

@@ -89,6 +89,50 @@ HD u64 ntt_reduce_any(u64 x, const NttTable &tab)
     return v >= tab.q ? v - tab.q : v;
 }
 
+// Canonical residue of a 128-bit P = hi*2^64 + lo < 2^(2k+1) for q = 2^k - c with 44 <= k <= 61 and c < 2^24 (ntt_fold128_ok):
+// P = Ph*2^k + Pl = Ph*c + Pl; Ph*c is taken in two 32-bit halves of Ph, the upper product T (< 2^(k-7)) is folded once more
+// at its own bit k-32, and every partial sum stays below 2^64:  Pl + A + Th*c + (Tl << 32) < 2^61 + 2^56 + 2^49 + 2^61.
+// Five narrow multiplies and no quotient word, against ~12 for the two-word Barrett step.
+HD bool ntt_fold128_ok(u32 fold_k, u32 fold_c) { return fold_k >= 44 && fold_k <= 61 && fold_c < (1u << 24); }
+HD u64 ntt_reduce128_fold(u64 hi, u64 lo, const NttTable &tab)
+{
+    const u32 k = tab.fold_k, c = tab.fold_c, s = k - 32;
+    const u64 pl = lo & (((u64)1 << k) - 1);
+    const u64 ph = (hi << (64 - k)) | (lo >> k);                 // < 2^(k+1)
+    const u64 a = (u64)(u32)ph * c;
+    const u64 t = (u64)(u32)(ph >> 32) * c;
+    const u64 w = pl + a + (u64)(u32)(t >> s) * c + ((t & (((u64)1 << s) - 1)) << 32);
+    return ntt_reduce_any(w, tab);
+}
+
+// Where a pass that reads global memory takes its coefficients from.
+struct SrcPlain {};                                               // the limb itself
+// The dyadic tensor product of two NTT-form ciphertexts, computed on load in front of the inverse transform
+// (BEHZ step 4, d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1): value(e) = x0[e]*y0[e] (+ x1[e]*y1[e]) mod q.
+struct SrcTensor { const u64 *x0, *y0, *x1, *y1; };               // x1 == nullptr: one product
+HD u64x2 src_load2(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return *reinterpret_cast<const u64x2 *>(glob + e); }
+HD u64 src_load1(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return glob[e]; }
+HD u64x2 src_load2(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
+{
+    const u64x2 x = ldg16(s.x0 + e), y = ldg16(s.y0 + e);
+    u128p p0 = mul128(x[0], y[0]), p1 = mul128(x[1], y[1]);
+    if (s.x1) {                                                   // wave-uniform
+        const u64x2 u = ldg16(s.x1 + e), v = ldg16(s.y1 + e);
+        mac128(p0, u[0], v[0]);
+        mac128(p1, u[1], v[1]);
+    }
+    u64x2 r;
+    r[0] = ntt_reduce128_fold(p0.hi, p0.lo, tab);
+    r[1] = ntt_reduce128_fold(p1.hi, p1.lo, tab);
+    return r;
+}
+HD u64 src_load1(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
+{
+    u128p p = mul128(s.x0[e], s.y0[e]);
+    if (s.x1) mac128(p, s.x1[e], s.y1[e]);
+    return ntt_reduce128_fold(p.hi, p.lo, tab);
+}
+
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
 // makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).
 HD int lds_slot(int e) { return e + ((e >> 4) << 1); }
@@ -150,8 +194,8 @@ HD int ntt_mode(const NttTable &tab) { return tab.narrow ? NTT_NARROW : (tab.wid
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
 // MODE: range discipline of the modulus (wave-uniform per limb): see NTT_NARROW / NTT_WIDE / NTT_WIDE_NEAR
-template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false, bool RAW = false>
-HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
+template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false, bool RAW = false, class SRC = SrcPlain>
+HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab, const SRC &src = SRC())
 {
     constexpr int R = 1 << K;                  // radix
     constexpr int G = 16 >> K;                 // independent groups per thread
@@ -182,7 +226,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int g = 0; g < G; g += 2) {
                 const int e = idx(g, j);
-                const u64x2 v = (IN == IO_GLOBAL) ? *reinterpret_cast<const u64x2 *>(glob + e)
+                const u64x2 v = (IN == IO_GLOBAL) ? src_load2(src, glob, e, tab)
                                                    : *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
                 r[g][j] = v[0]; r[g + 1][j] = v[1];
             }
@@ -192,7 +236,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int j = 0; j < R; j += 2) {
                 const int e = idx(g, j);
-                const u64x2 v = (IN == IO_GLOBAL) ? *reinterpret_cast<const u64x2 *>(glob + e)
+                const u64x2 v = (IN == IO_GLOBAL) ? src_load2(src, glob, e, tab)
                                                    : *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
                 r[g][j] = v[0]; r[g][j + 1] = v[1];
             }
@@ -202,7 +246,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab)
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 const int e = idx(g, j);
-                r[g][j] = (IN == IO_GLOBAL) ? glob[e] : lds[lds_slot(e)];
+                r[g][j] = (IN == IO_GLOBAL) ? src_load1(src, glob, e, tab) : lds[lds_slot(e)];
             }
     }
 
@@ -337,14 +381,15 @@ constexpr int plan_s(int logn, int p)
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
-template <int LOGN, bool INV, int MODE, int PASS, bool RED = false, bool RAW = false>
-HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab)
+// STAGED: the caller has already put the input into the LDS image (k_intt_tensor forms its products with coalesced loads).
+template <int LOGN, bool INV, int MODE, int PASS, bool RED = false, bool RAW = false, class SRC = SrcPlain, bool STAGED = false>
+HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab, const SRC &src = SRC())
 {
     constexpr int P = plan_passes(LOGN);
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
     constexpr int K = plan_k(LOGN, p);
     constexpr int S = plan_s(LOGN, p);
-    constexpr int IN = (PASS == 0) ? IO_GLOBAL : IO_LDS;          // both directions read the limb straight from global memory
+    constexpr int IN = (PASS == 0 && !STAGED) ? IO_GLOBAL : IO_LDS;   // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW>(lds, glob, w, tab);
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW, SRC>(lds, glob, w, tab, src);
 }

@@ -293,6 +293,58 @@ def test_partition_rule_of_the_c_abi_matches_the_bench_sharding():
         apsu_amd.partition_bundles([(5, 0, 1)], 4, 2)
 
 
+def test_tensor_fold128_reduction(emu):
+    """ntt_reduce128_fold: P mod q for every 128-bit P < 2^(2k+1), the range of a0*b1 + a1*b0 with canonical operands;
+    all primes of the 36 parameter files that admit it (44..61 bits, c < 2^24), against Python integers, extremes included"""
+    primes = set()
+    for name in ALL_PARAM_FILES:
+        Cx = ref.RefContext.from_params(ref.load_params(common.param_json(name)))
+        primes.update(Cx.q)
+        primes.update([Cx.m_sk, Cx.gamma] + list(Cx.B))
+    rng = np.random.default_rng(12)
+    used = 0
+    for q in sorted(primes):
+        k = q.bit_length()
+        ps = [0, 1, q - 1, q, (q - 1) * (q - 1), 2 * (q - 1) * (q - 1), (1 << (2 * k + 1)) - 1, (1 << (2 * k)) - 1, 1 << (2 * k),
+              (1 << k) - 1, 1 << k, ((1 << (k + 1)) - 1) << k, (1 << 64) - 1, 1 << 64, ((1 << 32) - 1) << k, ((1 << (k + 1)) - 1) << k | ((1 << k) - 1)]
+        for _ in range(300):
+            a, b, c, d = (int(v) % q for v in rng.integers(0, 1 << 63, 4, dtype=np.uint64))
+            ps += [a * b, a * b + c * d]
+        hi = np.array([v >> 64 for v in ps], dtype=np.uint64); lo = np.array([v & ((1 << 64) - 1) for v in ps], dtype=np.uint64)
+        out = np.zeros_like(lo)
+        fk = emu.emu_reduce128(C.c_uint64(q), hi.ctypes.data_as(u64p), lo.ctypes.data_as(u64p), out.ctypes.data_as(u64p), len(ps))
+        if k < 44:
+            assert fk == 0
+            continue
+        assert fk == k, hex(q)
+        used += 1
+        assert [int(v) for v in out] == [v % q for v in ps], hex(q)
+    assert used >= 10
+
+
+@pytest.mark.parametrize("n,bits", [(64, 50), (256, 60), (1024, 56), (4096, 48), (8192, 56), (8192, 60), (16384, 58)])
+def test_intt_tensor_loader_emulation(emu, n, bits):
+    """k_intt_tensor's first pass: the inverse transform that forms x0*y0 (+ x1*y1) mod q while it loads equals the
+    inverse transform of the products (both through the kernel's own pass functions, stepped on the CPU)"""
+    logn = n.bit_length() - 1
+    c = ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20)
+    q = c.q[0]
+    rng = np.random.default_rng(n + bits)
+    x0, y0, x1, y1 = (rng.integers(0, q, n, dtype=np.uint64) for _ in range(4))
+    x0[:4] = [0, q - 1, q - 1, 1]; y0[:4] = [q - 1, q - 1, 0, 1]; x1[:2] = [q - 1, q - 1]; y1[:2] = [q - 1, q - 1]
+    T = 1024 if n == 16384 else (512 if n == 8192 else 64)
+    for cross in (False, True):
+        out = np.zeros(n, dtype=np.uint64)
+        null = C.POINTER(C.c_uint64)()
+        rc = emu.emu_intt_tensor_limb(logn, C.c_uint64(q), x0.ctypes.data_as(u64p), y0.ctypes.data_as(u64p),
+                                      x1.ctypes.data_as(u64p) if cross else null, y1.ctypes.data_as(u64p) if cross else null,
+                                      out.ctypes.data_as(u64p), T)
+        assert rc == 0, emu.emu_last_error()
+        prod = np.array([(int(a) * int(b) + (int(u) * int(v) if cross else 0)) % q for a, b, u, v in zip(x0, y0, x1, y1)], dtype=np.uint64)
+        assert emu.emu_ntt_limb(logn, 1, C.c_uint64(q), prod.ctypes.data_as(u64p), T) == 0
+        assert (out == prod).all()
+
+
 def test_ntt_final_reduction_fold_and_barrett(emu):
     """ntt_reduce_any: x mod q for ANY 64-bit x.  Primes of the shape 2^k - c (all of SEAL's coefficient and BEHZ primes
     of 33 bits and more) take the one-multiply fold, the others Barrett; both against Python integers, extremes included"""
