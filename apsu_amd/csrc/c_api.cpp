@@ -231,6 +231,14 @@ int apsu_he_set_eval_pipeline(apsu_he_ctx *c, int groups)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_eval_pipeline(groups); }); }
 int apsu_he_mask_generate(apsu_he_ctx *c, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks)
 { return guarded([&] { REQUIRE(c && (masks_dev || !count), "null argument"); c->eng->mask_generate(seed, count, masks_dev, values, blocks); }); }
+int apsu_he_mask_generate_blake2xb(apsu_he_ctx *c, const uint64_t *seed, uint64_t first_value, uint32_t count, uint64_t *masks_dev,
+                                   uint64_t *values, uint64_t *blocks)
+{
+    return guarded([&] {
+        REQUIRE(c && seed && (masks_dev || !count), "null argument");
+        c->eng->mask_generate_blake2xb(seed, first_value, count, masks_dev, values, blocks);
+    });
+}
 int apsu_he_decrypt_decode(apsu_he_ctx *c, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
                            uint64_t *values, uint64_t *blocks)
 { return guarded([&] { REQUIRE(c && sk_ntt && (cts || !count), "null argument"); c->eng->decrypt_decode(sk_ntt, cts, cts_on_device != 0, count, values, blocks); }); }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "modmath.h"
 #include "ntt_core.h"
+#include "blake2x.h"
 
 namespace apsu_he {
 
@@ -122,6 +123,8 @@ void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st
 // drop last limb of `polys` polynomials per job: src [polys][L][n] -> dst [polys][L-1][n]
 void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
+// out[i] = (the (first + i)-th 32-bit output of SEAL's Blake2xb generator under `seed`) % bound
+void launch_fill_blake2xb(u64 *out, size_t words, const Blake2xbSeed &seed, u64 first, u64 bound, hipStream_t st);
 // N1: BinBundle build (polyn_with_roots per bin, BatchEncoder scatter, monomial detection)
 void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
                              hipStream_t st);

@@ -1391,6 +1391,19 @@ static uint32_t plain_modulus_len(u64 t)
 
 void Engine::mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host)
 {
+    mask_generate_impl(count, masks_dev, values_host, blocks_host, [&](u64 *vals, size_t words) { launch_fill_random(vals, words, seed, hp_.t, st_); });
+}
+
+void Engine::mask_generate_blake2xb(const u64 seed[8], u64 first_value, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host)
+{
+    Blake2xbSeed sd;
+    for (int i = 0; i < 8; i++) sd.w[i] = seed[i];
+    mask_generate_impl(count, masks_dev, values_host, blocks_host,
+                       [&](u64 *vals, size_t words) { launch_fill_blake2xb(vals, words, sd, first_value, hp_.t, st_); });
+}
+
+void Engine::mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill)
+{
     Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (!hp_.batching) throw std::logic_error("plain_modulus does not support batching");
@@ -1401,7 +1414,7 @@ void Engine::mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values
     TIER1_SLOTS();
     WITH_ARENA({
         u64 *vals = ws((size_t)count * n);
-        { PROF(P_OTHER, 0); launch_fill_random(vals, (size_t)count * n, seed, hp_.t, st_); }                       // :248-251
+        { PROF(P_OTHER, 0); fill(vals, (size_t)count * n); }                                                       // :248-251
         // BatchEncoder::encode (:271): slot permutation, inverse negacyclic NTT mod t
         { PROF(P_OTHER, 0); launch_scatter_slots(vals, reinterpret_cast<const uint32_t *>(d_slot_map_.p()), masks_dev, n, (int)count, st_); }
         d_ntt(masks_dev, count, map_ct() + tid, 1, true);

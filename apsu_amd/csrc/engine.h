@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -124,6 +125,8 @@ public:
     // N4: mask generation + block packing (receiver_osn.cpp:53-73,217-284) and the querier's
     // decrypt + decode + packing (result_package.cpp:175-213 ; sender_osn.cpp:675-700)
     void mask_generate(u64 seed, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host);
+    // the same with the reference's generator: SEAL's Blake2xb PRNG under `seed`, starting at its first_value-th 32-bit output
+    void mask_generate_blake2xb(const u64 seed[8], u64 first_value, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host);
     void decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_device, uint32_t count, u64 *values_host, u64 *blocks_host);
     // test hook: stored form of coefficient d.  kind: 0 = raw mod t (d = 0), 1 = NTT form at pt_level,
     // 2 = pre-lifted + NTT at the high level (coefficient-form a_{i*h}); returns words written
@@ -225,6 +228,7 @@ private:
         std::vector<std::array<int, 3>> nodes;           // per non-source slot: {slot, slot_p1, slot_p2}
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_, sched_low_, sched_high_;
+    void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
     bool fuse_tensor_ = false;        // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     int two_stream_mode_ = -1;

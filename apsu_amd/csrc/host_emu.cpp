@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ntt_core.h"
+#include "blake2x.h"
 #include "params.h"
 #include "powers_dag.h"
 
@@ -118,6 +119,21 @@ int emu_intt_tensor_limb(int logn, uint64_t q, const uint64_t *x0, const uint64_
 #undef CASE
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// `count` 32-bit outputs of the Blake2xb generator (blake2x.h, the code k_fill_blake2xb runs) starting at output `first`
+int emu_blake2xb_values(const uint64_t *seed, uint64_t first, uint32_t *out, int count)
+{
+    Blake2xbSeed sd;
+    for (int i = 0; i < 8; i++) sd.w[i] = seed[i];
+    u64 blk[8];
+    u64 have = ~(u64)0;
+    for (int i = 0; i < count; i++) {
+        const u64 g = first + (u64)i;
+        if (g / 16 != have) { have = g / 16; blake2xb_stream_block(sd, have, blk); }
+        out[i] = blake2xb_stream_u32(blk, (unsigned)(g % 16));
+    }
+    return 0;
 }
 
 // ntt_reduce128_fold on explicit (hi, lo) pairs; returns 0 when the modulus does not admit it

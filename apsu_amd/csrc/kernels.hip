@@ -455,6 +455,31 @@ void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t
     KERNEL_CHECK();
 }
 
+// Mask values as the reference draws them (receiver_osn.cpp:221-224,248-251): SEAL's Blake2xb generator under a 64-byte seed,
+// out[i] = generate() % bound with the 32-bit generate(), i = the (first + i)-th output of the generator.  One lane per
+// 64-byte stream block (16 values): it derives the root hash of its 4096-byte buffer and its own expansion node (3 BLAKE2b
+// compressions; the redundant root hashes are ~2 us of work for a whole query's masks).
+__global__ __launch_bounds__(EW_T) void k_fill_blake2xb(u64 *__restrict__ out, size_t words, Blake2xbSeed seed, u64 first, u64 bound)
+{
+    const u64 sb = first / 16 + (u64)blockIdx.x * EW_T + threadIdx.x;       // stream block of this lane
+    if (sb * 16 >= first + words) return;
+    u64 blk[8];
+    blake2xb_stream_block(seed, sb, blk);
+#pragma unroll
+    for (unsigned j = 0; j < 16; j++) {
+        const u64 g = sb * 16 + j;
+        if (g >= first && g < first + words) out[g - first] = (u64)blake2xb_stream_u32(blk, j) % bound;
+    }
+}
+
+void launch_fill_blake2xb(u64 *out, size_t words, const Blake2xbSeed &seed, u64 first, u64 bound, hipStream_t st)
+{
+    if (!words) return;
+    const u64 blocks = (first + words + 15) / 16 - first / 16;
+    hipLaunchKernelGGL(k_fill_blake2xb, dim3((unsigned)((blocks + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, out, words, seed, first, bound);
+    KERNEL_CHECK();
+}
+
 // ============================================================================ N1: BinBundle build on the GPU
 // polyn_with_roots (common/apsu/util/interpolate.cpp:27-80) for every bin of a BinBundle.  One WAVE per bin: the
 // monic polynomial lives in registers, coefficient i in lane i % 64, slot i / 64, so multiplying by (x - a) is one

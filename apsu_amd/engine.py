@@ -340,6 +340,19 @@ class HeContext:
                                                     _p(vals) if want_values else None, _p(blks) if want_blocks else None))
         return vals, blks
 
+    def mask_generate_blake2xb(self, seed, count, masks_dev, first_value=0, want_values=True, want_blocks=True):
+        """N4 with the reference's generator: SEAL's Blake2xb PRNG under the eight 64-bit words `seed`
+        (receiver_osn.cpp:221-224, 248-251), starting at its first_value-th 32-bit output.  Same outputs as mask_generate."""
+        sd = np.ascontiguousarray(seed, dtype=np.uint64)
+        if sd.size != 8:
+            raise ValueError("seed must be eight 64-bit words")
+        vals = np.empty((count, self.n), dtype=np.uint64) if want_values else None
+        blks = np.empty((count, self.info.items_per_bundle, 2), dtype=np.uint64) if want_blocks else None
+        _check(load_library().apsu_he_mask_generate_blake2xb(self.h, _p(sd), C.c_uint64(first_value), C.c_uint32(count),
+                                                             C.c_void_p(int(masks_dev)), _p(vals) if want_values else None,
+                                                             _p(blks) if want_blocks else None))
+        return vals, blks
+
     def decrypt_decode(self, sk_ntt, cts, count=None, on_device=False, want_blocks=True):
         """N4: the querier's decrypt + decode + packing of `count` results (result_package.cpp:175-213).
         sk_ntt: secret key mod q_0 in NTT form [n]; cts: [count][2][1][n] array, or a device pointer with on_device."""

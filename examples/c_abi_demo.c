@@ -2,7 +2,7 @@
  *   gcc -O2 -Iinclude examples/c_abi_demo.c -Lapsu_amd -lapsu_he_gpu -Wl,-rpath,$PWD/apsu_amd -o c_abi_demo
  *   ./c_abi_demo tests/params/1M-1024-com.json
  * Runs the tier-1 NTT round trip, the tier-2 path (ComputePowers + eval_bundles on a synthetic BinBundle with a
- * mask drawn by apsu_he_mask_generate), the multi-device handle (apsu_he_multi_* / apsu_he_eval_all on devices {0, 0}:
+ * mask drawn by apsu_he_mask_generate_blake2xb, the reference's generator), the multi-device handle (apsu_he_multi_* / apsu_he_eval_all on devices {0, 0}:
  * two engines on one GPU) and the N3 framing of a ResultPackage, and prints FNV-1a checksums of every result.  tests/test_gpu_c_host.py builds
  * it, runs it, and compares the checksums with the same calls made through the Python binding. */
 #include <stdio.h>
@@ -90,7 +90,9 @@ int main(int argc, char **argv)
     uint64_t *mask_dev = NULL;
     if (hipMalloc((void **)&mask_dev, n * 8) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
     uint64_t *blocks = (uint64_t *)malloc((size_t)info.items_per_bundle * 2 * 8);
-    CHECK(apsu_he_mask_generate(ctx, 99, 1, mask_dev, NULL, blocks));
+    uint64_t prng_seed[8];                                      /* seal::prng_seed_type; the reference fills it with random_bytes */
+    for (int i = 0; i < 8; i++) prng_seed[i] = mix(99 + i);
+    CHECK(apsu_he_mask_generate_blake2xb(ctx, prng_seed, 0, 1, mask_dev, NULL, blocks));
     printf("blocks %016llx\n", (unsigned long long)fnv(blocks, (size_t)info.items_per_bundle * 16));
     uint64_t *out = (uint64_t *)malloc(2 * n * 8);
     const apsu_he_bundle *bl[1] = { bundle };

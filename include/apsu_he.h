@@ -150,6 +150,16 @@ int apsu_he_bundle_load(apsu_he_ctx *ctx, const uint8_t *buf, uint64_t size, aps
  * form (n words, host).  The rounding is the exact round(t*x/q_0): equal to SEAL's decrypt for every
  * ciphertext with a positive noise budget. */
 int apsu_he_mask_generate(apsu_he_ctx *ctx, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks);
+/* The same with the reference's own generator (receiver_osn.cpp:221-224: UniformRandomGeneratorInfo(prng_type::blake2xb,
+ * seed).make_prng(); :248-251: `generate() % plain_modulus`, generate() being SEAL's 32-bit draw): seed = the eight words of
+ * seal::prng_seed_type (the reference fills them with random_bytes); value(c, i) = (output number first_value + c*n + i of that
+ * generator) % plain_modulus, so one call with first_value = 0 over the BinBundles in the reference's loop order
+ * (cache_idx outer, bundle_idx inner, padded caches skipped) reproduces its masks for the same seed, and several calls
+ * can continue one stream.  BLAKE2b is checked against RFC 7693 / hashlib; the BLAKE2X expansion and SEAL's buffering
+ * (4096-byte buffers keyed by the seed, message = buffer counter) are restated from their published sources — unpinned,
+ * like every other SEAL-derived detail. */
+int apsu_he_mask_generate_blake2xb(apsu_he_ctx *ctx, const uint64_t seed[8], uint64_t first_value, uint32_t count, uint64_t *masks_dev,
+                                   uint64_t *values, uint64_t *blocks);
 int apsu_he_decrypt_decode(apsu_he_ctx *ctx, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
                            uint64_t *values, uint64_t *blocks);
 /* test hooks: degree of the batched polynomial; stored form of coefficient `degree`

@@ -68,7 +68,7 @@ def test_c_program_matches_python_binding(tmp_path):
     pw = G.compute_powers([0], [[src[s] for s in range(ns)]], rk)
     bundle = G.random_bundle(0, 0, G.max_items_per_bin - 1, 4242)
     buf = torch.empty(n, dtype=torch.int64, device="cuda")
-    _, blocks = G.mask_generate(99, 1, buf.data_ptr(), want_values=False)
+    _, blocks = G.mask_generate_blake2xb([int(mix(np.uint64(99 + i))) for i in range(8)], 1, buf.data_ptr(), want_values=False)
     assert lines["blocks"] == fnv(blocks)
     out = G.eval_bundles([bundle], pw, rk, [buf.data_ptr()], masks_on_device=True)
     assert lines["result"] == fnv(out)

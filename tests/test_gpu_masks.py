@@ -45,6 +45,38 @@ def test_mask_generate_16M_params():
     _masks(G, C, 5, 77, 2)
 
 
+@pytest.mark.parametrize("cfg", ["toy", "16M-4096", "1M-1024-com"])
+def test_mask_generate_blake2xb_stream(cfg):
+    """the reference's generator (receiver_osn.cpp:221-224,248-251): SEAL's Blake2xb PRNG under a 64-byte seed, 32-bit draws
+    % plain_modulus, against the Python model of it (oracle/blake2x.py); encode and packing as for the other generator;
+    a second call continues the stream where the first stopped"""
+    from oracle import blake2x
+    js = common.toy_json(felts=5) if cfg == "toy" else common.param_json(cfg)
+    C = ref.RefContext.from_params(ref.load_params(js))
+    G = apsu_amd.HeContext(js)
+    felts = ref.load_params(js)["felts_per_item"]
+    n, count = G.n, 3
+    seed = [(0x0123456789abcdef * (i + 3)) & ((1 << 64) - 1) for i in range(8)]
+    model = np.array(blake2x.Blake2xbPRNG(seed).values(max((count + 1) * n, 1021 + n)), dtype=np.uint64) % np.uint64(G.t)
+    buf = torch.empty((count + 1) * n, dtype=torch.int64, device="cuda")
+    vals, blks = G.mask_generate_blake2xb(seed, count, buf.data_ptr())
+    vals2, _ = G.mask_generate_blake2xb(seed, 1, buf.data_ptr() + count * n * 8, first_value=count * n)
+    torch.cuda.synchronize()
+    enc = buf.cpu().numpy().view(np.uint64).reshape(count + 1, n)
+    assert (vals.reshape(-1) == model[: count * n]).all()
+    assert (vals2.reshape(-1) == model[count * n:(count + 1) * n]).all()
+    for c in range(count):
+        assert (enc[c] == C.encode(vals[c])).all()
+        assert (blks[c] == C.vec_to_oc_block(vals[c], felts)[: blks.shape[1]]).all()
+    assert (enc[count] == C.encode(vals2[0])).all()
+    # an unaligned continuation (not a multiple of the 16 values of a BLAKE2b block)
+    v3, _ = G.mask_generate_blake2xb(seed, 1, buf.data_ptr(), first_value=1021, want_blocks=False)
+    assert (v3[0] == model[1021:1021 + n]).all()
+    with pytest.raises(ValueError):
+        G.mask_generate_blake2xb(seed[:7], 1, buf.data_ptr())
+    G.close()
+
+
 def test_loopback_masks_eval_decrypt():
     """all-GPU loopback: masks drawn on the device, evaluation with device-resident masks, the querier's
     decrypt/decode/packing on the device; every stage equals the oracle and the plaintext meaning holds"""

@@ -293,6 +293,49 @@ def test_partition_rule_of_the_c_abi_matches_the_bench_sharding():
         apsu_amd.partition_bundles([(5, 0, 1)], 4, 2)
 
 
+def test_blake2b_model_against_hashlib_and_rfc():
+    """oracle/blake2x.py: the BLAKE2b core (own compression function, explicit parameter block incl. the xof_length field
+    BLAKE2X puts into the upper half of node_offset) equals hashlib over keys, salts, personalisation and tree parameters"""
+    import hashlib, random
+    from oracle import blake2x as B
+    abc = B.blake2b(b"abc", B.param_block())
+    assert abc.hex() == ("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+                         "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")          # RFC 7693 appendix A
+    rng = random.Random(7)
+    for trial in range(200):
+        data = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 8, 63, 64, 127, 128, 129, 256, 257, 700])))
+        key = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 0, 1, 32, 64])))
+        ds = rng.choice([1, 16, 32, 48, 64])
+        salt = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 16]))); person = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 16])))
+        fan, depth, leaf = rng.choice([0, 1, 2, 255]), rng.choice([1, 2, 255]), rng.choice([0, 64, 1 << 20])
+        noff = rng.getrandbits(64) if rng.random() < 0.5 else rng.getrandbits(6) | (4096 << 32)
+        nd, inner = rng.choice([0, 1, 5]), rng.choice([0, 32, 64])
+        want = hashlib.blake2b(data, digest_size=ds, key=key, salt=salt, person=person, fanout=fan, depth=depth, leaf_size=leaf,
+                               node_offset=noff, node_depth=nd, inner_size=inner).digest()
+        assert B.blake2b(data, B.param_block(ds, len(key), fan, depth, leaf, noff & 0xffffffff, noff >> 32, nd, inner, salt, person), key) == want
+    # the expansion with depth 1 instead of 0 is expressible in hashlib: same construction, one parameter byte apart
+    seed, msg = bytes(range(64)), (5).to_bytes(8, "little")
+    root = hashlib.blake2b(msg, digest_size=64, key=seed, node_offset=4096 << 32).digest()
+    assert root == B.blake2b(msg, B.param_block(64, 64, 1, 1, 0, 0, 4096, 0, 0), seed)
+    for i in (0, 1, 63):
+        want = hashlib.blake2b(root, digest_size=64, fanout=0, depth=1, leaf_size=64, node_offset=i | (4096 << 32), inner_size=64).digest()
+        assert want == B.blake2b(root, B.param_block(64, 0, 0, 1, 64, i, 4096, 0, 64))
+
+
+def test_blake2xb_generator_code_matches_model(emu):
+    """apsu_amd/csrc/blake2x.h (the code the mask kernel runs) against the Python model of SEAL's Blake2xbPRNG:
+    buffer boundaries (1024 values per 4096-byte buffer), arbitrary starting offsets"""
+    from oracle import blake2x as B
+    u32p = C.POINTER(C.c_uint32)
+    for seed in ([0] * 8, list(range(1, 9)), [(0x9e3779b97f4a7c15 * (i + 1)) & ((1 << 64) - 1) for i in range(8)]):
+        sd = np.array(seed, dtype=np.uint64)
+        model = B.Blake2xbPRNG(seed).values(2 * 1024 + 40)
+        for first, count in ((0, 2088), (5, 30), (1023, 3), (1024, 16), (2040, 48), (17, 1)):
+            out = np.zeros(count, dtype=np.uint32)
+            assert emu.emu_blake2xb_values(sd.ctypes.data_as(u64p), C.c_uint64(first), out.ctypes.data_as(u32p), count) == 0
+            assert [int(v) for v in out] == model[first:first + count], (seed, first)
+
+
 def test_tensor_fold128_reduction(emu):
     """ntt_reduce128_fold: P mod q for every 128-bit P < 2^(2k+1), the range of a0*b1 + a1*b0 with canonical operands;
     all primes of the 36 parameter files that admit it (44..61 bits, c < 2^24), against Python integers, extremes included"""
