@@ -229,6 +229,12 @@ int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_two_stream(mode); }); }
 int apsu_he_set_eval_pipeline(apsu_he_ctx *c, int groups)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_eval_pipeline(groups); }); }
+int apsu_he_set_async_results(apsu_he_ctx *c, int on)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_async_results(on != 0); }); }
+int apsu_he_sync(apsu_he_ctx *c)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->wait(); }); }
+int apsu_he_stream(apsu_he_ctx *c, void **hip_stream)
+{ return guarded([&] { REQUIRE(c && hip_stream, "null argument"); *hip_stream = (void *)c->eng->stream(); }); }
 int apsu_he_mask_generate(apsu_he_ctx *c, uint64_t seed, uint32_t count, uint64_t *masks_dev, uint64_t *values, uint64_t *blocks)
 { return guarded([&] { REQUIRE(c && (masks_dev || !count), "null argument"); c->eng->mask_generate(seed, count, masks_dev, values, blocks); }); }
 int apsu_he_mask_generate_blake2xb(apsu_he_ctx *c, const uint64_t *seed, uint64_t first_value, uint32_t count, uint64_t *masks_dev,

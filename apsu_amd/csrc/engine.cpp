@@ -128,6 +128,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // kernel.  Same bits; measured level with the separate kernels at N = 1 and 1.5 % slower on the per-rank shards
         // (profiles/r02_fuse_tensor.txt), so it is off by default.  Needs the 128-bit fold reduction for
         // every coefficient and BEHZ modulus (true for all primes SEAL's search returns at 44..61 bits).
+        if (const char *v = std::getenv("APSU_HE_ASYNC")) async_results_ = std::atoi(v) != 0;     // default of apsu_he_set_async_results
         fuse_tensor_ = false;
         if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) {
             fuse_tensor_ = std::atoi(v) != 0;
@@ -307,6 +308,12 @@ void Engine::sync()
     HIP_CHECK(hipStreamSynchronize(parked_.st));
     HIP_CHECK(hipStreamSynchronize(st_mac_));
     if (prof_on_) prof_collect();
+}
+
+void Engine::wait()
+{
+    Enter g(this);
+    sync();
 }
 
 void Engine::switch_lane(int lane)
@@ -1869,7 +1876,9 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 }
             }
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
-            sync();
+            // device-resident masks and results: nothing of the caller's is read or written by the host, so the call may
+            // return with the work queued (stream order protects the workspace, the job tables and the pooled powers)
+            if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) sync();
         });
     }
 }

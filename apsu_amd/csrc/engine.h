@@ -152,6 +152,9 @@ public:
     // pipelined evaluation: -1 = default policy, 0 or 1 = one stream, n > 1 = up to n groups of BinBundles whose database
     // scans run on the MAC stream next to the previous group's VALU-bound tail
     void set_eval_pipeline(int groups) { std::lock_guard<std::mutex> g(mu_); eval_pipe_mode_ = groups < 0 ? -1 : groups; }
+    // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
+    void set_async_results(bool on) { std::lock_guard<std::mutex> g(mu_); async_results_ = on; }
+    void wait();                                                  // locked sync()
     // test hook: copy one computed power to the host (serialised with the other calls on this context)
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
                         int *is_ntt);
@@ -204,6 +207,7 @@ private:
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipStream_t st_mac_ = nullptr;    // low-priority stream of the pipelined evaluation's database scans
     std::vector<hipEvent_t> mac_done_;
+    bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     int eval_pipe_mode_ = -1;         // -1 default policy, 0/1 off, n > 1: groups
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;

@@ -331,6 +331,21 @@ class HeContext:
         """-1 default policy, 0/1 off, n > 1: up to n BinBundle groups whose database scans overlap the previous group's tail"""
         _check(load_library().apsu_he_set_eval_pipeline(self.h, int(groups)))
 
+    def set_async_results(self, on):
+        """eval_bundles with device-resident masks and output returns once its work is queued; see sync() / stream"""
+        _check(load_library().apsu_he_set_async_results(self.h, int(bool(on))))
+
+    def sync(self):
+        """wait for everything this context has queued"""
+        _check(load_library().apsu_he_sync(self.h))
+
+    @property
+    def stream(self):
+        """the context's main HIP stream as an integer handle (e.g. for torch.cuda.ExternalStream)"""
+        p = C.c_void_p()
+        _check(load_library().apsu_he_stream(self.h, C.byref(p)))
+        return int(p.value or 0)
+
     def mask_generate(self, seed, count, masks_dev, want_values=True, want_blocks=True):
         """N4: `count` random masks (receiver_osn.cpp:217-284).  masks_dev: device pointer to count*n words receiving the
         encoded plaintexts.  -> (values [count][n] or None, blocks [count][items_per_bundle][2] (low, high) or None)"""

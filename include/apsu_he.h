@@ -231,6 +231,16 @@ int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
  * Same kernels, operands and results.  groups: -1 = default policy, 0 or 1 = off; APSU_HE_EVAL_PIPE sets the default. */
 int apsu_he_set_eval_pipeline(apsu_he_ctx *ctx, int groups);
 
+/* Device-resident pipelines: with on != 0, an apsu_he_eval_bundles call whose masks AND results live in device memory
+ * returns as soon as its work is queued (apsu_he_compute_powers with device-resident sources always does).  The results
+ * are complete after apsu_he_sync(ctx), or for work ordered after the context's main HIP stream (apsu_he_stream: a
+ * hipStream_t; e.g. hipEventRecord on it + hipStreamWaitEvent on the consumer's stream).  The caller's device buffers must
+ * stay alive and unmodified until then.  Host-memory arguments always synchronise, as does event profiling.
+ * Default off (APSU_HE_ASYNC=1 turns it on for contexts that never call this). */
+int apsu_he_set_async_results(apsu_he_ctx *ctx, int on);
+int apsu_he_sync(apsu_he_ctx *ctx);
+int apsu_he_stream(apsu_he_ctx *ctx, void **hip_stream);
+
 /* ---- "next" row N3: the network framing around the path, without flatc / flatbuffers / SEAL -----------------
  * What the reference pins is the FlatBuffers framing of its messages; these functions read and write it:
  *   ReceiverOperationHeader                   common/apsu/network/rop_header.fbs ; receiver_operation.cpp:27-87

@@ -180,6 +180,50 @@ def test_device_resident_io_and_profile_hooks():
     G.close()
 
 
+def test_async_device_results():
+    """apsu_he_set_async_results: with device-resident sources, masks and results the calls return with their work queued;
+    back-to-back queries without a host synchronisation give the bits of the synchronous path, results are complete
+    after apsu_he_sync and in stream order on apsu_he_stream"""
+    import torch
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 17, 60], 1: [99, 3]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    src = np.stack([np.stack([S.src[b][e] for e in S.sources]) for b in S.bundle_indices])
+    w = src[0, 0].size
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = np.stack([b["mask"] for b in S.bundles])
+    mask_d = torch.from_numpy(masks.view(np.int64)).cuda()
+    mp = [mask_d.data_ptr() + i * G.n * 8 for i in range(len(gb))]
+    want = np.stack([common.oracle_eval(S, opw, b) for b in S.bundles])
+    G.set_async_results(True)
+    outs = [torch.zeros((len(gb), 2, G.n), dtype=torch.int64, device="cuda") for _ in range(3)]
+    srcs = []
+    for k in range(6):                                     # queries back to back; every second one on zeroed sources
+        sk = src if k % 2 == 0 else np.zeros_like(src)
+        sd = torch.from_numpy(sk.view(np.int64)).cuda()
+        srcs.append(sd)                                     # device inputs must outlive the queued work
+        ptrs = [[sd.data_ptr() + ((bi * len(S.sources) + i) * w) * 8 for i in range(len(S.sources))] for bi in range(len(S.bundle_indices))]
+        pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)
+        G.eval_bundles(gb, pw, rk, mp, out=outs[k % 3].data_ptr(), masks_on_device=True, out_on_device=True)
+        del pw                                              # recycled while its evaluation is still queued
+    ext = torch.cuda.ExternalStream(G.stream)
+    torch.cuda.current_stream().wait_stream(ext)            # consumer ordered after the context's stream, no host wait
+    copy = outs[1].clone()                                  # k = 4: real sources
+    G.sync()
+    got = outs[1].cpu().numpy().view(np.uint64).reshape(want.shape)
+    assert (got == want).all()
+    torch.cuda.synchronize()
+    assert (copy.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all()
+    zero_q = outs[2].cpu().numpy().view(np.uint64).reshape(want.shape)          # k = 5: all-zero query ciphertexts
+    assert not (zero_q == want).all()
+    # host-memory results still synchronise in this mode
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk)
+    assert (G.eval_bundles(gb, pw, rk, list(masks)) == want).all()
+    G.close()
+
+
 def test_full_size_16M_properties():
     """BASELINE.json size (n = 8192, D = 1303, 241 MB per BinBundle) on the synthetic GPU-generated DB:
     (1) a second evaluation is bit-identical (determinism / no stale workspace);
