@@ -224,6 +224,53 @@ def test_async_device_results():
     G.close()
 
 
+def test_async_results_soak_with_changing_shapes(monkeypatch):
+    """queued-back-to-back queries whose batch shape changes every call (different BinBundle subsets and bundle-index sets:
+    the job-table cache misses, the workspace arena grows, pooled powers buffers change size) under both stream policies
+    give the bits of the synchronous path; nothing is waited for until the end"""
+    import torch
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 17, 60, 124], 1: [99, 3, 124]})
+    monkeypatch.setenv("APSU_HE_ARENA_BYTES", "1048576")              # a 1 MiB initial arena: overflow -> grow -> retry on the way
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    src = np.stack([np.stack([S.src[b][e] for e in S.sources]) for b in S.bundle_indices])
+    sd = torch.from_numpy(src.view(np.int64)).cuda()
+    w = src[0, 0].size
+    ns = len(S.sources)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = np.stack([b["mask"] for b in S.bundles])
+    mask_d = torch.from_numpy(masks.view(np.int64)).cuda()
+    rng = np.random.default_rng(5)
+    subsets = []
+    for _ in range(24):
+        k = int(rng.integers(1, len(gb) + 1))
+        subsets.append(sorted(int(v) for v in rng.choice(len(gb), size=k, replace=False)))
+
+    def run(sub, out):
+        idx = sorted({S.bundles[i]["bundle_idx"] for i in sub})
+        ptrs = [[sd.data_ptr() + ((S.bundle_indices.index(b) * ns + i) * w) * 8 for i in range(ns)] for b in idx]
+        pw = G.compute_powers(idx, ptrs, rk, on_device=True)
+        G.eval_bundles([gb[i] for i in sub], pw, rk, [mask_d.data_ptr() + i * G.n * 8 for i in sub], out=out.data_ptr(),
+                       masks_on_device=True, out_on_device=True)
+
+    want = []
+    for sub in subsets:                                                   # synchronous reference, one query at a time
+        o = torch.zeros((len(sub), 2, G.n), dtype=torch.int64, device="cuda")
+        run(sub, o)
+        want.append(o.cpu().numpy())
+    G.set_async_results(True)
+    for split in (1, 0):
+        G.set_two_stream(split)
+        outs = [torch.zeros((len(sub), 2, G.n), dtype=torch.int64, device="cuda") for sub in subsets]
+        for sub, o in zip(subsets, outs):
+            run(sub, o)
+        G.sync()
+        for q, (o, wnt) in enumerate(zip(outs, want)):
+            assert (o.cpu().numpy() == wnt).all(), (split, q)
+    G.close()
+
+
 def test_full_size_16M_properties():
     """BASELINE.json size (n = 8192, D = 1303, 241 MB per BinBundle) on the synthetic GPU-generated DB:
     (1) a second evaluation is bit-identical (determinism / no stale workspace);
