@@ -62,7 +62,8 @@ typedef struct {
 typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   /* powers.h:53-77 */
 
 const char *apsu_he_last_error(void);
-/* Exported symbol list (for binding checks). */
+/* 1: tiers 1 and 2, N1, N2, N4.  2 (additive): apsu_he_multi_*, apsu_he_eval_all, apsu_he_partition_bundles, apsu_he_wire_*,
+ * apsu_he_set_eval_pipeline, apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
