@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--config", default="16M-4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed steps")
-    ap.add_argument("--profile-every", type=int, default=10, help="bracket the NTT launches with HIP events in every n-th timed step")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="bracket the NTT launches with HIP events in every n-th timed step (0 = in the last timed step only)")
     args = ap.parse_args()
 
     import torch
@@ -193,14 +194,16 @@ def main():
     fence()
     if not args.no_profile:
         take_profile()                             # setup + warm-up launches go to the process totals only
-    # The NTT launches are bracketed by HIP events (on the engine's stream) in every `profile_every`-th timed step
-    # only: an event pair per launch costs ~10 us of stream time, 0.2 ms per query if every step carried them.
+    # The NTT launches are bracketed by HIP events (on the engine's stream) in ONE timed step by default (the last one, whose
+    # closing synchronisation coincides with the fence), or in every `profile_every`-th: a sampled step runs ComputePowers on
+    # one stream, carries an event pair per launch (~10 us of stream time each) and ends with a host wait -- measured
+    # +0.9 ms for that step, i.e. +0.045 ms on `value` per sampled step at K = 20 (profiles/r02_bench_sampling.txt).
     sampled = 0
     if not args.no_profile:
         ctx.profile_enable(0)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        on = (not args.no_profile) and i % args.profile_every == 0
+        on = (not args.no_profile) and ((i % args.profile_every == 0) if args.profile_every > 0 else (i == args.steps - 1))
         if on:
             ctx.profile_enable(2)
             sampled += 1
@@ -268,7 +271,9 @@ def main():
         ntt_bytes = ntt_limbs * 16 * n                                  # 16*n bytes per limb transform
         achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
         result["roofline"] = {
-            "kernel": "k_ntt (forward+inverse, in-path launches of every %d-th timed step)" % args.profile_every, "bound": "hbm",
+            "kernel": "k_ntt (forward+inverse, in-path launches of %s)" % (("every %d-th timed step" % args.profile_every)
+                                                                        if args.profile_every > 0 else "the last timed step"),
+            "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "algorithmic_bytes_per_launch": int(ntt_bytes / max(1, ntt_launches)),
@@ -276,6 +281,13 @@ def main():
             "launches_per_step": ntt_launches / steps, "limb_transforms_per_step": ntt_limbs / steps, "steps_sampled": sampled,
             "note": "working sets of in-path launches are mostly Infinity-Cache resident; see ntt_stream for >=1 GiB batches",
         }
+        # the same figure over the two untimed steps that carry events around EVERY launch (cross-check of the sample)
+        u_ms = prof_all["ntt_fwd"][0] + prof_all["ntt_inv"][0]
+        u_l = prof_all["ntt_fwd"][1] + prof_all["ntt_inv"][1]
+        u_b = (prof_all["ntt_fwd"][2] + prof_all["ntt_inv"][2]) * 16 * n
+        if u_ms > 0:
+            result["roofline"]["untimed_check"] = {"frac": round(u_b / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "avg_launch_us": round(u_ms * 1e3 / max(1, u_l), 2), "launches": u_l}
         mac_ms, _, mac_units = prof_all["dyadic_mac"]
         mac_bytes = mac_units * n * 8                                   # plaintext bytes streamed from HBM
         result["kernels_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof_all.items()}
