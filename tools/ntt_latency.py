@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import apsu_amd
-js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", "16M-4096.json")).read()
+js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", (sys.argv[1] if len(sys.argv) > 1 else "16M-4096") + ".json")).read()
 G = apsu_amd.HeContext(js)
 n, first = G.n, G.first_chain_idx
 L = first + 1
