@@ -1,10 +1,11 @@
-"""what one rank of an N-GPU run does (16M-4096): per-rank step time on a single GPU, for N = 1, 2, 4, 8"""
+"""what one rank of an N-GPU run does (default 16M-4096; argv[1] = another config of bench.py): per-rank step time on a
+single GPU, for N = 1, 2, 4, 8 (the shards of rank 0 and of the last rank are executed here, one after the other)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, apsu_amd
 from apsu_amd.sharding import partition
 from bench import SEED0, WORKLOADS
-cfg = "16M-4096"
+cfg = sys.argv[1] if len(sys.argv) > 1 else "16M-4096"
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", cfg + ".json")).read()
 ctx = apsu_amd.HeContext(js)
 n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
@@ -20,8 +21,13 @@ out = torch.zeros((len(units), 2, n), dtype=torch.int64, device="cuda")
 for world in (1, 2, 4, 8):
     assign = partition(units, ctx.bundle_idx_count, world)
     worst = 0
-    for r in (0, world - 1):
+    seen = set()
+    for r in range(world):                                  # every distinct shard shape once (the worst rank sets the step)
         mine = assign[r]
+        sig = (len({u[0] for u in mine}), len(mine), sum(u[2] for u in mine))
+        if sig in seen or not mine:
+            continue
+        seen.add(sig)
         idx = sorted({u[0] for u in mine})
         sp = [[sd.data_ptr() + ((b * ns + s) * 2 * Lf * n) * 8 for s in range(ns)] for b in idx]
         mp = [md.data_ptr() + i * n * 8 for i in range(len(mine))]
