@@ -34,3 +34,13 @@ def test_two_rank_bench_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["gather_check"] == {"rank0_rows_match": True, "all_binbundle_rows_filled": True, "rows": 34}
     assert d["config"]["binbundles_rank0"] == 17
+
+
+def test_rccl_collective_pattern_one_rank():
+    """the "nccl" (= RCCL) backend itself, as far as one GPU allows: a one-rank process group running the collective pattern
+    of bench.py's N > 1 path (gather ordered after an external stream through events, result buffers alternating)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selfcheck.py")], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "rccl one-rank selfcheck ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
