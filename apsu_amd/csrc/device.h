@@ -161,7 +161,7 @@ void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs
 void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
                      hipStream_t st);
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
-                       hipStream_t st);
+                       hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0);
 void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
 // Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
 // Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.

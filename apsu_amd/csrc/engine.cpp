@@ -129,6 +129,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // (profiles/r02_fuse_tensor.txt), so it is off by default.  Needs the 128-bit fold reduction for
         // every coefficient and BEHZ modulus (true for all primes SEAL's search returns at 44..61 bits).
         if (const char *v = std::getenv("APSU_HE_ASYNC")) async_results_ = std::atoi(v) != 0;     // default of apsu_he_set_async_results
+        if (const char *v = std::getenv("APSU_HE_FUSE_EXT")) fuse_ext_ = std::atoi(v) != 0;       // =0: separate extension kernel per DAG level
         fuse_tensor_ = false;
         if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) {
             fuse_tensor_ = std::atoi(v) != 0;
@@ -527,7 +528,7 @@ void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool 
     launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_);
 }
 
-void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx)
+bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out, int n_ext)
 {
     const int L = chain_idx + 1;
     const size_t n = hp_.n;
@@ -543,7 +544,9 @@ void Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
     { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
-    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_); }
+    const bool fuse_ext = ext_out && n_ext > 0 && fuse_ext_ && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
+    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0); }
+    return fuse_ext;
 }
 
 // ============================================================================ tier 1
@@ -918,7 +921,7 @@ void Engine::build_schedule()
 //   stage 0: workspace + sources;  stage d >= 1: the products of depth d;  stage -1: final conversions.
 // The stages of one walk must run in order on one lane; `run` carries the walk's buffers between them, so two walks
 // (the halves of a split DAG) can be interleaved level by level on two lanes.
-struct Engine::DagRun { u64 *pwf = nullptr, *ext = nullptr, *dbuf = nullptr; size_t arena_mark = 0; };
+struct Engine::DagRun { u64 *pwf = nullptr, *ext = nullptr, *dbuf = nullptr; size_t arena_mark = 0; int ext_done = -1; };   // ext_done: level whose parents are already extended
 
 void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *const *src, bool on_device, const RelinKeys *rk,
                      Powers &pwr, bool do_low, bool do_high)
@@ -969,7 +972,8 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 const auto &pl = s.levels[d - 1];
                 const int npar = pl.sp - pl.s0;
                 if (npar > 0) {
-                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), hlevel(first).L, hlevel(first).nB, slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
+                    // (parents that came out of a key switch were extended by its mod-down kernel: run.ext_done)
+                    if (run.ext_done != (int)d - 1) { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), hlevel(first).L, hlevel(first).nB, slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
                     d_ntt(ext_ptr(pl.s0, 0), (size_t)npar * nb * 2 * Ef, map_ext(first), (int)Ef, false);
                 }
                 const auto &cl = s.levels[d];
@@ -993,7 +997,11 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
                 }
                 { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
-                if (hp_.using_keyswitching && nn > 0) d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first);   // :431
+                if (hp_.using_keyswitching && nn > 0) {                                                                          // :431
+                    const int npar_here = ((size_t)d + 1 < s.levels.size()) ? (cl.sp - cl.s0) : 0;
+                    if (d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first, npar_here ? ext_ptr(cl.s0, 0) : nullptr, npar_here * nb))
+                        run.ext_done = (int)d;
+                }
             }
             return;
         }

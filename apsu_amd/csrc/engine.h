@@ -183,7 +183,9 @@ private:
     void d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse);
     void d_ntt_ct(u64 *data, size_t polys, int chain_idx, bool inverse) { d_ntt(data, polys * (chain_idx + 1), map_ct(), chain_idx + 1, inverse); }
     // BFV multiply of `njobs` (a, b) pairs given as ext-NTT operands; writes size-3 results
-    void d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx);
+    // ext_out / n_ext: the first n_ext ciphertexts also get their BEHZ extension written to ext_out[b][2][E][n] (fused into
+    // the mod-down; returns false when the level has no unrolled extension and the caller must run launch_behz_ext itself)
+    bool d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out = nullptr, int n_ext = 0);
     void check_level(int chain_idx) const;
 
     HeParams hp_;
@@ -233,6 +235,7 @@ private:
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_, sched_low_, sched_high_;
     void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
+    bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = false;        // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     int two_stream_mode_ = -1;

@@ -735,34 +735,12 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext(const DevLevel *__restrict__ 
 
 HD u64 lazy2(u64 x, const ShoupConst &c, u64 q) { return mul_shoup_lazy(x, c.w, c.wq, q); }      // x*c mod q in [0,2q), any x
 
-// Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices: same values, ~35 % fewer multiplies.
-// DROP: the input is one level higher (TL + 1 limbs per polynomial) and is first mod-switched to this level
-// (mod_switch_to_next_inplace, bin_bundle.cpp:269,298) — the drop and the extension share one pass over the data.
-template <int TL, bool DROP>
-__global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
-                                                    size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
+// BEHZ steps 1-2 for one coefficient (L = nB = TL <= 3, Shoup-form matrices): xin = the L canonical q-limb residues,
+// dst = limb 0 of the extended polynomial ([L q-limbs | nB B-limbs | m_sk][n]) at coefficient k.
+template <int TL>
+__device__ __forceinline__ void behz_ext2_body(const DevLevel *__restrict__ lv, const u64 *xin, u64 *__restrict__ dst, size_t n, size_t k)
 {
-    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
-    if (k >= n) return;
-    constexpr int L = TL, nBsk = TL + 1, E = 2 * TL + 1, LIN = TL + (DROP ? 1 : 0);
-    const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
-    const u64 *src = in + c * in_stride + p * (size_t)LIN * n;
-    u64 *dst = out + (size_t)blockIdx.y * E * n;
-    u64 xin[L];
-    if (DROP) {
-        const DevLevel *ld = lv + 1;                              // constants of the level being left
-        const u64 ql = ld->q[L].q;
-        const u64 last = addmod(src[(size_t)L * n + k], ld->half, ql);
-#pragma unroll
-        for (int j = 0; j < L; j++) {
-            const Mod m = ld->q[j];
-            const u64 tmp = submod(barrett64(last, m), ld->half_mod[j], m.q);
-            xin[j] = mul_shoup(submod(src[(size_t)j * n + k], tmp, m.q), ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < L; j++) xin[j] = src[(size_t)j * n + k];
-    }
+    constexpr int L = TL, nBsk = TL + 1;
     u64 xs[L];
     u32 mt_acc = 0;
 #pragma unroll
@@ -783,6 +761,37 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__
         for (int j = 0; j < L; j++) v += lazy2(xs[j], lv->s_q_to_bsk[i][j], m);
         dst[(size_t)(L + i) * n + k] = mul_shoup(v, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m);
     }
+}
+
+// Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices: same values, ~35 % fewer multiplies.
+// DROP: the input is one level higher (TL + 1 limbs per polynomial) and is first mod-switched to this level
+// (mod_switch_to_next_inplace, bin_bundle.cpp:269,298) — the drop and the extension share one pass over the data.
+template <int TL, bool DROP>
+__global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
+                                                    size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    constexpr int L = TL, E = 2 * TL + 1, LIN = TL + (DROP ? 1 : 0);
+    const size_t c = blockIdx.y / polys, p = blockIdx.y % polys;
+    const u64 *src = in + c * in_stride + p * (size_t)LIN * n;
+    u64 *dst = out + (size_t)blockIdx.y * E * n;
+    u64 xin[L];
+    if (DROP) {
+        const DevLevel *ld = lv + 1;                              // constants of the level being left
+        const u64 ql = ld->q[L].q;
+        const u64 last = addmod(src[(size_t)L * n + k], ld->half, ql);
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const Mod m = ld->q[j];
+            const u64 tmp = submod(barrett64(last, m), ld->half_mod[j], m.q);
+            xin[j] = mul_shoup(submod(src[(size_t)j * n + k], tmp, m.q), ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < L; j++) xin[j] = src[(size_t)j * n + k];
+    }
+    behz_ext2_body<TL>(lv, xin, dst, n, k);
 }
 
 // drop one limb, then extend: `in` holds polynomials of L + 1 limbs at level lv + 1.  Only for the unrolled sizes;
@@ -1151,9 +1160,13 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
 
 // mod-down by the special prime with rounding and add into (c0, c1):
 // acc: [batch][2][L+1][n] coefficient form ; ct[b]: [>=2][L][n] at stride ct_stride
-template <int TL>
+// EXT: the first n_ext ciphertexts are operands of later products (ComputePowers' parents): their BEHZ extension
+// (steps 1-2, behz_ext2_body) is written to ext + (b*2 + comp)*(2L+1)*n while the new (c0, c1) are still in registers --
+// the extension kernel of the next DAG level and its re-read of the ciphertexts disappear.
+template <int TL, bool EXT = false>
 __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ acc,
-                                                     u64 *__restrict__ ct, size_t ct_stride, size_t n)
+                                                     u64 *__restrict__ ct, size_t ct_stride, size_t n,
+                                                     const DevLevel *__restrict__ lv = nullptr, u64 *__restrict__ ext = nullptr, int n_ext = 0)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
@@ -1165,22 +1178,36 @@ __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ 
         const u64 *a = acc + (b * 2 + comp) * (size_t)(L + 1) * n;
         u64 *c = ct + b * ct_stride + (size_t)comp * L * n;
         const u64 tl = barrett64(a[(size_t)L * n + k] + key->p_half, pm);
+        u64 x[TL ? TL : 1];
 #pragma unroll
         for (int j = 0; j < (TL ? TL : DMAXL); j++) {
             if (!TL && j >= L) continue;
             const Mod m = key->q[j];
             const u64 tk = submod(barrett64(tl, m), key->p_half_mod[j], m.q);
             const u64 v = mul_shoup(submod(a[(size_t)j * n + k], tk, m.q), key->inv_p[j].w, key->inv_p[j].wq, m.q);
-            c[(size_t)j * n + k] = addmod(c[(size_t)j * n + k], v, m.q);
+            const u64 r = addmod(c[(size_t)j * n + k], v, m.q);
+            c[(size_t)j * n + k] = r;
+            if (EXT) x[j] = r;
+        }
+        if constexpr (EXT && TL > 0) {
+            if ((int)b < n_ext) behz_ext2_body<TL>(lv, x, ext + ((b * 2 + comp) * (size_t)(2 * TL + 1)) * n, n, k);
         }
     }
 }
 
+// lv / ext / n_ext: see k_ks_moddown<TL, true>; only for L == nB <= 3 (the caller checks), ext == nullptr: plain mod-down
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
-                       hipStream_t st)
+                       hipStream_t st, const DevLevel *lv, u64 *ext, int n_ext)
 {
-#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n); break;
-    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_moddown<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n); }
+    if (ext && n_ext > 0 && L >= 1 && L <= 3) {
+#define KSX_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL, true>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, lv, ext, n_ext); break;
+        switch (L) { KSX_CASE(1) KSX_CASE(2) KSX_CASE(3) }
+#undef KSX_CASE
+        KERNEL_CHECK();
+        return;
+    }
+#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); break;
+    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_moddown<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); }
 #undef KS_CASE
     KERNEL_CHECK();
 }

@@ -346,6 +346,7 @@ def test_fallback_paths_match():
     # the summed-Bsk finish of eval_patstock's products and the default stream policy of ComputePowers have
     # alternatives (per-term finish: APSU_HE_EVAL_PER_TERM; ComputePowers forced onto one / two streams: APSU_HE_SPLIT=0/1;
     # the tensor product formed by the inverse transform's load instead of its own kernel: APSU_HE_FUSE_TENSOR=1;
+    # ComputePowers' BEHZ extension as its own kernel instead of the key switch's mod-down writing it: APSU_HE_FUSE_EXT=0;
     # read once per process); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte workspace budget
     # evaluates one BinBundle per chunk.  All must give the same bits, so scenarios run in child processes per switch.
     import subprocess, sys, os
@@ -355,7 +356,7 @@ def test_fallback_paths_match():
     big = ("t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced(); "
            "t.test_config_16M_4096_reduced()\n")
     for switch, value, code in (("APSU_HE_EVAL_PER_TERM", "1", small + big), ("APSU_HE_SPLIT", "0", small + big),
-                                ("APSU_HE_SPLIT", "1", small + big), ("APSU_HE_FUSE_TENSOR", "1", small + big), ("APSU_HE_ARENA_BYTES", "1048576", small),
+                                ("APSU_HE_SPLIT", "1", small + big), ("APSU_HE_FUSE_TENSOR", "1", small + big), ("APSU_HE_FUSE_EXT", "0", small + big), ("APSU_HE_ARENA_BYTES", "1048576", small),
                                 ("APSU_HE_EVAL_WS_BYTES", "1", small)):
         env = dict(os.environ, **{switch: value})
         r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)
