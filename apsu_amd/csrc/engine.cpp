@@ -294,10 +294,14 @@ Engine::~Engine()
     int cur = -1;
     const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device_ && hipSetDevice(device_) == hipSuccess;
     struct Back { bool on; int dev; ~Back() { if (on) (void)hipSetDevice(dev); } } back{ switched, cur };
+    // queued work first (apsu_he_set_async_results leaves evaluations in flight), then the buffers it uses
+    if (st_) (void)hipStreamSynchronize(st_);
+    if (parked_.st) (void)hipStreamSynchronize(parked_.st);
+    if (st_mac_) (void)hipStreamSynchronize(st_mac_);
     powers_pool_.clear();
-    if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
-    if (parked_.st) { (void)hipStreamSynchronize(parked_.st); (void)hipStreamDestroy(parked_.st); }
-    if (st_mac_) { (void)hipStreamSynchronize(st_mac_); (void)hipStreamDestroy(st_mac_); }
+    if (st_) (void)hipStreamDestroy(st_);
+    if (parked_.st) (void)hipStreamDestroy(parked_.st);
+    if (st_mac_) (void)hipStreamDestroy(st_mac_);
     for (hipEvent_t e : mac_done_) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
