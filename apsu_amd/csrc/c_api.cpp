@@ -51,7 +51,7 @@ template <class F> static int guarded(F &&fn)
 extern "C" {
 
 const char *apsu_he_last_error(void) { return g_last_error.c_str(); }
-int apsu_he_abi_version(void) { return 2; }
+int apsu_he_abi_version(void) { return 3; }
 
 int apsu_he_create(const char *json, int device, apsu_he_ctx **out)
 {
@@ -227,8 +227,6 @@ int apsu_he_bundle_load(apsu_he_ctx *c, const uint8_t *buf, uint64_t size, apsu_
 }
 int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_two_stream(mode); }); }
-int apsu_he_set_eval_pipeline(apsu_he_ctx *c, int groups)
-{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_eval_pipeline(groups); }); }
 int apsu_he_set_async_results(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_async_results(on != 0); }); }
 int apsu_he_sync(apsu_he_ctx *c)
@@ -534,6 +532,9 @@ int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id
         }
     });
 }
+
+int apsu_he_debug_counters(apsu_he_ctx *c, uint64_t *out, int capacity)
+{ return guarded([&] { REQUIRE(c && out && capacity >= 0, "null argument"); c->eng->counters_read(out, capacity); }); }
 
 int apsu_he_profile_enable(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->profile_enable(on); }); }

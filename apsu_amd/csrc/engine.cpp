@@ -82,14 +82,6 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
-        // the MAC stream carries the grid-filling, HBM-bound database scans of a pipelined evaluation
-        // (APSU_HE_MAC_PRIO = low | normal | high selects its dispatch priority for experiments; default low)
-        int mac_prio = least;
-        if (const char *v = std::getenv("APSU_HE_MAC_PRIO")) {
-            if (v[0] == 'h') mac_prio = greatest;
-            else if (v[0] == 'n') mac_prio = (least + greatest) / 2;
-        }
-        HIP_CHECK(hipStreamCreateWithPriority(&st_mac_, hipStreamNonBlocking, mac_prio));
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
 
@@ -115,6 +107,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             tabs[m].ninv = hp_.ntt[m].ninv;
             tabs[m].ninv_q = hp_.ntt[m].ninv_q;
             tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
+            tabs[m].r0 = hp_.ntt[m].mod.ratio[0];
             tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
             ntt_fold_params(tabs[m].q, tabs[m].fold_k, tabs[m].fold_c);
             tabs[m].wide_d4 = ntt_wide_d4(tabs[m].q, tabs[m].narrow != 0);
@@ -124,17 +117,17 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
-        // APSU_HE_FUSE_TENSOR=1: tensor product formed by the inverse transform's load (k_intt_tensor) instead of its own
-        // kernel.  Same bits; measured level with the separate kernels at N = 1 and 1.5 % slower on the per-rank shards
-        // (profiles/r02_fuse_tensor.txt), so it is off by default.  Needs the 128-bit fold reduction for
-        // every coefficient and BEHZ modulus (true for all primes SEAL's search returns at 44..61 bits).
+        // BEHZ step 4 (the dyadic tensor product) is formed by the load of the inverse transform that follows it (k_intt_tensor)
+        // instead of by its own kernel: same bits, and measured in one process against the separate kernels with
+        // tools/ab_test.py (profiles/r03_ab_fuse_tensor.txt): -0.059 +- 0.026 ms on the whole 16M-4096 query, -0.017 +- 0.0014 ms
+        // (-2.1 %) on the N = 8 shard.  APSU_HE_FUSE_TENSOR=0 restores the separate kernels.
         if (const char *v = std::getenv("APSU_HE_ASYNC")) async_results_ = std::atoi(v) != 0;     // default of apsu_he_set_async_results
+        if (const char *v = std::getenv("APSU_HE_MAX_INFLIGHT")) max_inflight_ = std::max(1, std::atoi(v));   // queued evaluations the host may run ahead
         if (const char *v = std::getenv("APSU_HE_FUSE_EXT")) fuse_ext_ = std::atoi(v) != 0;       // =0: separate extension kernel per DAG level
-        fuse_tensor_ = false;
-        if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) {
-            fuse_tensor_ = std::atoi(v) != 0;
-            for (int m = 0; m < hp_.plain_id() && m < nmod; m++) fuse_tensor_ = fuse_tensor_ && ntt_fold128_ok(tabs[m].fold_k, tabs[m].fold_c);
-        }
+        fuse_tensor_ = true;
+        if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) fuse_tensor_ = std::atoi(v) != 0;
+        // the key switch's inner product with the key formed by the load of the inverse transform behind it (k_intt_ks)
+        if (const char *v = std::getenv("APSU_HE_FUSE_KS")) fuse_ks_ = std::atoi(v) != 0;
     }
     // level constants
     {
@@ -297,21 +290,19 @@ Engine::~Engine()
     // queued work first (apsu_he_set_async_results leaves evaluations in flight), then the buffers it uses
     if (st_) (void)hipStreamSynchronize(st_);
     if (parked_.st) (void)hipStreamSynchronize(parked_.st);
-    if (st_mac_) (void)hipStreamSynchronize(st_mac_);
     powers_pool_.clear();
     if (st_) (void)hipStreamDestroy(st_);
     if (parked_.st) (void)hipStreamDestroy(parked_.st);
-    if (st_mac_) (void)hipStreamDestroy(st_mac_);
-    for (hipEvent_t e : mac_done_) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : inflight_) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
 }
 
 void Engine::sync()
 {
+    counters_[C_HOST_SYNC]++;
     HIP_CHECK(hipStreamSynchronize(st_));
     HIP_CHECK(hipStreamSynchronize(parked_.st));
-    HIP_CHECK(hipStreamSynchronize(st_mac_));
     if (prof_on_) prof_collect();
 }
 
@@ -455,6 +446,7 @@ void Engine::ws_reset(size_t need)
     if (need) {                                   // grow the lane whose bump allocator overflowed
         switch_lane(overflow_lane_);
         if (need > arena_.bytes()) {
+            counters_[C_ARENA_GROW]++;
             sync();
             arena_.release();
             arena_.alloc(need + need / 4);
@@ -473,15 +465,24 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
     const size_t bytes = v.size() * sizeof(T);
     if (job_seq_ >= job_slots_.size()) job_slots_.resize(job_seq_ + 1);
     JobSlot &slot = job_slots_[job_seq_++];
-    if (slot.host.size() == bytes && std::memcmp(slot.host.data(), v.data(), bytes) == 0)
-        return reinterpret_cast<const T *>(slot.buf.p());                                             // unchanged since last call
-    if (slot.buf.bytes() < bytes) {
+    for (JobWay &w : slot.way)
+        if (w.host.size() == bytes && std::memcmp(w.host.data(), v.data(), bytes) == 0) {
+            counters_[C_JOB_HIT]++;
+            w.stamp = ++job_stamp_;
+            return reinterpret_cast<const T *>(w.buf.p());                                            // unchanged since an earlier call
+        }
+    counters_[C_JOB_UPLOAD]++;
+    JobWay &way = slot.way[slot.way[0].stamp <= slot.way[1].stamp ? 0 : 1];                           // least recently used
+    way.stamp = ++job_stamp_;
+    if (way.buf.bytes() < bytes) {
+        counters_[C_JOB_REALLOC]++;
         sync();                                   // the old buffer may still be read by queued kernels
-        slot.buf.alloc(bytes + bytes / 2);
+        way.buf.alloc(bytes + bytes / 2);
     }
     // through a pinned staging area so the copy is truly asynchronous and the std::vector may die
     const size_t aligned = (bytes + 63) & ~(size_t)63;
     if (stage_off_ + aligned > stage_bytes_) {
+        counters_[C_STAGE_WRAP]++;
         sync();                                   // everything staged so far has been consumed
         if (aligned > stage_bytes_) {
             if (stage_) (void)hipHostFree(stage_);
@@ -493,9 +494,34 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
     char *hp = static_cast<char *>(stage_) + stage_off_;
     std::memcpy(hp, v.data(), bytes);
     stage_off_ += aligned;
-    HIP_CHECK(hipMemcpyAsync(slot.buf.p(), hp, bytes, hipMemcpyHostToDevice, st_));
-    slot.host.assign(reinterpret_cast<const unsigned char *>(v.data()), reinterpret_cast<const unsigned char *>(v.data()) + bytes);
-    return reinterpret_cast<const T *>(slot.buf.p());
+    HIP_CHECK(hipMemcpyAsync(way.buf.p(), hp, bytes, hipMemcpyHostToDevice, st_));
+    way.host.assign(reinterpret_cast<const unsigned char *>(v.data()), reinterpret_cast<const unsigned char *>(v.data()) + bytes);
+    return reinterpret_cast<const T *>(way.buf.p());
+}
+
+void Engine::throttle_inflight()
+{
+    while (inflight_count_ >= (size_t)std::max(1, max_inflight_)) {
+        HIP_CHECK(hipEventSynchronize(inflight_[inflight_head_]));
+        inflight_head_ = (inflight_head_ + 1) % inflight_.size();
+        inflight_count_--;
+    }
+}
+
+void Engine::mark_inflight()
+{
+    const size_t cap = (size_t)std::max(1, max_inflight_) + 1;
+    if (inflight_.size() != cap) {                               // (re)build the ring; nothing pending survives a resize
+        for (size_t i = 0; i < inflight_count_; i++) (void)hipEventSynchronize(inflight_[(inflight_head_ + i) % inflight_.size()]);
+        for (hipEvent_t e : inflight_) (void)hipEventDestroy(e);
+        inflight_.assign(cap, nullptr);
+        for (hipEvent_t &e : inflight_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        inflight_head_ = inflight_count_ = 0;
+    }
+    throttle_inflight();
+    const size_t at = (inflight_head_ + inflight_count_) % inflight_.size();
+    HIP_CHECK(hipEventRecord(inflight_[at], st_));
+    inflight_count_++;
 }
 
 void Engine::recycle_powers(std::unique_ptr<Powers> p)
@@ -546,8 +572,13 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
         launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_);
     }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
-    { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
-    d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
+    if (fuse_ks_ && L <= 4) {                                    // the inner product with the key is the inverse transform's load
+        PROF(P_NTT_INV, (uint64_t)batch * 2 * (L + 1));
+        launch_intt_ks(hp_.logn, tdec, rk.data.u(), acc, L, hp_.K, batch, tabs(), map_ksacc(chain_idx), st_);
+    } else {
+        { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
+        d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
+    }
     const bool fuse_ext = ext_out && n_ext > 0 && fuse_ext_ && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
     { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0); }
     return fuse_ext;
@@ -1106,6 +1137,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     pw->n_low = (uint32_t)s.low_powers.size();
     pw->n_high = (uint32_t)s.high_powers.size();
     if (!recycled) {
+        counters_[C_POWERS_ALLOC]++;
         pw->low.alloc(need_low);
         if (pw->n_high) {
             pw->high.alloc(need_high);
@@ -1597,12 +1629,12 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
                 const bool need_vlast = i0_fast && low > high;
 
-                // Pipelining: the dyadic multiply-accumulate streams the database (HBM-bound) and needs only the low
-                // powers; everything behind it is VALU-bound (inverse NTTs, BEHZ products, key switch).  The BinBundles are
-                // cut into groups; group g+1's multiply-accumulate runs on the low-priority MAC stream while the main
-                // stream finishes group g.  Same kernels, same operands, same results; event profiling (whose timings
-                // are only meaningful without concurrency) uses one stream.
-                struct PsGroup {
+                // One batch: every Paterson-Stockmeyer BinBundle of the chunk, ordered by bundle index (the shared powers of
+                // one index then stay in the same L2).  (Cutting the batch into groups whose database scans overlap the previous
+                // group's VALU-bound tail on a second stream was built and measured in rounds 2 and 3, also with an LDS-DMA
+                // multiply-accumulate that leaves room for an NTT workgroup per CU: slower to level, the chip is power-bound.
+                // tools/microbench/eval_pipeline_experiment.patch, profiles/r03_eval_pipeline.txt.)
+                struct PsBatch {
                     std::vector<int> ids;                               // positions in this chunk
                     std::vector<int> nin, in_off;                       // inner polynomials per BinBundle, prefix offsets
                     int NI = 0;
@@ -1611,34 +1643,14 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const MacJob *mac_jobs = nullptr;
                     int n_mac = 0;
                     uint64_t units = 0;
-                };
-                std::vector<PsGroup> groups;
-                {
-                    std::vector<int> order = ps_ids;
-                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
-                    static const int pipe_env = [] { const char *v = std::getenv("APSU_HE_EVAL_PIPE"); return v ? atoi(v) : -1; }();
-                    int want = eval_pipe_mode_ >= 0 ? eval_pipe_mode_ : pipe_env;
-                    if (want < 0) want = 1;                             // default policy: one stream (measured slower when on)
-                    if (prof_on_ || want < 1) want = 1;
-                    // a group should still fill the machine: at least two BinBundles each
-                    const int G = std::max(1, std::min<int>(want, (int)order.size() / 2));
-                    uint64_t total = 0;
-                    for (int id : order) total += bundles[c0 + id]->degree + 1;
-                    groups.resize(G);
-                    uint64_t run = 0;
-                    for (int id : order) {
-                        int g = (int)std::min<uint64_t>((uint64_t)G - 1, run * G / std::max<uint64_t>(1, total));
-                        groups[g].ids.push_back(id);
-                        run += bundles[c0 + id]->degree + 1;
-                    }
-                    groups.erase(std::remove_if(groups.begin(), groups.end(), [](const PsGroup &g) { return g.ids.empty(); }), groups.end());
-                }
-                const bool piped = groups.size() > 1;
-                // high powers still in flight on the second stream (split ComputePowers), or pipelined groups: everything
-                // that needs only the low powers goes first, the cf products (which read the high powers) come later
+                } g;
+                g.ids = ps_ids;
+                std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
+                // high powers still in flight on the second stream (split ComputePowers): everything that needs only the low
+                // powers goes first, the cf products (which read the high powers) come later
                 const bool async_high = pw.high_async && pw.high_ready;
-                const bool late_high = async_high || piped;
-                auto cf_streams = [&](const PsGroup &g, std::vector<MacStream> &out) {
+                const bool late_high = async_high;
+                auto cf_streams = [&](const PsBatch &g, std::vector<MacStream> &out) {
                     for (size_t x = 0; x < g.ids.size(); x++) {
                         const Bundle &b = *bundles[c0 + g.ids[x]];
                         out.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H, (u32)(Lh * n),
@@ -1646,8 +1658,8 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     }
                 };
 
-                // ---- phase A: workspace and the job array of every group's multiply-accumulate
-                for (PsGroup &g : groups) {
+                // ---- phase A: workspace and the job array of the multiply-accumulate
+                {
                     const int Bs = (int)g.ids.size();
                     // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
                     g.nin.resize(Bs); g.in_off.resize(Bs);
@@ -1718,31 +1730,13 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     g.units = mac_units(mj);
                 }
 
-                // ---- the multiply-accumulates: in stream order on the MAC stream (pipelined) or on the main stream
-                // (the level-`low` constants serve every limb: levels share their leading primes)
-                if (piped) {
-                    if (mac_done_.size() < groups.size()) {
-                        const size_t old = mac_done_.size();
-                        mac_done_.resize(groups.size(), nullptr);
-                        for (size_t i = old; i < mac_done_.size(); i++) HIP_CHECK(hipEventCreateWithFlags(&mac_done_[i], hipEventDisableTiming));
-                    }
-                    // the MAC stream starts behind the low powers and the job arrays (main-stream order)
-                    HIP_CHECK(hipEventRecord(ev_main_, st_));
-                    HIP_CHECK(hipStreamWaitEvent(st_mac_, ev_main_, 0));
-                    for (size_t gi = 0; gi < groups.size(); gi++) {
-                        launch_mac(dlevel(low), (int)Ll, groups[gi].mac_jobs, n, groups[gi].n_mac, st_mac_);
-                        HIP_CHECK(hipEventRecord(mac_done_[gi], st_mac_));
-                    }
-                }
-
-                // ---- phase B per group: everything behind the multiply-accumulate
-                for (size_t gi = 0; gi < groups.size(); gi++) {
-                    PsGroup &g = groups[gi];
+                // ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
+                // primes) and everything behind it
+                {
                     const int Bs = (int)g.ids.size(), NI = g.NI;
                     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
                     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-                    if (piped) HIP_CHECK(hipStreamWaitEvent(st_, mac_done_[gi], 0));
-                    else { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_); }
+                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_); }
                     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
                     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
@@ -1763,7 +1757,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                     }
                     d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
-                    if (async_high && gi == 0) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
+                    if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
                     u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
                     // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
                     // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
@@ -1890,7 +1884,8 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             // device-resident masks and results: nothing of the caller's is read or written by the host, so the call may
             // return with the work queued (stream order protects the workspace, the job tables and the pooled powers)
-            if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) sync();
+            if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) { sync(); inflight_count_ = 0; }
+            else mark_inflight();
         });
     }
 }

@@ -141,6 +141,11 @@ public:
 
     // introspection for tests
     size_t workspace_bytes() const { return arena_.bytes(); }
+    // Host-side events that cost a query time without showing up in any kernel: host waits taken inside the engine,
+    // job-table uploads (cache misses) and hits, workspace-arena growths, powers-buffer allocations, wraps of the pinned
+    // staging area.  Steady state = only hits move.  (apsu_he_debug_counters)
+    enum Counter { C_HOST_SYNC = 0, C_JOB_UPLOAD, C_JOB_HIT, C_ARENA_GROW, C_POWERS_ALLOC, C_STAGE_WRAP, C_JOB_REALLOC, C_COUNT };
+    void counters_read(uint64_t *out, int capacity) const { for (int i = 0; i < capacity && i < C_COUNT; i++) out[i] = counters_[i]; }
 
     // ---------------- per-kernel timing with HIP events on the engine's stream (bench.py roofline)
     enum ProfKind { P_NTT_FWD = 0, P_NTT_INV, P_MAC, P_BEHZ_EXT, P_TENSOR, P_BEHZ_FINISH, P_KEYSWITCH, P_MODSWITCH, P_OTHER, P_COUNT };
@@ -149,9 +154,6 @@ public:
     void profile_read(ProfStats *out, bool reset);
     // two-stream ComputePowers: -1 = default policy (on for one or two bundle indices), 0 = off, 1 = on
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
-    // pipelined evaluation: -1 = default policy, 0 or 1 = one stream, n > 1 = up to n groups of BinBundles whose database
-    // scans run on the MAC stream next to the previous group's VALU-bound tail
-    void set_eval_pipeline(int groups) { std::lock_guard<std::mutex> g(mu_); eval_pipe_mode_ = groups < 0 ? -1 : groups; }
     // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
     void set_async_results(bool on) { std::lock_guard<std::mutex> g(mu_); async_results_ = on; }
     void wait();                                                  // locked sync()
@@ -207,16 +209,25 @@ private:
     int cur_lane_ = 0, overflow_lane_ = 0;
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
-    hipStream_t st_mac_ = nullptr;    // low-priority stream of the pipelined evaluation's database scans
-    std::vector<hipEvent_t> mac_done_;
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
-    int eval_pipe_mode_ = -1;         // -1 default policy, 0/1 off, n > 1: groups
+    // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded
+    // run-ahead (20 queued queries = 1300 launches + 200 stream events) makes the HIP runtime block the host inside a
+    // launch and drain its queues, which shows up as idle gaps on the device (profiles/r03_shard_probe.txt).
+    std::vector<hipEvent_t> inflight_;
+    size_t inflight_head_ = 0, inflight_count_ = 0;
+    int max_inflight_ = 2;
+    void throttle_inflight();
+    void mark_inflight();
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
     // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the
     // previous call of the same shape (workspace addresses are deterministic), so it is kept on the
     // device and the copy is skipped when the content hash matches.
-    struct JobSlot { DevBuf buf; std::vector<unsigned char> host; };
+    // Two ways per slot: a caller that still holds the previous query's powers while it computes the next one alternates
+    // between two powers buffers, hence between two versions of every table that names them (tools/shard_probe.py).
+    struct JobWay { DevBuf buf; std::vector<unsigned char> host; uint64_t stamp = 0; };
+    struct JobSlot { JobWay way[2]; };
+    uint64_t job_stamp_ = 0;
     std::vector<JobSlot> job_slots_;
     size_t job_seq_ = 0, job_seq_base_ = 0;   // slots [base, ..) belong to the running top-level op
     std::vector<std::unique_ptr<Powers>> powers_pool_;
@@ -224,6 +235,7 @@ public:
     void recycle_powers(std::unique_ptr<Powers> p);
 private:
     std::vector<DevBuf> retired_;     // arenas replaced while kernels may still reference them
+    uint64_t counters_[C_COUNT] = {};
 
     // PowersDag schedule (slot order = depth, parents first, power)
     struct Sched {
@@ -236,7 +248,8 @@ private:
     } sched_, sched_low_, sched_high_;
     void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
-    bool fuse_tensor_ = false;        // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
+    bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
+    bool fuse_ks_ = false;            // the key switch's inner product is formed by the inverse transform's load (k_intt_ks)
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     int two_stream_mode_ = -1;
     void build_schedule();

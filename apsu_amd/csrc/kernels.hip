@@ -109,7 +109,6 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
 // the NTT-form operands while it loads (SrcTensor) and writes the coefficient-form limb to job.d[p][e]: the tensor kernel,
 // its 3*E limb writes and the transform's re-read of them are gone.  Workgroups g >= n_tensor transform
 // plain[g - n_tensor] in place (limbs that join the same launch).  Operand polys are src_ps words apart.
-// Requires ntt_fold128_ok for every modulus in the map (the host checks; otherwise k_tensor + k_ntt run).
 template <int LOGN, int T>
 __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
                                                    u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
@@ -165,6 +164,42 @@ void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, s
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
     }
 #undef T_CASE
+    KERNEL_CHECK();
+}
+
+// Inverse NTT of the key switch's inner products (App. B10, the accumulation step and the transform behind it in one
+// launch): workgroup g owns acc[b][comp][I] with (b, comp, I) = g / (2 (L+1)), (g / (L+1)) % 2, g % (L+1), forms
+// sum_J tdec[b][I][J] (.) rk[J][comp][ki(I)] while it loads (SrcKs) and writes the coefficient-form limb: k_ks_inner, its
+// 2 (L+1) limb writes per ciphertext and the transform's re-read of them are gone.  L <= 4.
+template <int LOGN, int T>
+__global__ __launch_bounds__(T, 4) void k_intt_ks(const u64 *__restrict__ tdec, const u64 *__restrict__ rk, u64 *__restrict__ acc, int L, int K,
+                                               const NttTable *__restrict__ tabs, const int *__restrict__ modmap)
+{
+    constexpr int N = 1 << LOGN;
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
+    const int tid = threadIdx.x;
+    const size_t g = blockIdx.x, per = (size_t)2 * (L + 1), b = g / per;
+    const int r = (int)(g - b * per), comp = r / (L + 1), I = r - comp * (L + 1);
+    const int ki = I == L ? K - 1 : I;
+    const NttTable tab = tabs[modmap[I] & NTT_MAP_MASK];
+    const SrcKs ops{ tdec + ((b * (L + 1) + I) * L) * N, rk + ((size_t)comp * K + ki) * N, (size_t)N, (size_t)2 * K * N, L };
+    u64 *p = acc + g * N;
+    if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
+    else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
+    else ntt_body<LOGN, true, NTT_WIDE, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
+}
+
+void launch_intt_ks(int logn, const u64 *tdec, const u64 *rk, u64 *acc, int L, int K, int batch, const NttTable *tabs, const int *modmap,
+                    hipStream_t st)
+{
+    const size_t count = (size_t)batch * 2 * (L + 1);
+    if (!count) return;
+#define K_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_ks<LN, T>), dim3((unsigned)count), dim3(T), 0, st, tdec, rk, acc, L, K, tabs, modmap); break;
+    switch (logn) {
+    K_CASE(14, 1024) K_CASE(13, 512) K_CASE(12, 256) K_CASE(11, 128) K_CASE(10, 64) K_CASE(8, 64) K_CASE(6, 64)
+    default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    }
+#undef K_CASE
     KERNEL_CHECK();
 }
 
@@ -1225,12 +1260,6 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // else.  `chunk` terms (2*chunk*2^(2s) < 2^64) are accumulated before the sums are recombined
 // (S00 + Sx*2^s + S11*2^(2s)) and reduced; for the 48..56-bit coefficient primes a whole inner polynomial
 // fits in one chunk.
-#ifndef APSU_MAC_RING
-#define APSU_MAC_RING 2
-#endif
-#ifndef APSU_MAC_LDS_KB
-#define APSU_MAC_LDS_KB 0
-#endif
 template <int G, int C>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
@@ -1315,35 +1344,6 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     };
 
     const u32 cnt = job.cnt;
-#if APSU_MAC_RING == 4
-    // four register sets, three terms in flight behind the one being consumed (HBM latency x bandwidth needs
-    // more than 64 KB of loads in flight per CU)
-    Term A, B, Cc, D;
-    const u32 last = cnt - 1;
-    load_term(0, A);
-    load_term(1 < cnt ? 1 : last, B);
-    load_term(2 < cnt ? 2 : last, Cc);
-    u32 in_chunk = 0;
-    const u32 nquads = cnt >> 2;
-    for (u32 qd = 0; qd < nquads; qd++) {                        // branch-free body: four terms per trip
-        const u32 i = qd * 4;
-        load_term(i + 3, D);
-        mac_term(A);
-        load_term(i + 4 < cnt ? i + 4 : last, A);                // clamped prefetch (a re-read hits the cache)
-        mac_term(B);
-        load_term(i + 5 < cnt ? i + 5 : last, B);
-        mac_term(Cc);
-        load_term(i + 6 < cnt ? i + 6 : last, Cc);
-        mac_term(D);
-        in_chunk += 4;
-        if (in_chunk + 7 > chunk) { fold(); in_chunk = 1; }      // room for the next quad or the tail; the residue counts as one term
-    }
-    const u32 rem = cnt & 3;                                     // A, B, Cc hold the next three terms
-    if (rem > 0) mac_term(A);
-    if (rem > 1) mac_term(B);
-    if (rem > 2) mac_term(Cc);
-    fold();
-#else
     Term A, B;                                                   // ping-pong register sets: no copies
     load_term(0, A);
     u32 in_chunk = 0;
@@ -1359,7 +1359,6 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     }
     if (cnt & 1) mac_term(A);                                    // A holds the last term
     fold();
-#endif
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {
@@ -1388,11 +1387,8 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
-    // Unused dynamic LDS caps the workgroups per CU, leaving registers and wave slots for the short kernels of the
-    // engine's second stream (ComputePowers' high-power chain) while this grid-filling launch streams the DB.
-    static const unsigned reserve = [] { const char *e = std::getenv("APSU_HE_MAC_LDS_KB"); return (unsigned)(e ? atoi(e) : APSU_MAC_LDS_KB) * 1024u; }();
     hipLaunchKernelGGL((k_mac<G, C>), dim3((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G))),
-                       dim3(EW_T), reserve, st, lv, jobs, n);
+                       dim3(EW_T), 0, st, lv, jobs, n);
     KERNEL_CHECK();
 }
 

@@ -48,6 +48,7 @@ struct NttTable {
     // below 2q when (2^(64-k) + 2) * c <= 2^k.  fold_k = 0: not available (small or unstructured moduli), Barrett is used.
     u32 fold_k, fold_c;
     u32 wide_d4;                       // 2^63 - 4q when that fits 32 bits (wide moduli next to 2^61), else 0
+    u64 r0;                            // low word of floor(2^128 / q) (with r1: the two-word Barrett ratio)
 };
 
 HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
@@ -89,9 +90,10 @@ HD u64 ntt_reduce_any(u64 x, const NttTable &tab)
     return v >= tab.q ? v - tab.q : v;
 }
 
-// Canonical residue of a 128-bit P = hi*2^64 + lo < 2^(2k+1) for q = 2^k - c with 44 <= k <= 61 and c < 2^24 (ntt_fold128_ok):
-// P = Ph*2^k + Pl = Ph*c + Pl; Ph*c is taken in two 32-bit halves of Ph, the upper product T (< 2^(k-7)) is folded once more
-// at its own bit k-32, and every partial sum stays below 2^64:  Pl + A + Th*c + (Tl << 32) < 2^61 + 2^56 + 2^49 + 2^61.
+// Canonical residue of a 128-bit P = hi*2^64 + lo < 2^(2k+2) (a sum of up to FOUR products of residues) for q = 2^k - c with
+// 44 <= k <= 61 and c < 2^24 (ntt_fold128_ok):
+// P = Ph*2^k + Pl = Ph*c + Pl with Ph < 2^(k+2); Ph*c is taken in two 32-bit halves of Ph, the upper product T (< 2^(k-6)) is
+// folded once more at its own bit k-32, and every partial sum stays below 2^64:  Pl + A + Th*c + (Tl << 32) < 2^61 + 2^56 + 2^50 + 2^61.
 // Five narrow multiplies and no quotient word, against ~12 for the two-word Barrett step.
 HD bool ntt_fold128_ok(u32 fold_k, u32 fold_c) { return fold_k >= 44 && fold_k <= 61 && fold_c < (1u << 24); }
 HD u64 ntt_reduce128_fold(u64 hi, u64 lo, const NttTable &tab)
@@ -103,6 +105,14 @@ HD u64 ntt_reduce128_fold(u64 hi, u64 lo, const NttTable &tab)
     const u64 t = (u64)(u32)(ph >> 32) * c;
     const u64 w = pl + a + (u64)(u32)(t >> s) * c + ((t & (((u64)1 << s) - 1)) << 32);
     return ntt_reduce_any(w, tab);
+}
+
+// canonical residue of a 128-bit sum of at most four products of canonical residues: the fold where the modulus admits it,
+// the two-word Barrett step otherwise (wave-uniform choice)
+HD u64 ntt_reduce128(u64 hi, u64 lo, const NttTable &tab)
+{
+    if (ntt_fold128_ok(tab.fold_k, tab.fold_c)) return ntt_reduce128_fold(hi, lo, tab);
+    return barrett128(u128p{ lo, hi }, Mod{ tab.q, tab.r0, tab.r1 });
 }
 
 // Where a pass that reads global memory takes its coefficients from.
@@ -122,15 +132,37 @@ HD u64x2 src_load2(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
         mac128(p1, u[1], v[1]);
     }
     u64x2 r;
-    r[0] = ntt_reduce128_fold(p0.hi, p0.lo, tab);
-    r[1] = ntt_reduce128_fold(p1.hi, p1.lo, tab);
+    r[0] = ntt_reduce128(p0.hi, p0.lo, tab);
+    r[1] = ntt_reduce128(p1.hi, p1.lo, tab);
     return r;
 }
 HD u64 src_load1(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
 {
     u128p p = mul128(s.x0[e], s.y0[e]);
     if (s.x1) mac128(p, s.x1[e], s.y1[e]);
-    return ntt_reduce128_fold(p.hi, p.lo, tab);
+    return ntt_reduce128(p.hi, p.lo, tab);
+}
+// The key switch's inner product with the key, computed on load in front of the inverse transform (App. B10):
+// value(e) = sum_{J < terms} td[J*td_stride + e] * rk[J*rk_stride + e] mod q, terms <= 4 (one per decomposition limb).
+struct SrcKs { const u64 *td, *rk; size_t td_stride, rk_stride; int terms; };
+HD u64x2 src_load2(const SrcKs &s, const u64 *, int e, const NttTable &tab)
+{
+    u128p p0{ 0, 0 }, p1{ 0, 0 };
+    for (int J = 0; J < s.terms; J++) {                          // wave-uniform trip count
+        const u64x2 x = ldg16(s.td + (size_t)J * s.td_stride + e), y = ldg16(s.rk + (size_t)J * s.rk_stride + e);
+        mac128(p0, x[0], y[0]);
+        mac128(p1, x[1], y[1]);
+    }
+    u64x2 r;
+    r[0] = ntt_reduce128(p0.hi, p0.lo, tab);
+    r[1] = ntt_reduce128(p1.hi, p1.lo, tab);
+    return r;
+}
+HD u64 src_load1(const SrcKs &s, const u64 *, int e, const NttTable &tab)
+{
+    u128p p{ 0, 0 };
+    for (int J = 0; J < s.terms; J++) mac128(p, s.td[(size_t)J * s.td_stride + e], s.rk[(size_t)J * s.rk_stride + e]);
+    return ntt_reduce128(p.hi, p.lo, tab);
 }
 
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and

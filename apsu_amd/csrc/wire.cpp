@@ -108,7 +108,12 @@ struct Reader {
     const uint8_t *b;
     size_t n;
     const char *what;
+    // Work budget (flatbuffers::Verifier has max_tables for the same reason): offsets may legally point at shared children,
+    // so a small buffer can describe a quadratic number of (part, ciphertext) visits.  Every table and every vector element
+    // visited costs one unit; a buffer without sharing needs at most n / 4 of them (each owns four bytes).
+    mutable size_t visits = 0;
     [[noreturn]] void bad() const { throw std::runtime_error(std::string("failed to load ") + what + ": invalid buffer"); }
+    void visit(size_t units = 1) const { visits += units; if (visits > n / 4 + 1024) bad(); }
     void need(size_t off, size_t len) const { if (off > n || len > n - off) bad(); }
     uint8_t u8(size_t off) const { need(off, 1); return b[off]; }
     uint16_t u16(size_t off) const { need(off, 2); if (off % 2) bad(); return (uint16_t)(b[off] | (b[off + 1] << 8)); }
@@ -129,6 +134,7 @@ struct Reader {
     }
     Table table(size_t pos) const
     {
+        visit();
         Table t;
         t.pos = pos;
         const int32_t so = (int32_t)u32(pos);
@@ -175,6 +181,7 @@ struct Reader {
         const uint32_t len = u32(pos);
         if ((uint64_t)len * 4 > n) bad();
         need(pos + 4, (size_t)len * 4);
+        visit(len);
         std::vector<size_t> out(len);
         for (uint32_t i = 0; i < len; i++) out[i] = follow(pos + 4 + 4 * (size_t)i);
         return out;
@@ -214,9 +221,8 @@ Header parse_header(const uint8_t *buf, size_t size)
     const Reader::Table t = r.table(r.root());
     Header h;
     h.version = r.get_u32(t, 0, 0);
-    h.type = r.get_u32(t, 1, 0);
-    if (h.type > 4) r.bad();                                           // enum range (flatc verifies known values only by table shape)
-    return h;
+    h.type = r.get_u32(t, 1, 0);           // raw value: the reference's verifier does not range-check the enum either
+    return h;                              // (receiver_operation.cpp:67-86); an unknown type is the dispatcher's rop_invalid
 }
 
 // ================================================================================================ query request

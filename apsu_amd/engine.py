@@ -209,6 +209,14 @@ class HeContext:
     PROFILE_CLASSES = ("ntt_fwd", "ntt_inv", "dyadic_mac", "behz_ext", "behz_tensor", "behz_finish", "keyswitch",
                        "modswitch", "other")
 
+    COUNTERS = ("host_sync", "job_upload", "job_hit", "arena_grow", "powers_alloc", "stage_wrap", "job_realloc")
+
+    def debug_counters(self):
+        """host-side events inside the engine (monotonic): see apsu_he_debug_counters"""
+        out = (C.c_uint64 * len(self.COUNTERS))()
+        _check(load_library().apsu_he_debug_counters(self.h, out, len(self.COUNTERS)))
+        return {k: int(out[i]) for i, k in enumerate(self.COUNTERS)}
+
     def profile_enable(self, mode=1):
         """0/False off, 1/True every kernel class, 2 NTT launches only (least intrusive)"""
         _check(load_library().apsu_he_profile_enable(self.h, int(mode)))
@@ -326,10 +334,6 @@ class HeContext:
     def set_two_stream(self, mode):
         """-1 default policy, 0 off, 1 on: ComputePowers' high-power chain on a second stream"""
         _check(load_library().apsu_he_set_two_stream(self.h, int(mode)))
-
-    def set_eval_pipeline(self, groups):
-        """-1 default policy, 0/1 off, n > 1: up to n BinBundle groups whose database scans overlap the previous group's tail"""
-        _check(load_library().apsu_he_set_eval_pipeline(self.h, int(groups)))
 
     def set_async_results(self, on):
         """eval_bundles with device-resident masks and output returns once its work is queued; see sync() / stream"""

@@ -63,7 +63,9 @@ typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   
 
 const char *apsu_he_last_error(void);
 /* 1: tiers 1 and 2, N1, N2, N4.  2 (additive): apsu_he_multi_*, apsu_he_eval_all, apsu_he_partition_bundles, apsu_he_wire_*,
- * apsu_he_set_eval_pipeline, apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb. */
+ * apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb.
+ * 3: apsu_he_set_eval_pipeline removed (measured-negative scheduling experiment, tools/microbench/); added
+ * apsu_he_debug_counters, apsu_he_phase_*, the SEAL object codec apsu_he_wire_seal_*. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -226,12 +228,6 @@ int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uin
  * contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
 int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
 
-/* Scheduling option of apsu_he_eval_bundles: the BinBundles of a call are cut into up to `groups` groups; a group's
- * database scan (the dyadic multiply-accumulate, HBM-bound, needs only the low powers) runs on a low-priority stream
- * while the main stream finishes the previous group's VALU-bound tail (inverse NTTs, ct x ct products, key switch).
- * Same kernels, operands and results.  groups: -1 = default policy, 0 or 1 = off; APSU_HE_EVAL_PIPE sets the default. */
-int apsu_he_set_eval_pipeline(apsu_he_ctx *ctx, int groups);
-
 /* Device-resident pipelines: with on != 0, an apsu_he_eval_bundles call whose masks AND results live in device memory
  * returns as soon as its work is queued (apsu_he_compute_powers with device-resident sources always does).  The results
  * are complete after apsu_he_sync(ctx), or for work ordered after the context's main HIP stream (apsu_he_stream: a
@@ -300,6 +296,12 @@ int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id
 #define APSU_HE_PROFILE_CLASSES 9
 int apsu_he_profile_enable(apsu_he_ctx *ctx, int mode);   /* 0 off, 1 every class, 2 NTT launches only */
 int apsu_he_profile_read(apsu_he_ctx *ctx, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset);
+
+/* Host-side events inside the engine that cost a query time without being a kernel (diagnosis of launch-bound shards):
+ * 0 host waits, 1 job-table uploads (cache misses), 2 job-table hits, 3 workspace-arena growths, 4 powers-buffer
+ * allocations, 5 wraps of the pinned staging area, 6 job-table re-allocations.  Monotonic since apsu_he_create. */
+#define APSU_HE_DEBUG_COUNTERS 7
+int apsu_he_debug_counters(apsu_he_ctx *ctx, uint64_t *out, int capacity);
 
 #ifdef __cplusplus
 }

@@ -343,24 +343,25 @@ def test_concurrent_callers_on_one_context():
 
 
 def test_fallback_paths_match():
-    # the summed-Bsk finish of eval_patstock's products and the default stream policy of ComputePowers have
-    # alternatives (per-term finish: APSU_HE_EVAL_PER_TERM; ComputePowers forced onto one / two streams: APSU_HE_SPLIT=0/1;
-    # the tensor product formed by the inverse transform's load instead of its own kernel: APSU_HE_FUSE_TENSOR=1;
-    # ComputePowers' BEHZ extension as its own kernel instead of the key switch's mod-down writing it: APSU_HE_FUSE_EXT=0;
-    # read once per process); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte workspace budget
-    # evaluates one BinBundle per chunk.  All must give the same bits, so scenarios run in child processes per switch.
+    # The default path has literal alternatives behind environment switches (read once per process / context): the per-term
+    # finish of eval_patstock's products instead of the summed-Bsk one (APSU_HE_EVAL_PER_TERM); the BEHZ tensor product as its
+    # own kernel instead of being formed by the inverse transform's load (APSU_HE_FUSE_TENSOR=0); ComputePowers' BEHZ
+    # extension as its own kernel instead of the key switch's mod-down writing it (APSU_HE_FUSE_EXT=0); ComputePowers forced
+    # onto one / two streams (APSU_HE_SPLIT=0/1); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte
+    # workspace budget evaluates one BinBundle per chunk.  All must give the same bits; scenarios run in child processes.
     import subprocess, sys, os
     head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu_path as t\n"
             % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     small = "t.test_toy_paterson_stockmeyer_ragged_degrees(); t.test_toy_without_paterson_stockmeyer(); t.test_config_1M_1024_com()\n"
     big = ("t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced(); "
            "t.test_config_16M_4096_reduced()\n")
-    for switch, value, code in (("APSU_HE_EVAL_PER_TERM", "1", small + big), ("APSU_HE_SPLIT", "0", small + big),
-                                ("APSU_HE_SPLIT", "1", small + big), ("APSU_HE_FUSE_TENSOR", "1", small + big), ("APSU_HE_FUSE_EXT", "0", small + big), ("APSU_HE_ARENA_BYTES", "1048576", small),
-                                ("APSU_HE_EVAL_WS_BYTES", "1", small)):
-        env = dict(os.environ, **{switch: value})
+    for switches, code in (({"APSU_HE_EVAL_PER_TERM": "1", "APSU_HE_FUSE_TENSOR": "0"}, small + big),
+                           ({"APSU_HE_FUSE_TENSOR": "0", "APSU_HE_FUSE_EXT": "0", "APSU_HE_SPLIT": "0"}, small + big),
+                           ({"APSU_HE_SPLIT": "1"}, small + big),
+                           ({"APSU_HE_ARENA_BYTES": "1048576", "APSU_HE_EVAL_WS_BYTES": "1"}, small)):
+        env = dict(os.environ, **switches)
         r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, switch + "=" + value + "\n" + r.stdout + r.stderr
+        assert r.returncode == 0, repr(switches) + "\n" + r.stdout + r.stderr
 
 
 def test_powers_outlive_their_context():
@@ -457,8 +458,8 @@ def test_calls_from_a_thread_on_another_device():
 
 
 def test_scheduling_options_do_not_change_bits():
-    """apsu_he_set_two_stream / apsu_he_set_eval_pipeline only move launches between streams: same kernels, same
-    operands, same results (every combination against the oracle-checked default)"""
+    """apsu_he_set_two_stream only moves launches between streams, the host run-ahead bound (APSU_HE_MAX_INFLIGHT) only
+    delays the host: same kernels, same operands, same results (every setting against the oracle-checked default)"""
     import torch
     js = common.param_json("1M-1024-com")
     S = common.make_scenario(js, {0: [124, 77, 30, 124, 9], 1: [124, 5, 60]})
@@ -473,15 +474,28 @@ def test_scheduling_options_do_not_change_bits():
     masks = [b["mask"] for b in S.bundles]
     want = None
     for split in (0, 1):
-        for pipe in (1, 2, 4):
-            G.set_two_stream(split)
-            G.set_eval_pipeline(pipe)
-            for _ in range(2):
-                pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)   # device-resident inputs: the two-stream walk
-                out = G.eval_bundles(gb, pw, rk, masks)
-            if want is None:
-                want = out
-                for i, b in enumerate(S.bundles):
-                    assert (out[i] == common.oracle_eval(S, opw, b)).all()
-            assert (out == want).all(), (split, pipe)
+        G.set_two_stream(split)
+        for _ in range(2):
+            pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)   # device-resident inputs: the two-stream walk
+            out = G.eval_bundles(gb, pw, rk, masks)
+        if want is None:
+            want = out
+            for i, b in enumerate(S.bundles):
+                assert (out[i] == common.oracle_eval(S, opw, b)).all()
+        assert (out == want).all(), split
+    # queued evaluations (device-resident masks and results): six queries behind each other, the host at most two ahead
+    G.set_async_results(True)
+    md = torch.from_numpy(np.stack(masks).view(np.int64)).cuda()
+    od = torch.zeros((len(gb), 2, G.n), dtype=torch.int64, device="cuda")
+    keep = []
+    for _ in range(6):
+        pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)
+        keep.append(pw)                                                          # the caller holds earlier powers: two job-table versions alternate
+        if len(keep) > 2:
+            keep.pop(0)
+        G.eval_bundles(gb, pw, rk, [md.data_ptr() + i * G.n * 8 for i in range(len(gb))], out=od.data_ptr(), masks_on_device=True, out_on_device=True)
+    G.sync()
+    assert (od.cpu().numpy().view(np.uint64).reshape(len(gb), 2, 1, G.n) == want).all()
+    c = G.debug_counters()
+    assert c["job_hit"] > 0 and c["arena_grow"] <= 4
     G.close()

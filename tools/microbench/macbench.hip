@@ -1,5 +1,6 @@
 // Stand-alone timing of the engine's k_mac on a synthetic DB, to bisect its HBM efficiency (see readbw.hip for the ceilings).
 #include "../../apsu_amd/csrc/kernels.hip"
+#include "mac_ring.hip"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -85,8 +86,36 @@ int main(int argc, char** argv) {
             if (rep >= 2) t.push_back(ms);
         }
         std::sort(t.begin(), t.end());
-        printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, APSU_MAC_RING, nb, pad,
+        printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, 2, nb, pad,
                t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
+    }
+    if (getenv("RING")) {
+        // LDS-DMA ring variant: same jobs, separate output, bit-compared with k_mac's
+        u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
+        std::vector<MacJob> jobs2 = jobs;
+        for (size_t x = 0; x < jobs2.size(); x++) for (int g = 0; g < MAC_G; g++) jobs2[x].out[g] = out2 + (jobs[x].out[g] - out);
+        MacJob *dj2; CHECK(hipMalloc(&dj2, jobs2.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj2, jobs2.data(), jobs2.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+        for (unsigned nt = 0; nt < 2; nt++) {
+            std::vector<float> t;
+            for (int rep = 0; rep < 16; rep++) {
+                CHECK(hipEventRecord(e0)); launch_mac_ring(lv, 3, dj2, n, (int)jobs2.size(), 0, nt, getenv("RING_D") ? atoi(getenv("RING_D")) : 3, getenv("RING_LDS_KB") ? atoi(getenv("RING_LDS_KB")) * 1024 : 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep >= 2) t.push_back(ms);
+            }
+            std::sort(t.begin(), t.end());
+            printf("k_mac_ring<%d,T=%d> nt=%u: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", MAC_G, APSU_MAC_RING_T, nt,
+                   t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
+        }
+        const size_t ow = (size_t)streams * 2 * L * n;
+        std::vector<u64> h1(ow), h2(ow);
+        CHECK(hipMemcpy(h1.data(), out, ow * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h2.data(), out2, ow * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t x = 0; x < ow; x++) bad += h1[x] != h2[x];
+        printf("ring vs k_mac: %zu of %zu output words differ\n", bad, ow);
+        // once more k_mac, after the ring runs (same clocks / thermal state)
+        std::vector<float> t;
+        for (int rep = 0; rep < 12; rep++) { CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj, n, (int)jobs.size(), 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms); }
+        std::sort(t.begin(), t.end());
+        printf("k_mac again: min %.3f median %.3f\n", t[0], t[t.size() / 2]);
     }
     if (!getenv("MORPH")) return 0;
     for (int rep = 0; rep < 2; rep++) {
