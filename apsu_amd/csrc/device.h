@@ -64,6 +64,12 @@ struct DevLevel {
     // Same residues, one modular product per coefficient less.  Null for levels that use the generic finish.
     const ShoupConst *fin_q[DMAXL];
     const ShoupConst *fin_b[DMAXB];
+    // The same idea for the consumers of an inverse NTT that drop this level's last limb (mod_switch_to_next: the fused
+    // drop + extension of eval_patstock's inner polynomials, the i = 0 block's finish): the transform writes raw values and
+    // the twist rides on the drop's own constant, drop_tw[j][k] = n^-1 psi_j^-k q_last^-1 mod q_j (j < L - 1);
+    // last_tw[k] = n^-1 psi_{L-1}^-k (the dropped limb needs its canonical residue).  Null where unused.
+    const ShoupConst *drop_tw[DMAXL];
+    const ShoupConst *last_tw;
 };
 
 // Key-switching constants (App. B10); moduli indexed by key limb.
@@ -73,6 +79,9 @@ struct DevKey {
     u64 p_half;
     u64 p_half_mod[DMAXL];
     ShoupConst inv_p[DMAXL];
+    // mod-down behind a RAW inverse transform: md_tw[j][k] = n^-1 psi_j^-k p^-1 mod q_j, p_tw[k] = n^-1 psi_p^-k mod p
+    const ShoupConst *md_tw[DMAXL];
+    const ShoupConst *p_tw;
 };
 
 // Multiply-accumulate job: for g < ng:  out[g][2][L][n] = sum_{j<cnt} PW_j (.) PT_{g,j}   (NTT domain).
@@ -139,8 +148,9 @@ void launch_flag_monomial(const u64 *pt, size_t n, int batch, unsigned char *fla
 void launch_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
                      hipStream_t st);
 // mod_switch_to_next + extension in one pass (input: L + 1 limbs per polynomial at level lv + 1); false = not available for this size
+// raw: `in` comes from an inverse NTT that left out its twist (NTT_MAP_RAW); needs lv[1].drop_tw / last_tw
 bool launch_drop_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
-                          hipStream_t st);
+                          hipStream_t st, bool raw = false);
 struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
 void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
 // The same for a sum of products sharing one output (eval_patstock's sum over i): a, b: [terms][2][E][n];
@@ -152,9 +162,6 @@ void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size
 // output job.d[3][limbs][n], coefficient form), followed by n_plain limbs at `plain` transformed in place; modmap covers both
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
                         const NttTable *tabs, const int *modmap, int period, hipStream_t st);
-// key switch: inner product with the key formed by the load of the inverse transform (acc[batch][2][L+1][n], coefficient form)
-void launch_intt_ks(int logn, const u64 *tdec, const u64 *rk, u64 *acc, int L, int K, int batch, const NttTable *tabs, const int *modmap,
-                    hipStream_t st);
 struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
 void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)
@@ -163,8 +170,9 @@ void launch_behz_finish(const DevLevel *lv, int L, int nB, const FinishJob *jobs
 // key switching
 void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u64 *acc, size_t n, int batch,
                      hipStream_t st);
+// raw: acc comes from an inverse NTT that left out its twist (L <= 4; needs key->md_tw / p_tw)
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
-                       hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0);
+                       hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0, bool raw = false);
 void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
 // Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
 // Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.
@@ -174,6 +182,7 @@ void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, s
 // i = 0 block of eval_patstock when exactly one limb is dropped (bin_bundle.cpp:314-324, note N1):
 // acc[p][m] += (S[p][m] + terms*half - sum_t ((V[t][p] + half) mod q_last)) * q_last^-1  mod q_m
 struct I0Job { const u64 *s; const u64 *v; u64 *acc; int terms; int store; };   // s:[2][L-1][n] v:[terms][2][n] acc:[2][L-1][n] (store: = instead of +=)
-void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st);
+// raw: s and v come from an inverse NTT that left out its twist (needs lv_low->drop_tw / last_tw)
+void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st, bool raw = false);
 
 } // namespace apsu_he

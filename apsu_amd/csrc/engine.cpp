@@ -126,8 +126,10 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_FUSE_EXT")) fuse_ext_ = std::atoi(v) != 0;       // =0: separate extension kernel per DAG level
         fuse_tensor_ = true;
         if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) fuse_tensor_ = std::atoi(v) != 0;
-        // the key switch's inner product with the key formed by the load of the inverse transform behind it (k_intt_ks)
-        if (const char *v = std::getenv("APSU_HE_FUSE_KS")) fuse_ks_ = std::atoi(v) != 0;
+        // the inverse transforms in front of the drop-last-limb / mod-down kernels leave their twist to those kernels' constants
+        // (the way the unrolled BEHZ finish has taken it since round 2): -0.035 +- 0.020 ms (-1.0 %) on the whole query,
+        // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist
+        if (const char *v = std::getenv("APSU_HE_RAW_TWIST")) raw_twist_ = std::atoi(v) != 0;
     }
     // level constants
     {
@@ -236,6 +238,29 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 }
             }
         }
+        // per-position constants of the drop-last-limb consumers of a RAW inverse transform (device.h: drop_tw / last_tw)
+        {
+            std::vector<ShoupConst> dt;
+            std::vector<std::pair<int, int>> where;                   // (level, limb) ; limb = -1: last_tw
+            const TwPair *twbase = reinterpret_cast<const TwPair *>(d_tw_.p());
+            for (int c = 1; c < nl; c++) {
+                const LevelConstants &h = hp_.level[c];
+                const int L = h.L;
+                for (int j = 0; j + 1 < L; j++) {
+                    const NttTablesHost &tb = hp_.ntt[j];
+                    for (size_t k = 0; k < n; k++) dt.push_back(shoup_const(tb.mod.mul(h.inv_q_last[j], tb.scale[k]), tb.mod.value));
+                    where.push_back({ c, j });
+                }
+                // the dropped limb's plain twist is the transform's own scale table (same {w, wq} layout)
+                lv[c].last_tw = reinterpret_cast<const ShoupConst *>(twbase + ((size_t)(L - 1) * 3 + 2) * n);
+            }
+            if (!dt.empty()) {
+                d_drop_.alloc(dt.size() * sizeof(ShoupConst));
+                HIP_CHECK(hipMemcpy(d_drop_.p(), dt.data(), dt.size() * sizeof(ShoupConst), hipMemcpyHostToDevice));
+                const ShoupConst *base = reinterpret_cast<const ShoupConst *>(d_drop_.p());
+                for (size_t i = 0; i < where.size(); i++) lv[where[i].first].drop_tw[where[i].second] = base + i * n;
+            }
+        }
         d_levels_.alloc(lv.size() * sizeof(DevLevel));
         HIP_CHECK(hipMemcpy(d_levels_.p(), lv.data(), lv.size() * sizeof(DevLevel), hipMemcpyHostToDevice));
         auto up = [](DevBuf &b, const std::vector<int> &v) {
@@ -243,6 +268,9 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
             HIP_CHECK(hipMemcpy(b.p(), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
         };
         up(d_map_ext_, map_ext); up(d_map_ext_fin_, map_ext_fin); up(d_map_ks_, map_ks); up(d_map_ksacc_, map_ksacc);
+        std::vector<int> map_ksacc_raw = map_ksacc;
+        for (int &v : map_ksacc_raw) v |= NTT_MAP_RAW;
+        up(d_map_ksacc_raw_, map_ksacc_raw);
         std::vector<int> ident(DMAXL + DMAXB + 4);                     // identity over every modulus id (incl. plain modulus)
         for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
         up(d_map_ct_, ident);
@@ -260,6 +288,16 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 k.p_half_mod[j] = k.p_half % hp_.key_q[j];
                 k.inv_p[j] = shoup_const(hp_.inv_p_mod_q[j], hp_.key_q[j]);
             }
+            // per-position constants of the mod-down behind a RAW inverse transform (device.h: md_tw / p_tw)
+            std::vector<ShoupConst> mt;
+            for (int j = 0; j < hp_.K - 1; j++) {
+                const NttTablesHost &tb = hp_.ntt[j];
+                for (size_t kk = 0; kk < n; kk++) mt.push_back(shoup_const(tb.mod.mul(hp_.inv_p_mod_q[j], tb.scale[kk]), tb.mod.value));
+            }
+            d_mdtw_.alloc(mt.size() * sizeof(ShoupConst));
+            HIP_CHECK(hipMemcpy(d_mdtw_.p(), mt.data(), mt.size() * sizeof(ShoupConst), hipMemcpyHostToDevice));
+            for (int j = 0; j < hp_.K - 1; j++) k.md_tw[j] = reinterpret_cast<const ShoupConst *>(d_mdtw_.p()) + (size_t)j * n;
+            k.p_tw = reinterpret_cast<const ShoupConst *>(reinterpret_cast<const TwPair *>(d_tw_.p()) + ((size_t)(hp_.K - 1) * 3 + 2) * n);
         }
         d_key_.alloc(sizeof(DevKey));
         HIP_CHECK(hipMemcpy(d_key_.p(), &k, sizeof(DevKey), hipMemcpyHostToDevice));
@@ -345,7 +383,7 @@ void Engine::profile_read(ProfStats *out, bool reset)
 
 void Engine::prof_begin(int kind, uint64_t units)
 {
-    if (!prof_on_ || (prof_ntt_only_ && kind > P_NTT_INV)) return;
+    if (!prof_on_ || (prof_ntt_only_ && kind > P_NTT_INV && kind != P_NTT_FUSED)) return;
     ProfRec r{ nullptr, nullptr, kind, units };
     for (hipEvent_t *e : { &r.a, &r.b }) {
         if (!prof_pool_.empty()) { *e = prof_pool_.back(); prof_pool_.pop_back(); }
@@ -572,15 +610,15 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
         launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_);
     }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
-    if (fuse_ks_ && L <= 4) {                                    // the inner product with the key is the inverse transform's load
-        PROF(P_NTT_INV, (uint64_t)batch * 2 * (L + 1));
-        launch_intt_ks(hp_.logn, tdec, rk.data.u(), acc, L, hp_.K, batch, tabs(), map_ksacc(chain_idx), st_);
-    } else {
-        { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
-        d_ntt(acc, (size_t)batch * 2 * (L + 1), map_ksacc(chain_idx), L + 1, true);
-    }
+    // the inverse transform leaves its twist to the mod-down kernel, whose own constants absorb it (unrolled sizes)
+    const bool raw = raw_twist_ && L <= 4;
+    const int *amap = raw ? map_ksacc_raw(chain_idx) : map_ksacc(chain_idx);
+    // (the inner product formed by the inverse transform's load, the way the BEHZ tensor product is, was measured in round 3:
+    //  2 % SLOWER on the whole query -- six operand streams per output and tdec read twice; tools/microbench/intt_ks_experiment.hip)
+    { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
+    d_ntt(acc, (size_t)batch * 2 * (L + 1), amap, L + 1, true);
     const bool fuse_ext = ext_out && n_ext > 0 && fuse_ext_ && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
-    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0); }
+    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0, raw); }
     return fuse_ext;
 }
 
@@ -1025,7 +1063,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                     }
                 }
                 if (fuse_tensor_) {                                                                                              // :422/:424
-                    PROF(P_TENSOR, tj.size() * 3 * Ef);
+                    PROF(P_NTT_FUSED, tj.size() * 3 * Ef);
                     launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_);
                 } else {
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
@@ -1628,6 +1666,10 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
                 const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
                 const bool need_vlast = i0_fast && low > high;
+                // RAW inverse transforms (no twist, no final reduction) where the consumer's own constants absorb the twist:
+                // the inner polynomials when the fused drop + extension kernel takes them, the i = 0 block's sums and last limbs
+                const bool raw_drop = raw_twist_ && low == high + 1 && hlevel(high).L == hlevel(high).nB && hlevel(high).L <= 3;
+                const bool raw_i0 = raw_twist_ && need_vlast;
 
                 // One batch: every Paterson-Stockmeyer BinBundle of the chunk, ordered by bundle index (the shared powers of
                 // one index then stay in the same L2).  (Cutting the batch into groups whose database scans overlap the previous
@@ -1697,6 +1739,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         }
                     }
                     map_push((size_t)g.NI * 2, 0, (int)Ll);
+                    if (raw_drop) for (int &v : g.imap) v |= NTT_MAP_RAW;          // consumed by the fused drop + extension only
                     if (i0_fast) {
                         for (int x = 0; x < Bs; x++) {
                             const Bundle &b = *bundles[c0 + g.ids[x]];
@@ -1704,6 +1747,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                                     (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh });
                         }
                         map_push((size_t)Bs * 2, 0, (int)Lh);
+                        if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * 2 * Lh; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
                     }
                     if (need_vlast || !i0_fast) {
                         for (int x = 0; x < Bs; x++) {
@@ -1720,8 +1764,10 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                                             (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
                             }
                         }
-                        if (i0_fast) map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
-                        else map_push((size_t)Bs * l * 2, 0, (int)Ll);
+                        if (i0_fast) {
+                            map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
+                            if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * l * 2; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
+                        } else map_push((size_t)Bs * l * 2, 0, (int)Ll);
                     }
                     if (!late_high) { cf_streams(g, ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
                     auto mj = group_mac(ms);
@@ -1745,7 +1791,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     bool fused_drop = false;
                     if (low == high + 1) {
                         PROF(P_BEHZ_EXT, 0);
-                        fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_);
+                        fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_, raw_drop);
                     }
                     if (!fused_drop) {
                         u64 *innerh = inner;
@@ -1806,7 +1852,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                     pj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(1 + i, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n });
                                 }
                             { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
-                            PROF(P_TENSOR, dmap.size());
+                            PROF(P_NTT_FUSED, dmap.size());
                             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
                                                tabs(), upload_jobs(dmap), (int)dmap.size(), st_);
                         } else {
@@ -1839,7 +1885,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
                         }
                         if (fuse_tensor_ && tj.size() == (size_t)NI) {
-                            PROF(P_TENSOR, tj.size() * 3 * Eh);
+                            PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
                             launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_);
                         } else {
                             if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
@@ -1859,7 +1905,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         std::vector<I0Job> ij;
                         for (int x = 0; x < Bs; x++)
                             ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
-                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_); }
+                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0); }
                     } else {
                         u64 *termh = term;
                         for (int lv = low; lv > high; lv--) {

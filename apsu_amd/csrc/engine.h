@@ -148,7 +148,7 @@ public:
     void counters_read(uint64_t *out, int capacity) const { for (int i = 0; i < capacity && i < C_COUNT; i++) out[i] = counters_[i]; }
 
     // ---------------- per-kernel timing with HIP events on the engine's stream (bench.py roofline)
-    enum ProfKind { P_NTT_FWD = 0, P_NTT_INV, P_MAC, P_BEHZ_EXT, P_TENSOR, P_BEHZ_FINISH, P_KEYSWITCH, P_MODSWITCH, P_OTHER, P_COUNT };
+    enum ProfKind { P_NTT_FWD = 0, P_NTT_INV, P_MAC, P_BEHZ_EXT, P_TENSOR, P_BEHZ_FINISH, P_KEYSWITCH, P_MODSWITCH, P_OTHER, P_NTT_FUSED, P_COUNT };
     struct ProfStats { double ms[P_COUNT]; uint64_t launches[P_COUNT]; uint64_t units[P_COUNT]; };
     void profile_enable(int mode);      // 0 off, 1 every kernel class, 2 NTT launches only (cheapest)
     void profile_read(ProfStats *out, bool reset);
@@ -180,6 +180,7 @@ private:
     bool fast_finish(int chain_idx) const { const LevelConstants &h = hp_.level[chain_idx]; return h.L == h.nB && h.L <= 3; }
     const int *map_ks(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ks_.p()) + chain_idx * (DMAXL + 1) * DMAXL; }
     const int *map_ksacc(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ksacc_.p()) + chain_idx * (DMAXL + 1); }
+    const int *map_ksacc_raw(int chain_idx) const { return reinterpret_cast<const int *>(d_map_ksacc_raw_.p()) + chain_idx * (DMAXL + 1); }
 
     // device-pointer building blocks
     void d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse);
@@ -198,7 +199,7 @@ private:
     hipStream_t st_ = nullptr;
     std::mutex mu_;                   // ABI calls are serialised per context (thread-safe)
 
-    DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ext_fin_, d_map_ks_, d_map_ksacc_, d_fin_;
+    DevBuf d_tabs_, d_tw_, d_levels_, d_key_, d_map_ct_, d_map_ext_, d_map_ext_fin_, d_map_ks_, d_map_ksacc_, d_map_ksacc_raw_, d_fin_, d_drop_, d_mdtw_;
     DevBuf arena_;
     size_t arena_off_ = 0;
     // Lanes: lane 0 = the main stream, lane 1 = a second stream with its own arena for work that is independent of
@@ -249,7 +250,7 @@ private:
     void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
-    bool fuse_ks_ = false;            // the key switch's inner product is formed by the inverse transform's load (k_intt_ks)
+    bool raw_twist_ = true;           // inverse transforms in front of drop / mod-down kernels leave their twist to those kernels
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
     int two_stream_mode_ = -1;
     void build_schedule();

@@ -167,42 +167,6 @@ void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, s
     KERNEL_CHECK();
 }
 
-// Inverse NTT of the key switch's inner products (App. B10, the accumulation step and the transform behind it in one
-// launch): workgroup g owns acc[b][comp][I] with (b, comp, I) = g / (2 (L+1)), (g / (L+1)) % 2, g % (L+1), forms
-// sum_J tdec[b][I][J] (.) rk[J][comp][ki(I)] while it loads (SrcKs) and writes the coefficient-form limb: k_ks_inner, its
-// 2 (L+1) limb writes per ciphertext and the transform's re-read of them are gone.  L <= 4.
-template <int LOGN, int T>
-__global__ __launch_bounds__(T, 4) void k_intt_ks(const u64 *__restrict__ tdec, const u64 *__restrict__ rk, u64 *__restrict__ acc, int L, int K,
-                                               const NttTable *__restrict__ tabs, const int *__restrict__ modmap)
-{
-    constexpr int N = 1 << LOGN;
-    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
-    const int tid = threadIdx.x;
-    const size_t g = blockIdx.x, per = (size_t)2 * (L + 1), b = g / per;
-    const int r = (int)(g - b * per), comp = r / (L + 1), I = r - comp * (L + 1);
-    const int ki = I == L ? K - 1 : I;
-    const NttTable tab = tabs[modmap[I] & NTT_MAP_MASK];
-    const SrcKs ops{ tdec + ((b * (L + 1) + I) * L) * N, rk + ((size_t)comp * K + ki) * N, (size_t)N, (size_t)2 * K * N, L };
-    u64 *p = acc + g * N;
-    if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
-    else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
-    else ntt_body<LOGN, true, NTT_WIDE, T, false, false, SrcKs>(lds, p, tab, tid, nullptr, ops);
-}
-
-void launch_intt_ks(int logn, const u64 *tdec, const u64 *rk, u64 *acc, int L, int K, int batch, const NttTable *tabs, const int *modmap,
-                    hipStream_t st)
-{
-    const size_t count = (size_t)batch * 2 * (L + 1);
-    if (!count) return;
-#define K_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_ks<LN, T>), dim3((unsigned)count), dim3(T), 0, st, tdec, rk, acc, L, K, tabs, modmap); break;
-    switch (logn) {
-    K_CASE(14, 1024) K_CASE(13, 512) K_CASE(12, 256) K_CASE(11, 128) K_CASE(10, 64) K_CASE(8, 64) K_CASE(6, 64)
-    default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
-    }
-#undef K_CASE
-    KERNEL_CHECK();
-}
-
 template <int LOGN, int T>
 static void launch_ntt_t(bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
                          hipStream_t st)
@@ -801,7 +765,7 @@ __device__ __forceinline__ void behz_ext2_body(const DevLevel *__restrict__ lv, 
 // Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices: same values, ~35 % fewer multiplies.
 // DROP: the input is one level higher (TL + 1 limbs per polynomial) and is first mod-switched to this level
 // (mod_switch_to_next_inplace, bin_bundle.cpp:269,298) — the drop and the extension share one pass over the data.
-template <int TL, bool DROP>
+template <int TL, bool DROP, bool RAW = false>
 __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__ lv, const u64 *__restrict__ in,
                                                     size_t in_stride, int polys, u64 *__restrict__ out, size_t n)
 {
@@ -815,12 +779,23 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__
     if (DROP) {
         const DevLevel *ld = lv + 1;                              // constants of the level being left
         const u64 ql = ld->q[L].q;
-        const u64 last = addmod(src[(size_t)L * n + k], ld->half, ql);
+        u64 lastc = src[(size_t)L * n + k];
+        if (RAW) {                                                // the inverse transform left its twist to this kernel
+            const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(ld->last_tw + k));
+            lastc = mul_shoup(lastc, tw[0], tw[1], ql);
+        }
+        const u64 last = addmod(lastc, ld->half, ql);
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const Mod m = ld->q[j];
             const u64 tmp = submod(barrett64(last, m), ld->half_mod[j], m.q);
-            xin[j] = mul_shoup(submod(src[(size_t)j * n + k], tmp, m.q), ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);
+            if (RAW) {
+                // (c_j - tmp) q_last^-1 with c_j = raw_j * twist: two lazy products, the twist folded into the first constant
+                const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(ld->drop_tw[j] + k));
+                const u64 a = mul_shoup_lazy(src[(size_t)j * n + k], tw[0], tw[1], m.q);                       // [0, 2q)
+                const u64 b = mul_shoup_lazy(tmp, ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);           // [0, 2q)
+                xin[j] = csub(csub(a + (m.q << 1) - b, m.q << 1), m.q);
+            } else xin[j] = mul_shoup(submod(src[(size_t)j * n + k], tmp, m.q), ld->inv_q_last[j].w, ld->inv_q_last[j].wq, m.q);
         }
     } else {
 #pragma unroll
@@ -832,11 +807,14 @@ __global__ __launch_bounds__(EW_T) void k_behz_ext2(const DevLevel *__restrict__
 // drop one limb, then extend: `in` holds polynomials of L + 1 limbs at level lv + 1.  Only for the unrolled sizes;
 // returns false when the caller has to run the two steps separately.
 bool launch_drop_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size_t in_stride, int polys, u64 *out, size_t n, int cts,
-                          hipStream_t st)
+                          hipStream_t st, bool raw)
 {
     if (!cts) return true;
     const dim3 g = ew_grid(n, cts * polys), t(EW_T);
-#define EXT2_CASE(TL) if (L == TL && nB == TL) { hipLaunchKernelGGL((k_behz_ext2<TL, true>), g, t, 0, st, lv, in, in_stride, polys, out, n); KERNEL_CHECK(); return true; }
+#define EXT2_CASE(TL) if (L == TL && nB == TL) { \
+        if (raw) hipLaunchKernelGGL((k_behz_ext2<TL, true, true>), g, t, 0, st, lv, in, in_stride, polys, out, n); \
+        else hipLaunchKernelGGL((k_behz_ext2<TL, true>), g, t, 0, st, lv, in, in_stride, polys, out, n); \
+        KERNEL_CHECK(); return true; }
     EXT2_CASE(1) EXT2_CASE(2) EXT2_CASE(3)
 #undef EXT2_CASE
     return false;
@@ -1198,7 +1176,7 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
 // EXT: the first n_ext ciphertexts are operands of later products (ComputePowers' parents): their BEHZ extension
 // (steps 1-2, behz_ext2_body) is written to ext + (b*2 + comp)*(2L+1)*n while the new (c0, c1) are still in registers --
 // the extension kernel of the next DAG level and its re-read of the ciphertexts disappear.
-template <int TL, bool EXT = false>
+template <int TL, bool EXT = false, bool RAW = false>
 __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ key, int Lrt, const u64 *__restrict__ acc,
                                                      u64 *__restrict__ ct, size_t ct_stride, size_t n,
                                                      const DevLevel *__restrict__ lv = nullptr, u64 *__restrict__ ext = nullptr, int n_ext = 0)
@@ -1212,14 +1190,25 @@ __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ 
     for (int comp = 0; comp < 2; comp++) {
         const u64 *a = acc + (b * 2 + comp) * (size_t)(L + 1) * n;
         u64 *c = ct + b * ct_stride + (size_t)comp * L * n;
-        const u64 tl = barrett64(a[(size_t)L * n + k] + key->p_half, pm);
+        u64 ap = a[(size_t)L * n + k];
+        if (RAW) {                                                // RAW: the inverse transform left its twist to this kernel
+            const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(key->p_tw + k));
+            ap = mul_shoup(ap, tw[0], tw[1], pm.q);
+        }
+        const u64 tl = barrett64(ap + key->p_half, pm);
         u64 x[TL ? TL : 1];
 #pragma unroll
         for (int j = 0; j < (TL ? TL : DMAXL); j++) {
             if (!TL && j >= L) continue;
             const Mod m = key->q[j];
             const u64 tk = submod(barrett64(tl, m), key->p_half_mod[j], m.q);
-            const u64 v = mul_shoup(submod(a[(size_t)j * n + k], tk, m.q), key->inv_p[j].w, key->inv_p[j].wq, m.q);
+            u64 v;
+            if (RAW) {
+                const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(key->md_tw[j] + k));
+                const u64 u = mul_shoup_lazy(a[(size_t)j * n + k], tw[0], tw[1], m.q);                         // [0, 2q)
+                const u64 w = mul_shoup_lazy(tk, key->inv_p[j].w, key->inv_p[j].wq, m.q);                     // [0, 2q)
+                v = csub(csub(u + (m.q << 1) - w, m.q << 1), m.q);
+            } else v = mul_shoup(submod(a[(size_t)j * n + k], tk, m.q), key->inv_p[j].w, key->inv_p[j].wq, m.q);
             const u64 r = addmod(c[(size_t)j * n + k], v, m.q);
             c[(size_t)j * n + k] = r;
             if (EXT) x[j] = r;
@@ -1232,17 +1221,21 @@ __global__ __launch_bounds__(EW_T) void k_ks_moddown(const DevKey *__restrict__ 
 
 // lv / ext / n_ext: see k_ks_moddown<TL, true>; only for L == nB <= 3 (the caller checks), ext == nullptr: plain mod-down
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
-                       hipStream_t st, const DevLevel *lv, u64 *ext, int n_ext)
+                       hipStream_t st, const DevLevel *lv, u64 *ext, int n_ext, bool raw)
 {
+    const dim3 g = ew_grid(n, batch), t(EW_T);
     if (ext && n_ext > 0 && L >= 1 && L <= 3) {
-#define KSX_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL, true>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, lv, ext, n_ext); break;
+#define KSX_CASE(TL) case TL: if (raw) hipLaunchKernelGGL((k_ks_moddown<TL, true, true>), g, t, 0, st, key, L, acc, ct, ct_stride, n, lv, ext, n_ext); \
+                              else hipLaunchKernelGGL((k_ks_moddown<TL, true>), g, t, 0, st, key, L, acc, ct, ct_stride, n, lv, ext, n_ext); break;
         switch (L) { KSX_CASE(1) KSX_CASE(2) KSX_CASE(3) }
 #undef KSX_CASE
         KERNEL_CHECK();
         return;
     }
-#define KS_CASE(TL) case TL: hipLaunchKernelGGL((k_ks_moddown<TL>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); break;
-    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_moddown<0>), ew_grid(n, batch), dim3(EW_T), 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); }
+    if (raw && (L < 1 || L > 4)) throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+#define KS_CASE(TL) case TL: if (raw) hipLaunchKernelGGL((k_ks_moddown<TL, false, true>), g, t, 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); \
+                             else hipLaunchKernelGGL((k_ks_moddown<TL>), g, t, 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); break;
+    switch (L) { KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) default: hipLaunchKernelGGL((k_ks_moddown<0>), g, t, 0, st, key, L, acc, ct, ct_stride, n, nullptr, nullptr, 0); }
 #undef KS_CASE
     KERNEL_CHECK();
 }
@@ -1481,6 +1474,7 @@ void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, s
 
 // Sum of `terms` individually rounded drop-last-limb results, computed from the exact sum S of the kept
 // limbs and the per-term last limbs V (all coefficient form):  SURVEY note N1 / DESIGN.md §4.
+template <bool RAW>
 __global__ __launch_bounds__(EW_T) void k_i0_finish(const DevLevel *__restrict__ lv, const I0Job *__restrict__ jobs, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
@@ -1491,23 +1485,39 @@ __global__ __launch_bounds__(EW_T) void k_i0_finish(const DevLevel *__restrict__
     const u64 ql = lv->q[L - 1].q, half = lv->half;
     u64 R = 0;                                                  // integer sum of (v + half) mod q_last; terms*q_last < 2^64 (host-checked)
     const u64 *v = job.v + (size_t)p * n + k;
-    for (int t = 0; t < job.terms; t++) R += addmod(v[(size_t)t * 2 * n], half, ql);
+    u64 tw0 = 0, tw1 = 0;
+    if (RAW) { const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(lv->last_tw + k)); tw0 = tw[0]; tw1 = tw[1]; }
+    for (int t = 0; t < job.terms; t++) {
+        u64 x = v[(size_t)t * 2 * n];
+        if (RAW) x = mul_shoup(x, tw0, tw1, ql);                // RAW: the inverse transform left its twist to this kernel
+        R += addmod(x, half, ql);
+    }
     for (int m = 0; m + 1 < L; m++) {
         const Mod mq = lv->q[m];
         // terms * (half mod q_m) - (R mod q_m)
         const u64 th = barrett128(mul128((u64)job.terms, lv->half_mod[m]), mq);
         const u64 corr = submod(th, barrett64(R, mq), mq.q);
         const size_t o = ((size_t)p * (L - 1) + m) * n + k;
-        const u64 val = addmod(job.s[o], corr, mq.q);
-        const u64 r = mul_shoup(val, lv->inv_q_last[m].w, lv->inv_q_last[m].wq, mq.q);
+        u64 r;
+        if (RAW) {
+            // (s + corr) q_last^-1 with s = raw * twist: the twist rides on the first product's constant
+            const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(lv->drop_tw[m] + k));
+            const u64 a = mul_shoup_lazy(job.s[o], tw[0], tw[1], mq.q);                                         // [0, 2q)
+            const u64 b = mul_shoup_lazy(corr, lv->inv_q_last[m].w, lv->inv_q_last[m].wq, mq.q);              // [0, 2q)
+            r = csub(csub(a + b, mq.q << 1), mq.q);
+        } else {
+            const u64 val = addmod(job.s[o], corr, mq.q);
+            r = mul_shoup(val, lv->inv_q_last[m].w, lv->inv_q_last[m].wq, mq.q);
+        }
         job.acc[o] = job.store ? r : addmod(job.acc[o], r, mq.q);
     }
 }
 
-void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st)
+void launch_i0_finish(const DevLevel *lv_low, const I0Job *jobs, size_t n, int njobs, hipStream_t st, bool raw)
 {
     if (!njobs) return;
-    hipLaunchKernelGGL(k_i0_finish, ew_grid(n, njobs * 2), dim3(EW_T), 0, st, lv_low, jobs, n);
+    if (raw) hipLaunchKernelGGL(k_i0_finish<true>, ew_grid(n, njobs * 2), dim3(EW_T), 0, st, lv_low, jobs, n);
+    else hipLaunchKernelGGL(k_i0_finish<false>, ew_grid(n, njobs * 2), dim3(EW_T), 0, st, lv_low, jobs, n);
     KERNEL_CHECK();
 }
 

@@ -142,29 +142,6 @@ HD u64 src_load1(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
     if (s.x1) mac128(p, s.x1[e], s.y1[e]);
     return ntt_reduce128(p.hi, p.lo, tab);
 }
-// The key switch's inner product with the key, computed on load in front of the inverse transform (App. B10):
-// value(e) = sum_{J < terms} td[J*td_stride + e] * rk[J*rk_stride + e] mod q, terms <= 4 (one per decomposition limb).
-struct SrcKs { const u64 *td, *rk; size_t td_stride, rk_stride; int terms; };
-HD u64x2 src_load2(const SrcKs &s, const u64 *, int e, const NttTable &tab)
-{
-    u128p p0{ 0, 0 }, p1{ 0, 0 };
-    for (int J = 0; J < s.terms; J++) {                          // wave-uniform trip count
-        const u64x2 x = ldg16(s.td + (size_t)J * s.td_stride + e), y = ldg16(s.rk + (size_t)J * s.rk_stride + e);
-        mac128(p0, x[0], y[0]);
-        mac128(p1, x[1], y[1]);
-    }
-    u64x2 r;
-    r[0] = ntt_reduce128(p0.hi, p0.lo, tab);
-    r[1] = ntt_reduce128(p1.hi, p1.lo, tab);
-    return r;
-}
-HD u64 src_load1(const SrcKs &s, const u64 *, int e, const NttTable &tab)
-{
-    u128p p{ 0, 0 };
-    for (int J = 0; J < s.terms; J++) mac128(p, s.td[(size_t)J * s.td_stride + e], s.rk[(size_t)J * s.rk_stride + e]);
-    return ntt_reduce128(p.hi, p.lo, tab);
-}
-
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
 // makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).
 HD int lds_slot(int e) { return e + ((e >> 4) << 1); }

@@ -207,7 +207,7 @@ class HeContext:
         return [tuple(int(v) for v in r) for r in nodes]
 
     PROFILE_CLASSES = ("ntt_fwd", "ntt_inv", "dyadic_mac", "behz_ext", "behz_tensor", "behz_finish", "keyswitch",
-                       "modswitch", "other")
+                       "modswitch", "other", "ntt_fused")
 
     COUNTERS = ("host_sync", "job_upload", "job_hit", "arena_grow", "powers_alloc", "stage_wrap", "job_realloc")
 

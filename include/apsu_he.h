@@ -292,8 +292,10 @@ int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id
 /* ---- measurement hooks (replace the reference's STOPWATCH timers, receiver_osn.cpp:167,403,504) ----
  * Per-kernel-class device time from HIP events recorded on the engine's stream around each launch.
  * Classes (index): 0 ntt_fwd, 1 ntt_inv, 2 dyadic_mac, 3 behz_ext, 4 behz_tensor, 5 behz_finish,
- * 6 keyswitch, 7 modswitch, 8 other.  units: limb polynomials for 0/1, plaintext limb-terms for 2. */
-#define APSU_HE_PROFILE_CLASSES 9
+ * 6 keyswitch, 7 modswitch, 8 other, 9 ntt_fused (inverse transforms whose load forms the BEHZ tensor product or the key
+ * switch's inner product: k_intt_tensor, k_intt_ks).  units: limb polynomials for 0/1/9, plaintext limb-terms for 2.
+ * mode 2 times classes 0, 1 and 9 only. */
+#define APSU_HE_PROFILE_CLASSES 10
 int apsu_he_profile_enable(apsu_he_ctx *ctx, int mode);   /* 0 off, 1 every class, 2 NTT launches only */
 int apsu_he_profile_read(apsu_he_ctx *ctx, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset);
 

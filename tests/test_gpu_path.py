@@ -346,7 +346,8 @@ def test_fallback_paths_match():
     # The default path has literal alternatives behind environment switches (read once per process / context): the per-term
     # finish of eval_patstock's products instead of the summed-Bsk one (APSU_HE_EVAL_PER_TERM); the BEHZ tensor product as its
     # own kernel instead of being formed by the inverse transform's load (APSU_HE_FUSE_TENSOR=0); ComputePowers' BEHZ
-    # extension as its own kernel instead of the key switch's mod-down writing it (APSU_HE_FUSE_EXT=0); ComputePowers forced
+    # extension as its own kernel instead of the key switch's mod-down writing it (APSU_HE_FUSE_EXT=0); every inverse transform
+    # applying its own twist instead of leaving it to the drop / mod-down kernel behind it (APSU_HE_RAW_TWIST=0); ComputePowers forced
     # onto one / two streams (APSU_HE_SPLIT=0/1); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte
     # workspace budget evaluates one BinBundle per chunk.  All must give the same bits; scenarios run in child processes.
     import subprocess, sys, os
@@ -356,7 +357,7 @@ def test_fallback_paths_match():
     big = ("t.test_toy_wide_primes_many_low_powers_fallback_path(); t.test_config_256M_4096_reduced(); "
            "t.test_config_16M_4096_reduced()\n")
     for switches, code in (({"APSU_HE_EVAL_PER_TERM": "1", "APSU_HE_FUSE_TENSOR": "0"}, small + big),
-                           ({"APSU_HE_FUSE_TENSOR": "0", "APSU_HE_FUSE_EXT": "0", "APSU_HE_SPLIT": "0"}, small + big),
+                           ({"APSU_HE_FUSE_TENSOR": "0", "APSU_HE_FUSE_EXT": "0", "APSU_HE_SPLIT": "0", "APSU_HE_RAW_TWIST": "0"}, small + big),
                            ({"APSU_HE_SPLIT": "1"}, small + big),
                            ({"APSU_HE_ARENA_BYTES": "1048576", "APSU_HE_EVAL_WS_BYTES": "1"}, small)):
         env = dict(os.environ, **switches)
