@@ -13,6 +13,8 @@ from .engine import (  # noqa: F401
     MultiContext,
     Powers,
     RelinKeys,
+    host_alloc,
+    host_free,
     lib_path,
     load_library,
     partition_bundles,

@@ -10,9 +10,11 @@
 #include "engine.h"
 #include "multi.h"
 #include "wire.h"
+#include "seal_codec.h"
 
 using namespace apsu_he;
 
+#include <condition_variable>
 #include <mutex>
 #include <unordered_set>
 
@@ -20,12 +22,13 @@ struct apsu_he_powers;
 // live_powers: the apsu_he_powers handles whose buffers return to this context's pool when they are freed.
 // apsu_he_destroy orphans them (their device buffers are released there), so freeing a handle after its context is
 // safe — the Python binding's garbage collector does exactly that.
-struct apsu_he_ctx { std::unique_ptr<Engine> eng; std::unordered_set<apsu_he_powers *> live_powers; };
+struct apsu_he_ctx { std::unique_ptr<Engine> eng; std::unordered_set<apsu_he_powers *> live_powers; int recycling = 0; };
 struct apsu_he_relin { std::unique_ptr<RelinKeys> rk; };
 struct apsu_he_bundle { std::unique_ptr<Bundle> b; };
 struct apsu_he_powers { std::unique_ptr<Powers> p; apsu_he_ctx *ctx = nullptr; };
 struct apsu_he_multi { std::unique_ptr<MultiEngine> m; };
-static std::mutex g_registry_mu;      // guards every ctx::live_powers and powers::ctx (lock order: registry, then Engine)
+static std::mutex g_registry_mu;      // guards every ctx::live_powers / ctx::recycling and powers::ctx; never held while an Engine lock is taken
+static std::condition_variable g_registry_cv;
 
 static thread_local std::string g_last_error;
 
@@ -81,7 +84,8 @@ int apsu_he_destroy(apsu_he_ctx *ctx)
     return guarded([&] {
         if (!ctx) return;
         {
-            std::lock_guard<std::mutex> g(g_registry_mu);
+            std::unique_lock<std::mutex> g(g_registry_mu);
+            g_registry_cv.wait(g, [&] { return ctx->recycling == 0; });       // a powers_free in flight finishes its recycle first
             for (apsu_he_powers *p : ctx->live_powers) { p->ctx = nullptr; p->p.reset(); }
             ctx->live_powers.clear();
         }
@@ -273,13 +277,24 @@ int apsu_he_powers_free(apsu_he_powers *p)
 {
     return guarded([&] {
         if (!p) return;
+        // the registry lock only covers the bookkeeping: recycling takes the Engine's own lock, which a long synchronous call
+        // on that context may hold -- it must not stall powers_free / compute_powers / destroy of OTHER contexts.  A context
+        // being destroyed concurrently is kept alive for the recycle by its `recycling` count (apsu_he_destroy waits for 0).
+        apsu_he_ctx *owner = nullptr;
         {
             std::lock_guard<std::mutex> g(g_registry_mu);
             if (p->ctx) {
-                p->ctx->live_powers.erase(p);
-                p->ctx->eng->recycle_powers(std::move(p->p));
+                owner = p->ctx;
+                owner->live_powers.erase(p);
+                owner->recycling++;
                 p->ctx = nullptr;
             }
+        }
+        if (owner) {
+            try { owner->eng->recycle_powers(std::move(p->p)); } catch (...) { }
+            std::lock_guard<std::mutex> g(g_registry_mu);
+            owner->recycling--;
+            g_registry_cv.notify_all();
         }
         delete p;
     });
@@ -318,6 +333,29 @@ int apsu_he_partition_bundles(uint32_t bundle_idx_count, int n_devices, const ui
         for (int i = 0; i < count; i++) u[i] = ShardUnit{ bundle_idx[i], cache_idx[i], degree[i] };
         auto r = partition_units(u, bundle_idx_count, n_devices);
         for (int i = 0; i < count; i++) device_slot[i] = r[i];
+    });
+}
+int apsu_he_partition_bundles_ex(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
+                                 const uint32_t *degree, int count, uint64_t compute_powers_cost, int *device_slot)
+{
+    return guarded([&] {
+        REQUIRE(count >= 0 && (count == 0 || (bundle_idx && cache_idx && degree && device_slot)), "null argument");
+        std::vector<ShardUnit> u(count);
+        for (int i = 0; i < count; i++) u[i] = ShardUnit{ bundle_idx[i], cache_idx[i], degree[i] };
+        auto r = partition_units(u, bundle_idx_count, n_devices, compute_powers_cost);
+        for (int i = 0; i < count; i++) device_slot[i] = r[i];
+    });
+}
+// ComputePowers for ONE bundle index in the partition rule's cost unit (degree + 64 per BinBundle): about 110 per ciphertext
+// product of the PowersDag on MI355X (16M-4096: 66 products = 0.3-0.47 ms against 0.082 ms per BinBundle of degree 1303;
+// 256M-4096: 311 products = 2.0 ms against 0.213 ms per BinBundle of degree 3999; profiles/r02_rank_cost*.txt)
+int apsu_he_compute_powers_cost(const apsu_he_ctx *ctx, uint64_t *cost)
+{
+    return guarded([&] {
+        REQUIRE(ctx && cost, "null argument");
+        REQUIRE(ctx->eng->psu(), "context was created without PSUParams");
+        const PowersDag &dag = ctx->eng->dag();
+        *cost = 110u * (uint64_t)(dag.target_powers().size() - dag.source_count());
     });
 }
 
@@ -363,6 +401,42 @@ int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uin
         m->m->eval_all(src_cts, masks, out_cts, out_device_slot);
     });
 }
+int apsu_he_eval_all_ex(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts, int out_device_slot,
+                        unsigned flags, int in_device_slot)
+{
+    return guarded([&] {
+        REQUIRE(m && src_cts && masks && out_cts, "null argument");
+        REQUIRE((flags & ~0x3fu) == 0, "unknown flag");
+        m->m->eval_all(src_cts, masks, out_cts, out_device_slot, flags, in_device_slot);
+    });
+}
+const char *apsu_he_multi_last_gather(const apsu_he_multi *m) { return m ? m->m->last_gather() : ""; }
+int apsu_he_multi_phase_enable(apsu_he_multi *m, int on)
+{ return guarded([&] { REQUIRE(m, "null argument"); m->m->phase_enable(on != 0); }); }
+int apsu_he_multi_phase_read(apsu_he_multi *m, uint64_t *count, double *avg_ms, double *min_ms, double *max_ms, int reset)
+{
+    return guarded([&] {
+        REQUIRE(m, "null argument");
+        Engine::PhaseSummary all[Engine::PH_COUNT];
+        m->m->phase_read(all, reset != 0);
+        for (int i = 0; i < Engine::PH_COUNT; i++) {
+            if (count) count[i] = all[i].count;
+            if (avg_ms) avg_ms[i] = all[i].count ? all[i].sum_ms / (double)all[i].count : 0.0;
+            if (min_ms) min_ms[i] = all[i].min_ms;
+            if (max_ms) max_ms[i] = all[i].max_ms;
+        }
+    });
+}
+int apsu_he_host_alloc(size_t bytes, void **out)
+{
+    return guarded([&] {
+        REQUIRE(out && bytes, "null argument");
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+        *out = p;
+    });
+}
+int apsu_he_host_free(void *p) { return guarded([&] { if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); throw std::invalid_argument("not an apsu_he_host_alloc pointer"); } }); }
 
 // ---- N3: network framing (wire.h); host only
 struct apsu_he_wire_query { wire::QueryRequest q; };
@@ -495,17 +569,154 @@ int apsu_he_wire_result_label(const uint8_t *buf, size_t size, uint32_t index, c
         *data = p.label_result[index].p; *data_size = p.label_result[index].n;
     });
 }
+// every label of a package with ONE parse: data / sizes hold n_labels entries (as reported by apsu_he_wire_parse_result_package)
+int apsu_he_wire_result_labels(const uint8_t *buf, size_t size, uint32_t capacity, const uint8_t **data, size_t *sizes, uint32_t *n_labels)
+{
+    return guarded([&] {
+        REQUIRE(buf && (capacity == 0 || (data && sizes)), "null argument");
+        const wire::ResultPackage p = wire::parse_result_package(buf, size);
+        if (n_labels) *n_labels = (uint32_t)p.label_result.size();
+        REQUIRE(capacity == 0 || capacity >= p.label_result.size(), "label arrays too small");
+        for (size_t i = 0; i < p.label_result.size() && i < capacity; i++) { data[i] = p.label_result[i].p; sizes[i] = p.label_result[i].n; }
+    });
+}
+// ---- N3: SEAL's object serialisation (seal_codec.h; UNPINNED)
+struct apsu_he_seal_ctx { std::vector<sealio::Level> chain; size_t n = 0, K = 0; u64 t = 0; };
+static const sealio::Level &seal_level(const apsu_he_seal_ctx *c, int chain_idx)
+{
+    // chain[0] = key level (all K primes), chain[1 + i] = the level with K - 1 - i primes
+    const int K = (int)c->K;
+    if (chain_idx < 0 || chain_idx == K - 1) return c->chain[0];
+    REQUIRE(chain_idx < K - 1, "chain_idx out of range");
+    return c->chain[(size_t)(K - 1 - chain_idx)];
+}
+static int seal_chain_idx(const apsu_he_seal_ctx *c, const uint64_t id[4])
+{
+    for (size_t i = 0; i < c->chain.size(); i++)
+        if (!std::memcmp(c->chain[i].parms_id, id, 32)) return (int)c->chain[i].q.size() - 1;
+    return -1;
+}
+int apsu_he_seal_ctx_create_raw(uint64_t n, const uint64_t *coeff_modulus, int k, uint64_t plain_modulus, apsu_he_seal_ctx **out)
+{
+    return guarded([&] {
+        REQUIRE(coeff_modulus && out && k > 0 && k <= 64 && n >= 2 && n <= (1u << 20), "bad argument");
+        auto c = new apsu_he_seal_ctx;
+        c->n = (size_t)n; c->K = (size_t)k; c->t = plain_modulus;
+        c->chain = sealio::modulus_chain(n, std::vector<uint64_t>(coeff_modulus, coeff_modulus + k), plain_modulus);
+        *out = c;
+    });
+}
+int apsu_he_seal_ctx_create(const char *json, apsu_he_seal_ctx **out)
+{
+    return guarded([&] {
+        REQUIRE(json && out, "null argument");
+        PSUParams p = PSUParams::Load(json);
+        HeParams hp = HeParams::FromPSUParams(p);
+        auto c = new apsu_he_seal_ctx;
+        c->n = hp.n; c->K = (size_t)hp.K; c->t = hp.t;
+        c->chain = sealio::modulus_chain(hp.n, std::vector<uint64_t>(hp.key_q.begin(), hp.key_q.begin() + hp.K), hp.t);
+        *out = c;
+    });
+}
+int apsu_he_seal_ctx_free(apsu_he_seal_ctx *c) { return guarded([&] { delete c; }); }
+int apsu_he_seal_parms_id(const apsu_he_seal_ctx *c, int chain_idx, uint64_t out[4])
+{ return guarded([&] { REQUIRE(c && out, "null argument"); std::memcpy(out, seal_level(c, chain_idx).parms_id, 32); }); }
+int apsu_he_seal_sample_poly_uniform(const apsu_he_seal_ctx *c, int chain_idx, const uint64_t seed[8], uint64_t *out)
+{
+    return guarded([&] {
+        REQUIRE(c && seed && out, "null argument");
+        const sealio::Level &l = seal_level(c, chain_idx);
+        sealio::sample_poly_uniform(seed, l.q.data(), l.q.size(), c->n, out);
+    });
+}
+int apsu_he_seal_ct_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t parms_id[4], int *chain_idx, int *is_ntt_form,
+                         uint64_t *ct_size, uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, int *was_seeded, uint64_t *data,
+                         size_t data_capacity_words, size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        static const std::vector<sealio::Level> none;
+        const sealio::Ciphertext ct = sealio::load_ciphertext(buf, size, c ? c->chain : none, consumed);
+        if (parms_id) std::memcpy(parms_id, ct.parms_id, 32);
+        if (chain_idx) *chain_idx = c ? seal_chain_idx(c, ct.parms_id) : -1;
+        if (is_ntt_form) *is_ntt_form = ct.is_ntt_form;
+        if (ct_size) *ct_size = ct.size;
+        if (poly_modulus_degree) *poly_modulus_degree = ct.poly_modulus_degree;
+        if (coeff_modulus_size) *coeff_modulus_size = ct.coeff_modulus_size;
+        if (was_seeded) *was_seeded = ct.seeded ? 1 : 0;
+        if (data) {
+            REQUIRE(data_capacity_words >= ct.data.size(), "output buffer too small");
+            std::memcpy(data, ct.data.data(), ct.data.size() * sizeof(uint64_t));
+        }
+    });
+}
+int apsu_he_seal_ct_save(const apsu_he_seal_ctx *c, int chain_idx, int is_ntt_form, uint64_t ct_size, const uint64_t *data, const uint64_t *seed,
+                         int compr_mode, int version_major, int version_minor, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(c && data && out && out_size && ct_size >= 1 && ct_size <= 64, "bad argument");
+        const sealio::Level &l = seal_level(c, chain_idx);
+        sealio::Ciphertext ct;
+        std::memcpy(ct.parms_id, l.parms_id, 32);
+        ct.is_ntt_form = is_ntt_form ? 1 : 0; ct.size = ct_size; ct.poly_modulus_degree = c->n; ct.coeff_modulus_size = l.q.size();
+        ct.version_major = (uint8_t)version_major; ct.version_minor = (uint8_t)version_minor;
+        ct.data.assign(data, data + ct_size * l.q.size() * c->n);
+        if (seed) { ct.seeded = true; std::memcpy(ct.seed, seed, 64); }
+        wire_out(sealio::save_ciphertext(ct, (uint8_t)compr_mode), out, out_size);
+    });
+}
+int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,
+                                 size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(c && buf, "null argument");
+        const sealio::KSwitchKeys k = sealio::load_kswitch_keys(buf, size, c->chain, consumed);
+        if (std::memcmp(k.parms_id, c->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
+        const std::vector<uint64_t> flat = sealio::relin_keys_layout(k, c->K, c->n);
+        if (words) *words = flat.size();
+        if (ksk) {
+            REQUIRE(capacity_words >= flat.size(), "output buffer too small");
+            std::memcpy(ksk, flat.data(), flat.size() * sizeof(uint64_t));
+        }
+    });
+}
+int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk, const uint64_t *seeds, int compr_mode, int version_major,
+                                 int version_minor, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(c && ksk && out && out_size && c->K >= 2, "bad argument");
+        sealio::KSwitchKeys k;
+        std::memcpy(k.parms_id, c->chain[0].parms_id, 32);
+        k.version_major = (uint8_t)version_major; k.version_minor = (uint8_t)version_minor;
+        k.keys.resize(1);
+        const size_t per = 2 * c->K * c->n;
+        for (size_t j = 0; j + 1 < c->K; j++) {
+            sealio::Ciphertext ct;
+            std::memcpy(ct.parms_id, c->chain[0].parms_id, 32);
+            ct.is_ntt_form = 1; ct.size = 2; ct.poly_modulus_degree = c->n; ct.coeff_modulus_size = c->K;
+            ct.version_major = k.version_major; ct.version_minor = k.version_minor;
+            ct.data.assign(ksk + j * per, ksk + (j + 1) * per);
+            if (seeds) { ct.seeded = true; std::memcpy(ct.seed, seeds + 8 * j, 64); }
+            k.keys[0].push_back(std::move(ct));
+        }
+        wire_out(sealio::save_kswitch_keys(k, (uint8_t)compr_mode), out, out_size);
+    });
+}
+// the round-2 entry points (no context: unseeded objects only; zlib bodies are inflated)
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,
                               int version_major, int version_minor, uint8_t **out, size_t *out_size)
 {
     return guarded([&] {
         REQUIRE(parms_id && data && out && out_size, "null argument");
-        wire::SealCt ct;
-        for (int i = 0; i < 4; i++) ct.parms_id[i] = parms_id[i];
+        REQUIRE(ct_size <= 64 && coeff_modulus_size <= 64 && poly_modulus_degree <= (1u << 20), "implausible dimensions");
+        sealio::Ciphertext ct;
+        std::memcpy(ct.parms_id, parms_id, 32);
         ct.is_ntt_form = is_ntt_form ? 1 : 0; ct.size = ct_size; ct.poly_modulus_degree = poly_modulus_degree;
-        ct.coeff_modulus_size = coeff_modulus_size; ct.correction_factor = correction_factor; ct.scale = scale; ct.data = data;
-        wire_out(wire::seal_envelope_save(ct, (uint8_t)version_major, (uint8_t)version_minor), out, out_size);
+        ct.coeff_modulus_size = coeff_modulus_size; ct.correction_factor = correction_factor; ct.scale = scale;
+        ct.version_major = (uint8_t)version_major; ct.version_minor = (uint8_t)version_minor;
+        ct.data.assign(data, data + ct_size * coeff_modulus_size * poly_modulus_degree);
+        wire_out(sealio::save_ciphertext(ct, sealio::COMPR_NONE), out, out_size);
     });
 }
 int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id[4], int *is_ntt_form, uint64_t *ct_size,
@@ -514,22 +725,38 @@ int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id
 {
     return guarded([&] {
         REQUIRE(buf, "null argument");
-        uint8_t maj = 0, mn = 0;
-        const wire::SealCt ct = wire::seal_envelope_load(buf, size, &maj, &mn);
-        const uint64_t words = ct.size * ct.coeff_modulus_size * ct.poly_modulus_degree;
-        if (parms_id) for (int i = 0; i < 4; i++) parms_id[i] = ct.parms_id[i];
+        const sealio::Ciphertext ct = sealio::load_ciphertext(buf, size, {});
+        if (parms_id) std::memcpy(parms_id, ct.parms_id, 32);
         if (is_ntt_form) *is_ntt_form = ct.is_ntt_form;
         if (ct_size) *ct_size = ct.size;
         if (poly_modulus_degree) *poly_modulus_degree = ct.poly_modulus_degree;
         if (coeff_modulus_size) *coeff_modulus_size = ct.coeff_modulus_size;
         if (correction_factor) *correction_factor = ct.correction_factor;
         if (scale) *scale = ct.scale;
-        if (version_major) *version_major = maj;
-        if (version_minor) *version_minor = mn;
+        if (version_major) *version_major = ct.version_major;
+        if (version_minor) *version_minor = ct.version_minor;
         if (data) {
-            REQUIRE(data_capacity_words >= words, "output buffer too small");
-            std::memcpy(data, ct.data, words * sizeof(uint64_t));
+            REQUIRE(data_capacity_words >= ct.data.size(), "output buffer too small");
+            std::memcpy(data, ct.data.data(), ct.data.size() * sizeof(uint64_t));
         }
+    });
+}
+
+const char *apsu_he_phase_name(int phase) { return Engine::phase_name(phase); }
+int apsu_he_phase_enable(apsu_he_ctx *c, int on)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->phase_enable(on != 0); }); }
+int apsu_he_phase_read(apsu_he_ctx *c, int phase, uint64_t *count, double *avg_ms, double *min_ms, double *max_ms, int reset)
+{
+    return guarded([&] {
+        REQUIRE(c && phase >= 0 && phase < Engine::PH_COUNT, "unknown phase");
+        Engine::PhaseSummary all[Engine::PH_COUNT];
+        c->eng->phase_read(all, false);
+        const Engine::PhaseSummary &p = all[phase];
+        if (count) *count = p.count;
+        if (avg_ms) *avg_ms = p.count ? p.sum_ms / (double)p.count : 0.0;
+        if (min_ms) *min_ms = p.min_ms;
+        if (max_ms) *max_ms = p.max_ms;
+        if (reset) c->eng->phase_read(nullptr, true);
     });
 }
 

@@ -332,6 +332,9 @@ Engine::~Engine()
     if (st_) (void)hipStreamDestroy(st_);
     if (parked_.st) (void)hipStreamDestroy(parked_.st);
     for (hipEvent_t e : inflight_) if (e) (void)hipEventDestroy(e);
+    for (PhaseSpan &sp : phase_spans_) for (hipEvent_t e : { sp.a, sp.b, sp.b2 }) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : phase_pool_) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : { query_start_, query_end_ }) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
 }
@@ -419,6 +422,62 @@ void Engine::prof_collect()
     }
     prof_recs_.clear();
     if (keep) prof_recs_.push_back(open_rec);
+}
+
+// ---- phase timers
+const char *Engine::phase_name(int phase)
+{
+    static const char *names[PH_COUNT] = { "Receiver::RunQuery", "Receiver::ComputePowers", "Receiver::ProcessBinBundleCache" };
+    return phase >= 0 && phase < PH_COUNT ? names[phase] : "";
+}
+
+hipEvent_t Engine::phase_event(hipStream_t st)
+{
+    hipEvent_t e = nullptr;
+    if (!phase_pool_.empty()) { e = phase_pool_.back(); phase_pool_.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipEventRecord(e, st));
+    return e;
+}
+
+void Engine::phase_close_query()
+{
+    if (query_start_ && query_end_) phase_spans_.push_back(PhaseSpan{ query_start_, query_end_, nullptr, PH_RUN_QUERY });
+    else { if (query_start_) phase_pool_.push_back(query_start_); if (query_end_) phase_pool_.push_back(query_end_); }
+    query_start_ = query_end_ = nullptr;
+}
+
+void Engine::phase_collect()
+{
+    for (PhaseSpan &sp : phase_spans_) {
+        float ms = 0, ms2 = 0;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            if (sp.b2 && hipEventSynchronize(sp.b2) == hipSuccess && hipEventElapsedTime(&ms2, sp.a, sp.b2) == hipSuccess) ms = std::max(ms, ms2);
+            PhaseSummary &p = phase_[sp.phase];
+            p.min_ms = p.count ? std::min(p.min_ms, (double)ms) : ms;
+            p.max_ms = p.count ? std::max(p.max_ms, (double)ms) : ms;
+            p.sum_ms += ms;
+            p.count++;
+        }
+        for (hipEvent_t e : { sp.a, sp.b, sp.b2 }) if (e) phase_pool_.push_back(e);
+    }
+    phase_spans_.clear();
+}
+
+void Engine::phase_enable(bool on)
+{
+    Enter g(this);
+    if (!on && phase_on_) { phase_close_query(); phase_collect(); }
+    phase_on_ = on;
+}
+
+void Engine::phase_read(PhaseSummary *out, bool reset)
+{
+    Enter g(this);
+    phase_close_query();
+    phase_collect();
+    if (out) for (int i = 0; i < PH_COUNT; i++) out[i] = phase_[i];
+    if (reset) for (int i = 0; i < PH_COUNT; i++) phase_[i] = PhaseSummary{};
 }
 
 struct ProfScope {
@@ -1184,6 +1243,13 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     }
 
     struct LaneGuard { Engine *e; ~LaneGuard() { e->switch_lane(0); } } lane_guard{ this };
+    PhaseSpan cp_span;
+    if (phase_on_) {
+        phase_close_query();
+        cp_span.phase = PH_COMPUTE_POWERS;
+        cp_span.a = phase_event(st_);
+        query_start_ = phase_event(st_);
+    }
     // Two-stream walk: the high-power half of the DAG runs on the second stream next to the low-power half and to the
     // BinBundle inner products.  Measured on 16M-4096 (tools/pipe_sweep.py, tools/rank_cost.py): 3.84 ->
     // 3.65 ms for the whole query (four bundle indices), 0.95 -> 0.86 ms per rank with one bundle index.  Default: on
@@ -1195,6 +1261,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
     WITH_ARENA({
+        for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
         if (!split) {
             DagRun r;
             run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
@@ -1222,12 +1289,15 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             switch_lane(1);
             run_dag(sched_high_, rh, -1, nb, src, on_device, rk, *pw, false, true);
             HIP_CHECK(hipEventRecord(pw->high_ready, st_));
+            if (phase_on_ && cp_span.a && !cp_span.b2) cp_span.b2 = phase_event(st_);
             switch_lane(0);
         }
+        if (phase_on_ && cp_span.a && !cp_span.b) cp_span.b = phase_event(st_);
         // device-resident inputs: no sync, consumers (eval_bundles, powers_download) are ordered on / synchronise
         // with the engine's streams.  Host inputs: the caller's buffers must have been consumed before returning.
         if (!on_device) sync();
     });
+    if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
     return pw;
 }
 
@@ -1565,13 +1635,16 @@ void Engine::decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_devi
 
 // ============================================================================ tier 2: BinBundle evaluation
 void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
-                          const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device)
+                          const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device, u64 *const *out_rows)
 {
+    if (out_rows && !out_on_device) throw std::invalid_argument("out_rows are device-accessible destinations");
     Enter g(this);
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (count <= 0) return;
     const size_t n = hp_.n;
     job_seq_base_ = 256;                                     // job-cache slots 256..: eval_bundles
+    PhaseSpan ev_span;
+    if (phase_on_) { ev_span.phase = PH_PROCESS_BIN_BUNDLE_CACHE; ev_span.a = phase_event(st_); }
     const uint32_t ps = psu_.query_params.ps_low_degree, l = ps;
     const int high = pw.high_level, low = pw.low_level;
     const size_t Ll = low + 1, Lh = high + 1;
@@ -1623,7 +1696,8 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
         const int B = std::min(chunk, count - c0);
         WITH_ARENA({
             // final [B][2][1][n]: written in place when the caller's buffer is on the device
-            u64 *res = out_on_device ? out + (size_t)c0 * 2 * n : ws((size_t)B * 2 * n);
+            u64 *res = out_rows ? nullptr : (out_on_device ? out + (size_t)c0 * 2 * n : ws((size_t)B * 2 * n));
+            auto res_ptr = [&](int i) { return out_rows ? out_rows[c0 + i] : res + (size_t)i * 2 * n; };
             u64 *mask_d = nullptr;
             if (!masks_on_device) {
                 mask_d = ws((size_t)B * n);
@@ -1649,7 +1723,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     if (b.degree) ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
                                                           (u32)(Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv });   // :140-149
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
-                    ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res + (size_t)pl_ids[x] * 2 * n });
+                    ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
                 }
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
@@ -1923,13 +1997,18 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     std::vector<EpiJob> ej;
                     for (int x = 0; x < Bs; x++)
                         ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
-                                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res + (size_t)g.ids[x] * 2 * n });
+                                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]) });
                     { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
                 }
             }
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             // device-resident masks and results: nothing of the caller's is read or written by the host, so the call may
             // return with the work queued (stream order protects the workspace, the job tables and the pooled powers)
+            if (phase_on_ && c0 + B >= count) {                  // the last chunk closes the span (before any host wait)
+                ev_span.b = phase_event(st_);
+                phase_spans_.push_back(ev_span);
+                if (query_start_) { if (query_end_) phase_pool_.push_back(query_end_); query_end_ = phase_event(st_); }
+            }
             if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) { sync(); inflight_count_ = 0; }
             else mark_inflight();
         });

@@ -136,8 +136,10 @@ public:
     std::unique_ptr<Powers> compute_powers(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device,
                                            const RelinKeys *rk);
     // masks[i]: n words mod t (host, or device if on_device).  out: count * 2n words (host or device).
+    // out_rows (optional, implies device-accessible destinations): result i goes to out_rows[i] (2n words) instead of
+    // out + i * 2n -- rows of another device's buffer (peer access) or of page-locked host memory are written in place.
     void eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
-                      const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device);
+                      const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device, u64 *const *out_rows = nullptr);
 
     // introspection for tests
     size_t workspace_bytes() const { return arena_.bytes(); }
@@ -152,6 +154,14 @@ public:
     struct ProfStats { double ms[P_COUNT]; uint64_t launches[P_COUNT]; uint64_t units[P_COUNT]; };
     void profile_enable(int mode);      // 0 off, 1 every kernel class, 2 NTT launches only (cheapest)
     void profile_read(ProfStats *out, bool reset);
+    // ---------------- phase timers under the reference's STOPWATCH names (receiver_osn.cpp:167,403,504): device time from HIP
+    // events on the engine's streams.  RunQuery = start of a compute_powers call .. end of the last eval_bundles call before the
+    // next compute_powers; ComputePowers ends when BOTH streams of a two-stream walk have finished.
+    enum Phase { PH_RUN_QUERY = 0, PH_COMPUTE_POWERS, PH_PROCESS_BIN_BUNDLE_CACHE, PH_COUNT };
+    struct PhaseSummary { uint64_t count = 0; double sum_ms = 0, min_ms = 0, max_ms = 0; };      // cli/common_utils.cpp:54-76 prints these
+    static const char *phase_name(int phase);
+    void phase_enable(bool on);
+    void phase_read(PhaseSummary *out, bool reset);            // out[PH_COUNT]; waits for the recorded work
     // two-stream ComputePowers: -1 = default policy (on for one or two bundle indices), 0 = off, 1 = on
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
     // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
@@ -271,6 +281,16 @@ private:
     void prof_end();
     void prof_collect();
 
+    // phase timers
+    struct PhaseSpan { hipEvent_t a = nullptr, b = nullptr, b2 = nullptr; int phase = 0; };
+    bool phase_on_ = false;
+    std::vector<PhaseSpan> phase_spans_;
+    std::vector<hipEvent_t> phase_pool_;
+    PhaseSummary phase_[PH_COUNT];
+    hipEvent_t query_start_ = nullptr, query_end_ = nullptr;     // the open RunQuery span
+    hipEvent_t phase_event(hipStream_t st);
+    void phase_close_query();
+    void phase_collect();
     struct Enter;                     // lock + current-device guard taken by every public entry point
     friend struct EngineAccess;
     friend struct ProfScope;

@@ -37,10 +37,21 @@ public:
     int bundle_device(int id) const { return where_.at(id).first; }
     void clear_bundles();
 
-    // One query.  src_cts[b * source_count + s]: host ciphertexts of every bundle index (each device reads its own);
-    // masks[id]: n words mod t (host); out: bundle_count * 2n words, row = bundle id — host memory when
-    // out_slot < 0, else device memory on devices[out_slot] (gathered with peer copies over xGMI).
-    void eval_all(const u64 *const *src_cts, const u64 *const *masks, u64 *out, int out_slot);
+    // One query.  src_cts[b * source_count + s]: ciphertexts of every bundle index (each device reads its own);
+    // masks[id]: n words mod t; out: bundle_count * 2n words, row = bundle id — host memory when out_slot < 0, else device
+    // memory on devices[out_slot] (gathered over xGMI: peer copies, or one RCCL all-gather with IO_GATHER_RCCL).
+    // flags: where the caller's buffers live.  Host buffers are pageable unless flagged page-locked (IO_*_PINNED: DMA goes
+    // straight from / to them; pageable ones are staged through the device's own page-locked area, copy and DMA pipelined).
+    // IO_SRC_ON_DEVICE / IO_MASKS_ON_DEVICE: the pointers are device pointers on devices[in_slot] (other devices fetch
+    // what they need with peer copies).  Everything of a device's share is queued on its streams before the first wait.
+    enum : unsigned { IO_SRC_PINNED = 1, IO_MASKS_PINNED = 2, IO_OUT_PINNED = 4, IO_SRC_ON_DEVICE = 8, IO_MASKS_ON_DEVICE = 16,
+                      IO_GATHER_RCCL = 32 };
+    void eval_all(const u64 *const *src_cts, const u64 *const *masks, u64 *out, int out_slot, unsigned flags = 0, int in_slot = 0);
+    // what the last device-side gather used: "peer" or "rccl" ("" before the first one / host destination)
+    const char *last_gather() const { return last_gather_; }
+    // phase timers (Engine::phase_*): RunQuery = host wall time of eval_all; the other two = the slowest device's
+    void phase_enable(bool on);
+    void phase_read(Engine::PhaseSummary *out, bool reset);
 
 private:
     struct Dev {
@@ -52,6 +63,10 @@ private:
         DevBuf out;                                               // [bundles][2n] results of this device
         void *host_out = nullptr;                                 // pinned staging of the same size
         size_t host_out_bytes = 0;
+        DevBuf in;                                                // this device's query inputs: sources, then masks
+        void *host_in = nullptr;                                  // pinned staging for pageable inputs
+        size_t host_in_bytes = 0;
+        DevBuf gath;                                              // RCCL all-gather destination [devices][max rows][2n]
         // worker
         std::thread th;
         std::mutex mu;
@@ -68,6 +83,14 @@ private:
     std::vector<std::unique_ptr<Dev>> devs_;
     std::vector<std::pair<int, int>> where_;                      // id -> (slot, local position)
     std::mutex mu_;                                               // one query / placement call at a time
+    const char *last_gather_ = "";
+    // RCCL (librccl.so, loaded on first use): one communicator per device slot of this handle, null when unavailable
+    struct Rccl;
+    std::unique_ptr<Rccl> rccl_;
+    bool rccl_tried_ = false;
+    bool rccl_ready();
+    bool phase_on_ = false;
+    Engine::PhaseSummary run_query_;
 };
 
 } // namespace apsu_he

@@ -1,0 +1,331 @@
+// See seal_codec.h.  UNPINNED restatement of Microsoft SEAL's object serialisation; host code only.
+#include "seal_codec.h"
+
+#include <zlib.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "blake2x.h"
+
+namespace apsu_he {
+namespace sealio {
+
+namespace {
+
+[[noreturn]] void bad(const char *m) { throw std::runtime_error(std::string("failed to load SEAL object: ") + m); }
+
+uint64_t rd64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+void wr64(std::vector<uint8_t> &b, uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+
+constexpr size_t MAX_BODY = (size_t)1 << 30;                    // inflated size cap (zip bombs)
+
+struct Header { uint8_t vmaj = 0, vmin = 0, compr = 0; uint64_t total = 0; };
+
+Header read_header(const uint8_t *p, size_t avail)
+{
+    if (avail < 16) bad("truncated header");
+    if ((p[0] | (p[1] << 8)) != 0xA15E || p[2] != 0x10) bad("bad magic");
+    Header h;
+    h.vmaj = p[3]; h.vmin = p[4]; h.compr = p[5];
+    h.total = rd64(p + 8);
+    if (h.total < 16 || h.total > avail) bad("bad size");
+    if (!((h.vmaj == 3 && h.vmin >= 6) || h.vmaj == 4)) bad("unsupported SEAL version (need 3.6+ or 4.x)");
+    return h;
+}
+
+void write_header(std::vector<uint8_t> &b, uint8_t vmaj, uint8_t vmin, uint8_t compr, uint64_t total)
+{
+    b.push_back(0x5E); b.push_back(0xA1); b.push_back(0x10); b.push_back(vmaj); b.push_back(vmin); b.push_back(compr);
+    b.push_back(0); b.push_back(0);
+    wr64(b, total);
+}
+
+// A byte range that is either a view into the caller's buffer (compr none) or an owned inflated copy.
+struct Body {
+    Header h;
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    std::vector<uint8_t> owned;
+};
+
+Body open_object(const uint8_t *buf, size_t size)
+{
+    Body b;
+    b.h = read_header(buf, size);
+    const uint8_t *stored = buf + 16;
+    const size_t stored_n = (size_t)b.h.total - 16;
+    if (b.h.compr == COMPR_NONE) { b.p = stored; b.n = stored_n; return b; }
+    if (b.h.compr == COMPR_ZSTD) bad("zstd-compressed SEAL object: not supported in this build (no zstd); have the peer use zlib or none");
+    if (b.h.compr != COMPR_ZLIB) bad("unknown compression mode");
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) bad("zlib initialisation failed");
+    zs.next_in = const_cast<Bytef *>(stored);
+    zs.avail_in = (uInt)stored_n;
+    if ((size_t)zs.avail_in != stored_n) { inflateEnd(&zs); bad("object too large"); }
+    b.owned.resize(std::max<size_t>(4096, stored_n * 4));
+    size_t have = 0;
+    for (;;) {
+        if (have == b.owned.size()) {
+            if (b.owned.size() >= MAX_BODY) { inflateEnd(&zs); bad("inflated object too large"); }
+            b.owned.resize(std::min(MAX_BODY, b.owned.size() * 2));
+        }
+        zs.next_out = b.owned.data() + have;
+        zs.avail_out = (uInt)std::min<size_t>(b.owned.size() - have, 1u << 30);
+        const size_t before = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        have += before - zs.avail_out;
+        if (rc == Z_STREAM_END) break;
+        if (rc != Z_OK || (zs.avail_in == 0 && zs.avail_out != 0)) { inflateEnd(&zs); bad("corrupt zlib stream"); }
+    }
+    inflateEnd(&zs);
+    b.owned.resize(have);
+    b.p = b.owned.data(); b.n = have;
+    return b;
+}
+
+std::vector<uint8_t> close_object(const std::vector<uint8_t> &members, uint8_t vmaj, uint8_t vmin, uint8_t compr)
+{
+    std::vector<uint8_t> out;
+    if (compr == COMPR_NONE) {
+        write_header(out, vmaj, vmin, COMPR_NONE, 16 + members.size());
+        out.insert(out.end(), members.begin(), members.end());
+        return out;
+    }
+    if (compr != COMPR_ZLIB) throw std::invalid_argument("unsupported compression mode for saving (none or zlib)");
+    uLongf cap = compressBound((uLong)members.size());
+    std::vector<uint8_t> z(cap);
+    if (compress2(z.data(), &cap, members.data(), (uLong)members.size(), Z_DEFAULT_COMPRESSION) != Z_OK) throw std::runtime_error("zlib deflate failed");
+    write_header(out, vmaj, vmin, COMPR_ZLIB, 16 + cap);
+    out.insert(out.end(), z.begin(), z.begin() + cap);
+    return out;
+}
+
+struct Cursor {
+    const uint8_t *p; size_t n, at = 0;
+    void need(size_t k) const { if (k > n - at) bad("truncated body"); }
+    uint64_t u64() { need(8); const uint64_t v = rd64(p + at); at += 8; return v; }
+    uint8_t u8() { need(1); return p[at++]; }
+    const uint8_t *here() const { return p + at; }
+    size_t left() const { return n - at; }
+    void skip(size_t k) { need(k); at += k; }
+};
+
+const Level *find_level(const std::vector<Level> &chain, const uint64_t id[4])
+{
+    for (const Level &l : chain) if (!std::memcmp(l.parms_id, id, 32)) return &l;
+    return nullptr;
+}
+
+void blake2b_256(const uint8_t *msg, size_t len, uint64_t out[4])
+{
+    u64 h[8];
+    blake2b_init(h, (u64)32 | ((u64)1 << 16) | ((u64)1 << 24), 0, 0);      // digest 32, no key, fanout 1, depth 1
+    size_t off = 0;
+    u64 m[16];
+    while (len - off > 128) {
+        std::memcpy(m, msg + off, 128);
+        off += 128;
+        blake2b_compress(h, m, off, false);
+    }
+    std::memset(m, 0, sizeof(m));
+    std::memcpy(m, msg + off, len - off);
+    blake2b_compress(h, m, len, true);
+    for (int i = 0; i < 4; i++) out[i] = h[i];
+}
+
+void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::vector<Level> &chain, Ciphertext &ct)
+{
+    for (int i = 0; i < 4; i++) ct.parms_id[i] = c.u64();
+    ct.is_ntt_form = c.u8();
+    ct.size = c.u64(); ct.poly_modulus_degree = c.u64(); ct.coeff_modulus_size = c.u64();
+    if (vmaj >= 4) ct.correction_factor = c.u64();
+    { const uint64_t s = c.u64(); std::memcpy(&ct.scale, &s, 8); }
+    ct.version_major = vmaj; ct.version_minor = vmin;
+    if (ct.size > 64 || ct.coeff_modulus_size > 64 || ct.poly_modulus_degree > (1u << 20)) bad("implausible dimensions");
+    const uint64_t poly_words = ct.coeff_modulus_size * ct.poly_modulus_degree, total = ct.size * poly_words;
+    // the coefficient array: its own object
+    Body arr = open_object(c.here(), c.left());
+    c.skip((size_t)arr.h.total);
+    Cursor a{ arr.p, arr.n };
+    const uint64_t count = a.u64();
+    if (count > total) bad("coefficient array larger than the ciphertext");
+    a.need((size_t)count * 8);
+    ct.data.assign((size_t)total, 0);
+    for (uint64_t i = 0; i < count; i++) ct.data[(size_t)i] = rd64(a.here() + 8 * i);
+    if (count == total) { ct.seeded = false; return; }
+    if (!(ct.size == 2 && count == poly_words)) bad("inconsistent coefficient array size");
+    // seeded: the generator's description follows; c1 is what it samples
+    Body info = open_object(c.here(), c.left());
+    c.skip((size_t)info.h.total);
+    Cursor ic{ info.p, info.n };
+    const uint8_t type = ic.u8();
+    if (type == 2) bad("seeded ciphertext under the Shake256 generator: only SEAL's default (Blake2xb) is supported");
+    if (type != 1) bad("unknown generator type in a seeded ciphertext");
+    ic.need(64);
+    for (int i = 0; i < 8; i++) ct.seed[i] = rd64(ic.here() + 8 * i);
+    const Level *lv = find_level(chain, ct.parms_id);
+    if (!lv) bad("parms_id of a seeded ciphertext is not in this context's modulus chain");
+    if (lv->q.size() != ct.coeff_modulus_size) bad("coeff_modulus_size does not match the parms_id's level");
+    sample_poly_uniform(ct.seed, lv->q.data(), lv->q.size(), (size_t)ct.poly_modulus_degree, ct.data.data() + poly_words);
+    ct.seeded = true;
+}
+
+std::vector<uint8_t> ciphertext_members(const Ciphertext &ct)
+{
+    const uint64_t poly_words = ct.coeff_modulus_size * ct.poly_modulus_degree, total = ct.size * poly_words;
+    if (ct.size > 64 || ct.coeff_modulus_size > 64 || ct.poly_modulus_degree > (1u << 20)) throw std::invalid_argument("implausible ciphertext dimensions");
+    if (ct.data.size() != total) throw std::invalid_argument("ciphertext data size does not match its dimensions");
+    if (ct.seeded && ct.size != 2) throw std::invalid_argument("only size-2 ciphertexts can be saved seeded");
+    std::vector<uint8_t> m;
+    for (int i = 0; i < 4; i++) wr64(m, ct.parms_id[i]);
+    m.push_back(ct.is_ntt_form ? 1 : 0);
+    wr64(m, ct.size); wr64(m, ct.poly_modulus_degree); wr64(m, ct.coeff_modulus_size);
+    if (ct.version_major >= 4) wr64(m, ct.correction_factor);
+    { uint64_t s; std::memcpy(&s, &ct.scale, 8); wr64(m, s); }
+    const uint64_t count = ct.seeded ? poly_words : total;
+    std::vector<uint8_t> arr;
+    wr64(arr, count);
+    for (uint64_t i = 0; i < count; i++) wr64(arr, ct.data[(size_t)i]);
+    const std::vector<uint8_t> ao = close_object(arr, ct.version_major, ct.version_minor, COMPR_NONE);
+    m.insert(m.end(), ao.begin(), ao.end());
+    if (ct.seeded) {
+        std::vector<uint8_t> info;
+        info.push_back(1);                                        // prng_type::blake2xb
+        for (int i = 0; i < 8; i++) wr64(info, ct.seed[i]);
+        const std::vector<uint8_t> io = close_object(info, ct.version_major, ct.version_minor, COMPR_NONE);
+        m.insert(m.end(), io.begin(), io.end());
+    }
+    return m;
+}
+
+} // namespace
+
+void compute_parms_id(uint64_t out[4], uint64_t scheme, uint64_t n, const uint64_t *q, size_t count, uint64_t t)
+{
+    std::vector<uint8_t> msg;
+    wr64(msg, scheme); wr64(msg, n);
+    for (size_t i = 0; i < count; i++) wr64(msg, q[i]);
+    wr64(msg, t);
+    blake2b_256(msg.data(), msg.size(), out);
+}
+
+std::vector<Level> modulus_chain(uint64_t n, const std::vector<uint64_t> &key_moduli, uint64_t t)
+{
+    std::vector<Level> chain;
+    const size_t K = key_moduli.size();
+    auto add = [&](size_t cnt) {
+        Level l;
+        l.q.assign(key_moduli.begin(), key_moduli.begin() + cnt);
+        compute_parms_id(l.parms_id, 1 /* scheme_type::bfv */, n, l.q.data(), cnt, t);
+        chain.push_back(std::move(l));
+    };
+    add(K);
+    for (size_t cnt = K > 1 ? K - 1 : 0; cnt >= 1; cnt--) add(cnt);
+    return chain;
+}
+
+void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst)
+{
+    Blake2xbSeed s;
+    for (int i = 0; i < 8; i++) s.w[i] = seed[i];
+    uint64_t blk[8];
+    uint64_t cur = ~(uint64_t)0;                                  // stream block held in blk
+    auto word = [&](uint64_t w) -> uint64_t {                     // the w-th 64-bit word of the generator's output
+        if ((w >> 3) != cur) { cur = w >> 3; blake2xb_stream_block(s, cur, blk); }
+        return blk[w & 7];
+    };
+    const uint64_t bulk = (uint64_t)L * n;
+    for (uint64_t w = 0; w < bulk; w++) dst[w] = word(w);
+    uint64_t next = bulk;                                         // fresh draws continue behind the bulk fill
+    for (size_t j = 0; j < L; j++) {
+        const uint64_t max_random = ~(uint64_t)0;
+        const uint64_t max_multiple = max_random - (max_random % q[j]) - 1;
+        uint64_t *p = dst + j * n;
+        for (size_t k = 0; k < n; k++) {
+            uint64_t r = p[k];
+            while (r >= max_multiple) r = word(next++);
+            p[k] = r % q[j];
+        }
+    }
+}
+
+Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed)
+{
+    if (!buf) bad("null buffer");
+    Body b = open_object(buf, size);
+    Cursor c{ b.p, b.n };
+    Ciphertext ct;
+    parse_ciphertext_members(c, b.h.vmaj, b.h.vmin, chain, ct);
+    if (consumed) *consumed = (size_t)b.h.total;
+    return ct;
+}
+
+std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr)
+{
+    return close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, compr);
+}
+
+KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed)
+{
+    if (!buf) bad("null buffer");
+    Body b = open_object(buf, size);
+    Cursor c{ b.p, b.n };
+    KSwitchKeys k;
+    k.version_major = b.h.vmaj; k.version_minor = b.h.vmin;
+    for (int i = 0; i < 4; i++) k.parms_id[i] = c.u64();
+    const uint64_t dim1 = c.u64();
+    if (dim1 > 64) bad("implausible key count");
+    k.keys.resize((size_t)dim1);
+    for (uint64_t i = 0; i < dim1; i++) {
+        const uint64_t dim2 = c.u64();
+        if (dim2 > 64) bad("implausible decomposition count");
+        for (uint64_t j = 0; j < dim2; j++) {
+            Body pk = open_object(c.here(), c.left());             // PublicKey: an object holding one ciphertext object
+            c.skip((size_t)pk.h.total);
+            Body cb = open_object(pk.p, pk.n);
+            Cursor cc{ cb.p, cb.n };
+            Ciphertext ct;
+            parse_ciphertext_members(cc, cb.h.vmaj, cb.h.vmin, chain, ct);
+            k.keys[(size_t)i].push_back(std::move(ct));
+        }
+    }
+    if (consumed) *consumed = (size_t)b.h.total;
+    return k;
+}
+
+std::vector<uint8_t> save_kswitch_keys(const KSwitchKeys &k, uint8_t compr)
+{
+    std::vector<uint8_t> m;
+    for (int i = 0; i < 4; i++) wr64(m, k.parms_id[i]);
+    wr64(m, k.keys.size());
+    for (const auto &row : k.keys) {
+        wr64(m, row.size());
+        for (const Ciphertext &ct : row) {
+            const std::vector<uint8_t> co = close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, COMPR_NONE);
+            const std::vector<uint8_t> pk = close_object(co, ct.version_major, ct.version_minor, COMPR_NONE);
+            m.insert(m.end(), pk.begin(), pk.end());
+        }
+    }
+    return close_object(m, k.version_major, k.version_minor, compr);
+}
+
+std::vector<uint64_t> relin_keys_layout(const KSwitchKeys &k, size_t K, size_t n)
+{
+    if (k.keys.empty() || k.keys[0].empty()) throw std::invalid_argument("RelinKeys object holds no key");
+    const auto &row = k.keys[0];
+    if (K < 2 || row.size() != K - 1) throw std::invalid_argument("RelinKeys decomposition count does not match the parameters");
+    std::vector<uint64_t> out;
+    out.reserve(row.size() * 2 * K * n);
+    for (const Ciphertext &ct : row) {
+        if (ct.size != 2 || ct.coeff_modulus_size != K || ct.poly_modulus_degree != n || !ct.is_ntt_form)
+            throw std::invalid_argument("RelinKeys entry is not a size-2 NTT-form ciphertext at the key level");
+        out.insert(out.end(), ct.data.begin(), ct.data.end());
+    }
+    return out;
+}
+
+} // namespace sealio
+} // namespace apsu_he

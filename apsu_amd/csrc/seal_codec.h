@@ -1,0 +1,78 @@
+// N3: Microsoft SEAL's own object serialisation — what travels INSIDE the framed messages of wire.h
+// (Ciphertext.data, QueryRequest.relin_keys) — so that a DB-side process can take a real QueryRequest without SEAL on the host.
+//
+// **UNPINNED.**  Nothing in /root/reference pins this format (SEAL is an external dependency, no vectors, no tests), and
+// SEAL is not in this image: everything here restates upstream SEAL (>= 3.6 / 4.x; native/src/seal/{serialization,ciphertext,
+// kswitchkeys,publickey,dynarray,randomgen,encryptionparams}.{h,cpp}, util/{rlwe,hash,ztools}.cpp) from memory, and is
+// checked only against an independent Python model of the same description (tests/test_seal_codec.py; zlib and the BLAKE2b
+// core ARE pinned, by python's zlib / hashlib).  What the reference does with these objects:
+//   querier: Encryptor::encrypt_symmetric -> Serializable<Ciphertext> (c1 replaced by the seed of the PRNG that sampled it)
+//            sender/apsu/plaintext_powers.cpp:41-46 ; KeyGenerator::create_relin_keys -> Serializable<RelinKeys> sender_osn.cpp:223-227
+//            both saved with compr_mode_default (zstd if SEAL was built with it, else zlib) common/apsu/seal_object.h:183-196
+//   DB side: SEALObject::load / extract -> Ciphertext::load expands the seed  receiver/apsu/query.cpp:44-80
+//
+// Layout restated (all integers little-endian):
+//   SEALHeader (16 B): magic 0xA15E u16 | header_size 0x10 u8 | version major u8 | minor u8 | compr_mode u8 (0 none, 1 zlib,
+//                      2 zstd) | reserved u16 | size u64 (header + body as stored)
+//   body as stored   : the member bytes; with zlib ONE deflate stream (zlib format) of them
+//   Ciphertext       : parms_id 4 x u64 | is_ntt_form u8 | size u64 | poly_modulus_degree u64 | coeff_modulus_size u64 |
+//                      correction_factor u64 (version 4.x) | scale f64 | DynArray  [| UniformRandomGeneratorInfo  if seeded]
+//                      seeded: the DynArray holds c0 only (size/2 of the words); c1 = sample_poly_uniform(PRNG(seed))
+//   DynArray<u64>    : own SEALHeader (compr none) | count u64 | words
+//   UniformRandomGeneratorInfo : own SEALHeader | prng_type u8 (1 blake2xb, 2 shake256) | seed 64 B
+//   PublicKey        : own SEALHeader | Ciphertext object
+//   KSwitchKeys      : parms_id 4 x u64 | dim1 u64 | for each: dim2 u64 | dim2 x PublicKey object
+//                      RelinKeys: dim1 = 1, dim2 = decomposition count = K - 1, every key ciphertext size 2 over all K primes, NTT form
+//   parms_id         : BLAKE2b-256 of the u64 words {scheme (BFV = 1), poly_modulus_degree, coeff moduli..., plain_modulus}
+//   sample_poly_uniform (util/rlwe.cpp): fill L*n words from the generator, then per limb replace every word >= the largest
+//                      multiple of q below 2^64 - 1 by fresh 64-bit draws taken from the SAME stream, and reduce mod q
+//   generator        : Blake2xb (blake2x.h): 4096-byte buffers = blake2xb(4096, counter u64, key = seed), bytes handed out in order
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace apsu_he {
+namespace sealio {
+
+enum : uint8_t { COMPR_NONE = 0, COMPR_ZLIB = 1, COMPR_ZSTD = 2 };
+
+// encryption parameters of one level of the modulus chain: parms_id identifies it inside serialised objects
+struct Level { uint64_t parms_id[4]; std::vector<uint64_t> q; };
+void compute_parms_id(uint64_t out[4], uint64_t scheme, uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, size_t count,
+                      uint64_t plain_modulus);
+// key level first (all K primes), then every data level down to one prime (SEALContext's chain)
+std::vector<Level> modulus_chain(uint64_t poly_modulus_degree, const std::vector<uint64_t> &key_moduli, uint64_t plain_modulus);
+
+// util::sample_poly_uniform under SEAL's Blake2xb generator seeded with `seed`: dst[L][n]
+void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst);
+
+struct Ciphertext {
+    uint64_t parms_id[4] = { 0, 0, 0, 0 };
+    uint8_t is_ntt_form = 0;
+    uint64_t size = 0, poly_modulus_degree = 0, coeff_modulus_size = 0, correction_factor = 1;
+    double scale = 1.0;
+    bool seeded = false;                 // load: the object carried a seed (expanded into data); save: write the seeded form
+    uint64_t seed[8] = { 0 };
+    uint8_t version_major = 4, version_minor = 0;
+    std::vector<uint64_t> data;          // [size][coeff_modulus_size][poly_modulus_degree], expanded
+};
+
+// One serialised object of `size` bytes at buf (its header says how many are used: *consumed).  zlib bodies are inflated,
+// zstd is refused ("zstd-compressed SEAL object: not supported in this build").  Throws std::runtime_error on malformed input.
+Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr);
+// compr: COMPR_NONE or COMPR_ZLIB.  ct.seeded: c1 is NOT written, the seed is (the caller guarantees c1 = sample(seed)).
+std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr);
+
+struct KSwitchKeys {
+    uint64_t parms_id[4] = { 0, 0, 0, 0 };
+    std::vector<std::vector<Ciphertext>> keys;          // [dim1][dim2]
+    uint8_t version_major = 4, version_minor = 0;
+};
+KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr);
+std::vector<uint8_t> save_kswitch_keys(const KSwitchKeys &k, uint8_t compr);
+// RelinKeys -> the [decomp][2][K][n] array apsu_he_relin_upload takes (keys[0][*], every one size 2 at the key level, NTT form)
+std::vector<uint64_t> relin_keys_layout(const KSwitchKeys &k, size_t K, size_t n);
+
+} // namespace sealio
+} // namespace apsu_he

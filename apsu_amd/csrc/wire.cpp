@@ -357,71 +357,5 @@ ResultPackage parse_result_package(const uint8_t *buf, size_t size)
     return p;
 }
 
-// ================================================================================================ SEAL envelope (UNPINNED)
-namespace {
-void seal_header(Writer &w, uint8_t vmaj, uint8_t vmin, uint64_t total)
-{
-    w.u16(0xA15E); w.u8(0x10); w.u8(vmaj); w.u8(vmin); w.u8(0 /* compr_mode none */); w.u16(0); w.u64(total);
-}
-uint64_t rd64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
-}
-
-std::vector<uint8_t> seal_envelope_save(const SealCt &ct, uint8_t vmaj, uint8_t vmin)
-{
-    const uint64_t words = ct.size * ct.coeff_modulus_size * ct.poly_modulus_degree;
-    const bool v4 = vmaj >= 4;
-    const uint64_t arr_bytes = 16 + 8 + words * 8;
-    const uint64_t body = 32 + 1 + 8 * 3 + (v4 ? 8 : 0) + 8 + arr_bytes;
-    Writer w;
-    seal_header(w, vmaj, vmin, 16 + body);
-    for (int i = 0; i < 4; i++) w.u64(ct.parms_id[i]);
-    w.u8(ct.is_ntt_form);
-    w.u64(ct.size); w.u64(ct.poly_modulus_degree); w.u64(ct.coeff_modulus_size);
-    if (v4) w.u64(ct.correction_factor);
-    uint64_t sc; std::memcpy(&sc, &ct.scale, 8); w.u64(sc);
-    seal_header(w, vmaj, vmin, arr_bytes);
-    w.u64(words);
-    for (uint64_t i = 0; i < words; i++) w.u64(ct.data[i]);
-    return std::move(w.b);
-}
-
-SealCt seal_envelope_load(const uint8_t *buf, size_t size, uint8_t *vmaj, uint8_t *vmin)
-{
-    auto bad = [](const char *m) { throw std::runtime_error(std::string("failed to load SEAL object: ") + m); };
-    auto header = [&](const uint8_t *p, size_t avail, uint8_t *maj, uint8_t *min) -> uint64_t {
-        if (avail < 16) bad("truncated header");
-        if ((p[0] | (p[1] << 8)) != 0xA15E || p[2] != 0x10) bad("bad magic");
-        if (p[5] != 0) bad("compressed objects are not supported");
-        if (maj) *maj = p[3];
-        if (min) *min = p[4];
-        const uint64_t total = rd64(p + 8);
-        if (total < 16 || total > avail) bad("bad size");
-        return total;
-    };
-    uint8_t maj = 0, mn = 0;
-    const uint64_t total = header(buf, size, &maj, &mn);
-    if (vmaj) *vmaj = maj;
-    if (vmin) *vmin = mn;
-    const bool v4 = maj >= 4;
-    const size_t fixed = 16 + 32 + 1 + 24 + (v4 ? 8 : 0) + 8;
-    if (total < fixed + 16 + 8) bad("truncated body");
-    const uint8_t *p = buf + 16;
-    SealCt ct;
-    for (int i = 0; i < 4; i++) ct.parms_id[i] = rd64(p + 8 * i);
-    p += 32;
-    ct.is_ntt_form = *p++;
-    ct.size = rd64(p); ct.poly_modulus_degree = rd64(p + 8); ct.coeff_modulus_size = rd64(p + 16);
-    p += 24;
-    if (v4) { ct.correction_factor = rd64(p); p += 8; }
-    uint64_t sc = rd64(p); std::memcpy(&ct.scale, &sc, 8); p += 8;
-    const uint64_t arr_total = header(p, (size_t)(buf + total - p), nullptr, nullptr);
-    const uint64_t words = rd64(p + 16);
-    if (ct.size > 64 || ct.coeff_modulus_size > 64 || ct.poly_modulus_degree > (1u << 20)) bad("implausible dimensions");
-    if (words != ct.size * ct.coeff_modulus_size * ct.poly_modulus_degree) bad("seeded or inconsistent ciphertext data");
-    if (arr_total != 16 + 8 + words * 8) bad("inconsistent array size");
-    ct.data = reinterpret_cast<const uint64_t *>(p + 24);
-    return ct;
-}
-
 } // namespace wire
 } // namespace apsu_he

@@ -7,8 +7,8 @@
 //   ResultPackage                    common/apsu/network/result_package.fbs, result_package.cpp:29-150
 // (size-prefixed buffers, FinishSizePrefixed / VerifySizePrefixed...Buffer).  The byte vectors inside
 // (Ciphertext.data, QueryRequest.relin_keys) are SEAL's own serialisation (seal_object.h:161-219 -> Ciphertext::save);
-// nothing in /root/reference pins that format, so they are OPAQUE byte ranges here.  seal_envelope_* restates the
-// uncompressed (compr_mode::none) envelope from memory of upstream SEAL and is marked UNPINNED.
+// nothing in /root/reference pins that format, so they are OPAQUE byte ranges here; seal_codec.h restates SEAL's
+// object serialisation (seeded ciphertexts, zlib bodies, KSwitchKeys, parms_id) from memory of upstream SEAL and is marked UNPINNED.
 //
 // Host code only (no HIP).  Parsing verifies every offset, length and alignment before use, like flatbuffers::Verifier,
 // and fails with the reference's messages ("failed to load ...: invalid buffer").
@@ -54,23 +54,6 @@ struct ResultPackage {
 };
 std::vector<uint8_t> build_result_package(const ResultPackage &r);
 ResultPackage parse_result_package(const uint8_t *buf, size_t size);
-
-// ---- UNPINNED: SEAL's uncompressed object envelope for a Ciphertext (restated from memory) ----
-// 16-byte SEALHeader {magic 0xA15E, header_size 0x10, version major/minor, compr_mode, reserved, size u64} followed by
-// parms_id (4 x u64, opaque here: SEAL derives it by hashing the encryption parameters), is_ntt_form (1 byte),
-// size, poly_modulus_degree, coeff_modulus_size (u64 each), correction_factor (u64, SEAL 4.x), scale (double), then the
-// coefficient DynArray as its own object: header + u64 element count + raw little-endian words.
-struct SealCt {
-    uint64_t parms_id[4] = { 0, 0, 0, 0 };
-    uint8_t is_ntt_form = 0;
-    uint64_t size = 0, poly_modulus_degree = 0, coeff_modulus_size = 0, correction_factor = 1;
-    double scale = 1.0;
-    const uint64_t *data = nullptr;      // size * coeff_modulus_size * poly_modulus_degree words
-};
-std::vector<uint8_t> seal_envelope_save(const SealCt &ct, uint8_t version_major, uint8_t version_minor);
-// returns the header fields and a pointer INTO buf for the words; throws std::runtime_error on malformed input,
-// on a compressed object (compr_mode != none) and on a seeded ciphertext (not expanded here)
-SealCt seal_envelope_load(const uint8_t *buf, size_t size, uint8_t *version_major, uint8_t *version_minor);
 
 } // namespace wire
 } // namespace apsu_he

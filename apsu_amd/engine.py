@@ -209,6 +209,29 @@ class HeContext:
     PROFILE_CLASSES = ("ntt_fwd", "ntt_inv", "dyadic_mac", "behz_ext", "behz_tensor", "behz_finish", "keyswitch",
                        "modswitch", "other", "ntt_fused")
 
+    def phase_enable(self, on=True):
+        """phase timers under the reference's STOPWATCH names (apsu_he_phase_*)"""
+        _check(load_library().apsu_he_phase_enable(self.h, 1 if on else 0))
+
+    def phase_read(self, reset=True):
+        """-> {"Receiver::RunQuery": (count, avg_ms, min_ms, max_ms), "Receiver::ComputePowers": ..., "Receiver::ProcessBinBundleCache": ...}"""
+        L = load_library()
+        L.apsu_he_phase_name.restype = C.c_char_p
+        out = {}
+        for ph in range(3):
+            cnt = C.c_uint64(); avg = C.c_double(); mn = C.c_double(); mx = C.c_double()
+            _check(L.apsu_he_phase_read(self.h, ph, C.byref(cnt), C.byref(avg), C.byref(mn), C.byref(mx), 0))
+            out[L.apsu_he_phase_name(ph).decode()] = (int(cnt.value), avg.value, mn.value, mx.value)
+        if reset:
+            _check(L.apsu_he_phase_read(self.h, 0, None, None, None, None, 1))
+        return out
+
+    def compute_powers_cost(self):
+        """ComputePowers for one bundle index in the partition rule's cost unit (apsu_he_compute_powers_cost)"""
+        v = C.c_uint64()
+        _check(load_library().apsu_he_compute_powers_cost(self.h, C.byref(v)))
+        return int(v.value)
+
     COUNTERS = ("host_sync", "job_upload", "job_hit", "arena_grow", "powers_alloc", "stage_wrap", "job_realloc")
 
     def debug_counters(self):
@@ -427,16 +450,16 @@ class HeContext:
         return out
 
 
-def partition_bundles(units, bundle_idx_count, n_devices):
-    """apsu_he_partition_bundles: units [(bundle_idx, cache_idx, degree)] -> device slot per unit (no GPU needed)"""
+def partition_bundles(units, bundle_idx_count, n_devices, compute_powers_cost=0):
+    """apsu_he_partition_bundles(_ex): units [(bundle_idx, cache_idx, degree)] -> device slot per unit (no GPU needed)"""
     cnt = len(units)
-    b = np.array([u[0] for u in units], dtype=np.uint32)
-    c = np.array([u[1] for u in units], dtype=np.uint32)
-    d = np.array([u[2] for u in units], dtype=np.uint32)
+    b = np.array([u[0] for u in units] or [0], dtype=np.uint32)
+    c = np.array([u[1] for u in units] or [0], dtype=np.uint32)
+    d = np.array([u[2] for u in units] or [0], dtype=np.uint32)
     out = np.zeros(max(cnt, 1), dtype=np.int32)
-    _check(load_library().apsu_he_partition_bundles(C.c_uint32(bundle_idx_count), int(n_devices), C.c_void_p(b.ctypes.data),
-                                                    C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data), cnt,
-                                                    C.c_void_p(out.ctypes.data)))
+    _check(load_library().apsu_he_partition_bundles_ex(C.c_uint32(bundle_idx_count), int(n_devices), C.c_void_p(b.ctypes.data),
+                                                       C.c_void_p(c.ctypes.data), C.c_void_p(d.ctypes.data), cnt,
+                                                       C.c_uint64(int(compute_powers_cost)), C.c_void_p(out.ctypes.data)))
     return [int(x) for x in out[:cnt]]
 
 
@@ -490,14 +513,54 @@ class MultiContext:
         _check(load_library().apsu_he_multi_db_clear(self.h))
         self.n_bundles = 0
 
-    def eval_all(self, sources, masks, n, out_device_slot=-1, out_ptr=None):
-        """sources: flat list [bundle_idx][source] of host cts; masks: per bundle id.  -> [n_bundles][2][1][n] (host) or
-        writes to the device pointer out_ptr on devices[out_device_slot]"""
+    IO_SRC_PINNED, IO_MASKS_PINNED, IO_OUT_PINNED, IO_SRC_ON_DEVICE, IO_MASKS_ON_DEVICE, IO_GATHER_RCCL = 1, 2, 4, 8, 16, 32
+
+    def eval_all(self, sources, masks, n, out_device_slot=-1, out_ptr=None, flags=0, in_device_slot=0, out=None):
+        """sources: flat list [bundle_idx][source] of cts (numpy arrays, or device pointers as ints with IO_SRC_ON_DEVICE);
+        masks: per bundle id (likewise).  -> [n_bundles][2][1][n] (host; `out` = a caller-provided, e.g. page-locked, array)
+        or writes to the device pointer out_ptr on devices[out_device_slot]"""
         if out_device_slot < 0:
-            out = np.zeros((self.n_bundles, 2, 1, n), dtype=np.uint64)
+            if out is None:
+                out = np.zeros((self.n_bundles, 2, 1, n), dtype=np.uint64)
             outp = _p(out)
         else:
             out = None
             outp = C.c_void_p(int(out_ptr))
-        _check(load_library().apsu_he_eval_all(self.h, _ptr_array(list(sources)), _ptr_array(list(masks)), outp, int(out_device_slot)))
+        _check(load_library().apsu_he_eval_all_ex(self.h, _ptr_array(list(sources)), _ptr_array(list(masks)), outp, int(out_device_slot),
+                                                  C.c_uint(int(flags)), int(in_device_slot)))
         return out
+
+    def last_gather(self):
+        L = load_library()
+        L.apsu_he_multi_last_gather.restype = C.c_char_p
+        return L.apsu_he_multi_last_gather(self.h).decode()
+
+    def phase_enable(self, on=True):
+        _check(load_library().apsu_he_multi_phase_enable(self.h, 1 if on else 0))
+
+    def phase_read(self, reset=True):
+        L = load_library()
+        L.apsu_he_phase_name.restype = C.c_char_p
+        cnt = (C.c_uint64 * 3)(); avg = (C.c_double * 3)(); mn = (C.c_double * 3)(); mx = (C.c_double * 3)()
+        _check(L.apsu_he_multi_phase_read(self.h, cnt, avg, mn, mx, 1 if reset else 0))
+        return {L.apsu_he_phase_name(i).decode(): (int(cnt[i]), avg[i], mn[i], mx[i]) for i in range(3)}
+
+
+def host_alloc(shape, dtype=np.uint64):
+    """page-locked host array (apsu_he_host_alloc); release with host_free(array)"""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _check(load_library().apsu_he_host_alloc(C.c_size_t(max(1, nbytes)), C.byref(p)))
+    buf = (C.c_uint8 * max(1, nbytes)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED[a.ctypes.data] = p.value
+    return a
+
+
+def host_free(a):
+    p = _PINNED.pop(a.ctypes.data, None)
+    if p is not None:
+        _check(load_library().apsu_he_host_free(C.c_void_p(p)))
+
+
+_PINNED = {}

@@ -1,0 +1,93 @@
+"""ctypes binding of the SEAL object codec (include/apsu_he.h: apsu_he_seal_*; apsu_amd/csrc/seal_codec.h): seeded / zlib
+ciphertexts, RelinKeys, parms_id.  Host only.  UNPINNED restatement of upstream SEAL (see the header)."""
+import ctypes as C
+
+import numpy as np
+
+from .engine import _check, load_library
+from .wire import _buf, _take, u8p
+
+u64p = C.POINTER(C.c_uint64)
+COMPR_NONE, COMPR_ZLIB, COMPR_ZSTD = 0, 1, 2
+
+
+class SealContext:
+    """the modulus chain of one parameter set (PSUParams JSON, or n / coeff_modulus / plain_modulus)"""
+
+    def __init__(self, psu_params_json=None, n=None, coeff_modulus=None, plain_modulus=None):
+        L = load_library()
+        h = C.c_void_p()
+        if psu_params_json is not None:
+            _check(L.apsu_he_seal_ctx_create(psu_params_json.encode(), C.byref(h)))
+        else:
+            q = (C.c_uint64 * len(coeff_modulus))(*coeff_modulus)
+            _check(L.apsu_he_seal_ctx_create_raw(C.c_uint64(n), q, len(coeff_modulus), C.c_uint64(plain_modulus), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().apsu_he_seal_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parms_id(self, chain_idx=-1):
+        out = (C.c_uint64 * 4)()
+        _check(load_library().apsu_he_seal_parms_id(self.h, int(chain_idx), out))
+        return [int(v) for v in out]
+
+    def sample_poly_uniform(self, chain_idx, seed, L, n):
+        out = np.empty((L, n), dtype=np.uint64)
+        s = (C.c_uint64 * 8)(*[int(w) for w in seed])
+        _check(load_library().apsu_he_seal_sample_poly_uniform(self.h, int(chain_idx), s, out.ctypes.data_as(u64p)))
+        return out
+
+    def ct_load(self, buf):
+        """-> dict(parms_id, chain_idx, is_ntt_form, seeded, data [size][L][n], consumed)"""
+        Lb = load_library()
+        keep = _buf(buf)
+        pid = (C.c_uint64 * 4)()
+        ci, ntt, seeded = C.c_int(), C.c_int(), C.c_int()
+        sz, n, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        used = C.c_size_t()
+        _check(Lb.apsu_he_seal_ct_load(self.h, keep, C.c_size_t(len(buf)), pid, C.byref(ci), C.byref(ntt), C.byref(sz), C.byref(n),
+                                       C.byref(k), C.byref(seeded), None, C.c_size_t(0), C.byref(used)))
+        data = np.empty((sz.value, k.value, n.value), dtype=np.uint64)
+        _check(Lb.apsu_he_seal_ct_load(self.h, keep, C.c_size_t(len(buf)), pid, C.byref(ci), C.byref(ntt), C.byref(sz), C.byref(n),
+                                       C.byref(k), C.byref(seeded), data.ctypes.data_as(u64p), C.c_size_t(data.size), C.byref(used)))
+        return dict(parms_id=[int(v) for v in pid], chain_idx=ci.value, is_ntt_form=bool(ntt.value), seeded=bool(seeded.value),
+                    data=data, consumed=used.value)
+
+    def ct_save(self, chain_idx, is_ntt_form, data, seed=None, compr=COMPR_NONE, version=(4, 0)):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        s = (C.c_uint64 * 8)(*[int(w) for w in seed]) if seed is not None else None
+        out, size = u8p(), C.c_size_t()
+        _check(load_library().apsu_he_seal_ct_save(self.h, int(chain_idx), int(is_ntt_form), C.c_uint64(data.shape[0]),
+                                                   data.ctypes.data_as(u64p), s, int(compr), version[0], version[1],
+                                                   C.byref(out), C.byref(size)))
+        return _take(out, size)
+
+    def relin_keys_load(self, buf):
+        """-> (ksk [K-1][2][K][n] flat uint64 array, consumed)"""
+        Lb = load_library()
+        keep = _buf(buf)
+        words, used = C.c_size_t(), C.c_size_t()
+        _check(Lb.apsu_he_seal_relin_keys_load(self.h, keep, C.c_size_t(len(buf)), None, C.c_size_t(0), C.byref(words), C.byref(used)))
+        out = np.empty(words.value, dtype=np.uint64)
+        _check(Lb.apsu_he_seal_relin_keys_load(self.h, keep, C.c_size_t(len(buf)), out.ctypes.data_as(u64p), C.c_size_t(out.size),
+                                               C.byref(words), C.byref(used)))
+        return out, used.value
+
+    def relin_keys_save(self, ksk, seeds=None, compr=COMPR_NONE, version=(4, 0)):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        sd = None
+        if seeds is not None:
+            sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        out, size = u8p(), C.c_size_t()
+        _check(load_library().apsu_he_seal_relin_keys_save(self.h, ksk.ctypes.data_as(u64p), sd.ctypes.data_as(u64p) if sd is not None else None,
+                                                           int(compr), version[0], version[1], C.byref(out), C.byref(size)))
+        return _take(out, size)

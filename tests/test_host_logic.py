@@ -293,6 +293,41 @@ def test_partition_rule_of_the_c_abi_matches_the_bench_sharding():
         apsu_amd.partition_bundles([(5, 0, 1)], 4, 2)
 
 
+def test_partition_spill_pass_break_even():
+    """The spill pass (compute_powers_cost > 0): C++ and Python agree, every BinBundle is placed once, the slowest device never
+    gets slower, and the two reference points of DESIGN.md section 6 hold: 256M-4096 on 8 devices (3 indices x 34 BinBundles) does
+    NOT spill -- a second ComputePowers (311 products) costs more than the 17-vs-12 imbalance -- while a 3x larger DB does."""
+    import apsu_amd
+    from apsu_amd.sharding import partition, UNIT_OVERHEAD
+    def loads(units, slots, world, cp):
+        out = []
+        for r in range(world):
+            mine = [u for u, s in zip(units, slots) if s == r]
+            out.append(sum(u[2] + UNIT_OVERHEAD for u in mine) + cp * len({u[0] for u in mine}))
+        return out
+    rng = np.random.default_rng(11)
+    cases = []
+    for _ in range(30):
+        nb = int(rng.integers(1, 7))
+        units = [(int(rng.integers(0, nb)), ci, int(rng.integers(1, 4000))) for ci in range(int(rng.integers(1, 80)))]
+        cases.append((units, nb, int(rng.integers(1, 60000))))
+    for units, nb, cp in cases:
+        for world in (2, 3, 5, 8):
+            slots = apsu_amd.partition_bundles(units, nb, world, cp)
+            assign = partition(units, nb, world, cp)
+            want = {u: r for r, us in assign.items() for u in us}
+            assert len(want) == len(units) and [want[u] for u in units] == slots, (nb, world, cp)
+            base = apsu_amd.partition_bundles(units, nb, world, 0)
+            assert max(loads(units, slots, world, cp)) <= max(loads(units, base, world, cp))
+    cp = 110 * 311                                                   # 256M-4096: 311 ciphertext products per bundle index
+    units = [(b, ci, 3999) for b in range(3) for ci in range(34)]
+    assert apsu_amd.partition_bundles(units, 3, 8, cp) == apsu_amd.partition_bundles(units, 3, 8, 0)
+    big = [(b, ci, 3999) for b in range(3) for ci in range(100)]
+    spilled, plain = apsu_amd.partition_bundles(big, 3, 8, cp), apsu_amd.partition_bundles(big, 3, 8, 0)
+    assert spilled != plain and max(loads(big, spilled, 8, cp)) < max(loads(big, plain, 8, cp))
+    assert any(len({u[0] for u, s in zip(big, spilled) if s == r}) == 2 for r in range(8))      # some device now serves two indices
+
+
 def test_blake2b_model_against_hashlib_and_rfc():
     """oracle/blake2x.py: the BLAKE2b core (own compression function, explicit parameter block incl. the xof_length field
     BLAKE2X puts into the upper half of node_offset) equals hashlib over keys, salts, personalisation and tree parameters"""

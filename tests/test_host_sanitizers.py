@@ -1,5 +1,5 @@
 """CPU tier: the product's host code that parses untrusted or structured input, built with AddressSanitizer +
-UndefinedBehaviorSanitizer and driven through a fuzzing harness (tests/native/sanitize_harness.cpp): the N3 framing reader,
+UndefinedBehaviorSanitizer and driven through a fuzzing harness (tests/native/sanitize_harness.cpp): the N3 framing reader and the SEAL object codec (seeded / zlib ciphertexts, RelinKeys),
 the PSUParams JSON reader with the derived constants, the PowersDag and the partition rule.  (GPU AddressSanitizer is not
 available on this pool; the device side is covered by the bit-exact parity tests.)"""
 import os
@@ -15,7 +15,7 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "sanitize_harness")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
            os.path.join(ROOT, "tests", "native", "sanitize_harness.cpp")] + \
-          [os.path.join(SRC, f) for f in ("wire.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-o", exe]
+          [os.path.join(SRC, f) for f in ("wire.cpp", "seal_codec.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-lz", "-o", exe]
     subprocess.check_call(cmd)
     params = [os.path.join(ROOT, "tests", "params", f + ".json") for f in ("100K-1", "1M-1024-com", "1M-4096-32", "256M-4096")]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

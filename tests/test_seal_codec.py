@@ -1,0 +1,203 @@
+"""CPU tier: SEAL's object serialisation as restated in apsu_amd/csrc/seal_codec.{h,cpp} (N3) against an INDEPENDENT Python
+model of the same description, written here from the field list alone: struct.pack for the layout, python's zlib for
+compressed bodies, hashlib.blake2b for parms_id, oracle/blake2x.py (BLAKE2b core pinned by hashlib) for the seed expansion.
+**The format itself is UNPINNED** — nothing in the reference or this image holds a SEAL-produced object; these tests show that
+the C++ reader / writer and the Python model agree with each other and with the description, not with SEAL."""
+import hashlib
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import apsu_amd
+from apsu_amd import seal
+from oracle.blake2x import blake2xb
+
+N = 64
+Q = [0xffffffffc001, 0xffffee001, 0x1ffc001]     # 48, 36, 25 bits: three key-level primes (1M-1024-com's)
+T = 65537
+MAGIC = b"\x5e\xa1\x10"
+
+
+# ---------------------------------------------------------------------------------------------- the Python model
+def obj(members, compr=0, version=(4, 0)):
+    stored = zlib.compress(members) if compr == 1 else members
+    return MAGIC + bytes([version[0], version[1], compr, 0, 0]) + struct.pack("<Q", 16 + len(stored)) + stored
+
+
+def dyn_array(words, version):
+    return obj(struct.pack("<Q", len(words)) + struct.pack("<%dQ" % len(words), *[int(w) for w in words]), 0, version)
+
+
+def ct_members(parms_id, is_ntt, data, version, seed=None):
+    size, L, n = data.shape
+    m = struct.pack("<4Q", *parms_id) + bytes([1 if is_ntt else 0]) + struct.pack("<3Q", size, n, L)
+    if version[0] >= 4:
+        m += struct.pack("<Q", 1)
+    m += struct.pack("<d", 1.0)
+    if seed is None:
+        return m + dyn_array(data.reshape(-1), version)
+    return m + dyn_array(data[0].reshape(-1), version) + obj(bytes([1]) + struct.pack("<8Q", *seed), 0, version)
+
+
+def parms_id(n, q, t):
+    d = hashlib.blake2b(struct.pack("<%dQ" % (3 + len(q)), 1, n, *q, t), digest_size=32).digest()
+    return list(struct.unpack("<4Q", d))
+
+
+def prng_words(seed):
+    """SEAL's Blake2xb generator as a stream of 64-bit words"""
+    key = struct.pack("<8Q", *seed)
+    counter = 0
+    while True:
+        buf = blake2xb(4096, struct.pack("<Q", counter), key)
+        counter += 1
+        yield from struct.unpack("<512Q", buf)
+
+
+def sample_poly_uniform(seed, q, n):
+    g = prng_words(seed)
+    L = len(q)
+    out = np.array([next(g) for _ in range(L * n)], dtype=object).reshape(L, n)
+    for j, qj in enumerate(q):
+        max_multiple = (2**64 - 1) - ((2**64 - 1) % qj) - 1
+        for k in range(n):
+            r = out[j, k]
+            while r >= max_multiple:
+                r = next(g)
+            out[j, k] = r % qj
+    return out.astype(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = seal.SealContext(n=N, coeff_modulus=Q, plain_modulus=T)
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------- tests
+def test_parms_id_every_level(ctx):
+    assert ctx.parms_id(-1) == parms_id(N, Q, T) == ctx.parms_id(2)
+    assert ctx.parms_id(1) == parms_id(N, Q[:2], T)
+    assert ctx.parms_id(0) == parms_id(N, Q[:1], T)
+    with pytest.raises(ValueError):
+        ctx.parms_id(5)
+    js = open(os.path.join(os.path.dirname(__file__), "params", "16M-4096.json")).read()
+    c = seal.SealContext(js)
+    G_q = [0xfffffffff70001, 0xfffffffff78001, 0xfffffffffb4001, 0x3ffffffffc001]
+    assert c.parms_id(-1) == parms_id(8192, G_q, 4079617)
+    assert c.parms_id(2) == parms_id(8192, G_q[:3], 4079617)
+    c.close()
+
+
+def test_sample_poly_uniform_matches_model_including_rejections(ctx):
+    rng = np.random.default_rng(7)
+    # a 64-bit modulus-sized rejection zone is ~q / 2^64: force rejections with a context whose prime is just above 2^62
+    big = seal.SealContext(n=N, coeff_modulus=[(1 << 62) + 0x2c01, 0xffffee001], plain_modulus=T)   # not an NTT prime: sampling only needs the value
+    hits = 0
+    for _ in range(4):
+        seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+        assert (ctx.sample_poly_uniform(1, seed, 2, N) == sample_poly_uniform(seed, Q[:2], N)).all()
+        want = sample_poly_uniform(seed, [(1 << 62) + 0x2c01], N)
+        got = big.sample_poly_uniform(0, seed, 1, N)
+        assert (got == want).all()
+        g = prng_words(seed)
+        hits += sum(1 for _ in range(N) if next(g) >= (2**64 - 1) - ((2**64 - 1) % ((1 << 62) + 0x2c01)) - 1)
+    assert hits > 0                                                   # the rejection path really ran
+    big.close()
+
+
+@pytest.mark.parametrize("version", [(4, 0), (3, 6)])
+@pytest.mark.parametrize("compr", [0, 1])
+def test_ciphertext_plain_and_seeded_both_directions(ctx, version, compr):
+    rng = np.random.default_rng(11)
+    L = 2
+    pid = parms_id(N, Q[:L], T)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q[:L]]) for _ in range(2)])
+    # unseeded: model -> C++ ; C++ -> model bytes
+    blob = obj(ct_members(pid, False, data, version), compr, version)
+    got = ctx.ct_load(blob)
+    assert got["parms_id"] == pid and got["chain_idx"] == L - 1 and not got["seeded"] and not got["is_ntt_form"]
+    assert (got["data"] == data).all() and got["consumed"] == len(blob)
+    mine = ctx.ct_save(L - 1, False, data, compr=compr, version=version)
+    assert mine == blob                                              # byte-identical (python's zlib == the C library's default level)
+    # trailing bytes behind the object are not consumed
+    assert ctx.ct_load(blob + b"tail")["consumed"] == len(blob)
+    # seeded: c1 is the expansion of the seed
+    seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+    c1 = sample_poly_uniform(seed, Q[:L], N)
+    sdata = np.stack([data[0], c1])
+    sblob = obj(ct_members(pid, False, sdata, version, seed=seed), compr, version)
+    got = ctx.ct_load(sblob)
+    assert got["seeded"] and (got["data"] == sdata).all()
+    assert ctx.ct_save(L - 1, False, sdata, seed=seed, compr=compr, version=version) == sblob
+    assert len(sblob) < len(blob) or compr == 1
+
+
+def test_ciphertext_rejects_malformed(ctx):
+    rng = np.random.default_rng(3)
+    pid = parms_id(N, Q[:2], T)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q[:2]]) for _ in range(2)])
+    blob = obj(ct_members(pid, False, data, (4, 0)), 0)
+    for bad in (blob[:-1], blob[:40], b"\x00" + blob[1:], blob[:5] + bytes([2]) + blob[6:], blob[:5] + bytes([7]) + blob[6:],
+                blob[:3] + bytes([2, 0]) + blob[5:]):
+        with pytest.raises(apsu_amd.ApsuHeError):
+            ctx.ct_load(bad)
+    with pytest.raises(apsu_amd.ApsuHeError, match="zstd"):
+        ctx.ct_load(blob[:5] + bytes([2]) + blob[6:])
+    # a seeded ciphertext whose parms_id this context does not know
+    seed = [1, 2, 3, 4, 5, 6, 7, 8]
+    sblob = obj(ct_members([9, 9, 9, 9], False, data, (4, 0), seed=seed), 0)
+    with pytest.raises(apsu_amd.ApsuHeError, match="parms_id"):
+        ctx.ct_load(sblob)
+    # Shake256 generator
+    m = ct_members(pid, False, data, (4, 0), seed=seed)
+    shake = obj(m[:-65] + bytes([2]) + m[-64:], 0)
+    with pytest.raises(apsu_amd.ApsuHeError, match="Shake256"):
+        ctx.ct_load(shake)
+    # corrupt zlib stream, and random corruptions never crash
+    z = obj(ct_members(pid, False, data, (4, 0)), 1)
+    with pytest.raises(apsu_amd.ApsuHeError):
+        ctx.ct_load(z[:30] + bytes([z[30] ^ 0xff]) + z[31:])
+    for i in range(300):
+        b = bytearray(blob)
+        for _ in range(1 + i % 3):
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            ctx.ct_load(bytes(b))
+        except apsu_amd.ApsuHeError:
+            pass
+
+
+@pytest.mark.parametrize("compr", [0, 1])
+@pytest.mark.parametrize("seeded", [False, True])
+def test_relin_keys_both_directions(ctx, compr, seeded):
+    rng = np.random.default_rng(5)
+    K = len(Q)
+    pid = parms_id(N, Q, T)
+    keys, seeds = [], []
+    for j in range(K - 1):
+        seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+        c0 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q])
+        c1 = sample_poly_uniform(seed, Q, N) if seeded else np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q])
+        keys.append(np.stack([c0, c1]))
+        seeds.append(seed)
+    members = struct.pack("<4Q", *pid) + struct.pack("<Q", 1) + struct.pack("<Q", K - 1)
+    for j in range(K - 1):
+        members += obj(obj(ct_members(pid, True, keys[j], (4, 0), seed=seeds[j] if seeded else None), 0), 0)     # PublicKey { Ciphertext }
+    blob = obj(members, compr)
+    ksk, used = ctx.relin_keys_load(blob)
+    assert used == len(blob)
+    assert (ksk.reshape(K - 1, 2, K, N) == np.stack(keys)).all()
+    mine = ctx.relin_keys_save(np.stack(keys), seeds=np.array(seeds, dtype=np.uint64) if seeded else None, compr=compr)
+    assert mine == blob
+    # keys of another parameter set are refused
+    other = seal.SealContext(n=N, coeff_modulus=Q[:2], plain_modulus=T)
+    with pytest.raises((ValueError, apsu_amd.ApsuHeError)):          # seeded: unknown parms_id; unseeded: parameter mismatch
+        other.relin_keys_load(blob)
+    other.close()

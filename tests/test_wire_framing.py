@@ -289,3 +289,26 @@ def test_seal_envelope_round_trip_unpinned():
         bad = bytearray(buf); bad[5] = 2                                          # zstd-compressed: not supported
         with pytest.raises(RuntimeError):
             wire.seal_ct_load(bytes(bad))
+
+
+def test_shared_children_cannot_amplify_parse_work():
+    """offsets may legally point at shared children, so a small buffer can describe a quadratic number of
+    (part, ciphertext) visits — 4000 parts sharing ONE 4000-entry ciphertext vector is 80 KB and 16 M visits.  The reader
+    has a work budget linear in the buffer size (like flatbuffers::Verifier's max_tables) and refuses such a buffer quickly."""
+    import time
+    b = FbBuilder()
+    one = model_ct(b, b"x" * 8)
+    shared = b.offset_vector([one] * 4000)                            # 4000 entries -> the same ciphertext table
+    parts = [b.table([("u32", e + 1), ("off", shared)]) for e in range(4000)]
+    qv = b.offset_vector(parts)
+    qr = b.table([None, None, ("off", qv)])
+    rop = b.table([("u8", 3), ("off", qr)])
+    buf = b.finish_size_prefixed(rop)
+    assert len(buf) < 120000
+    t0 = time.perf_counter()
+    with pytest.raises(Exception, match="invalid buffer"):
+        wire.parse_query_request(buf)
+    assert time.perf_counter() - t0 < 0.2
+    # a legitimate message of the same size class still parses
+    big = model_query_request(0, None, [(e + 1, [b"c" * 16] * 4) for e in range(1000)])
+    assert len(wire.parse_query_request(big)[2]) == 1000

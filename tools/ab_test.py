@@ -29,7 +29,7 @@ def make(envs):
     n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
     Lf = first + 1; D = ctx.max_items_per_bin - 1
     units = [(b, ci, deg) for b in range(ctx.bundle_idx_count) for ci, deg in enumerate(WORKLOADS[args.config]["degrees"](D))]
-    mine = partition(units, ctx.bundle_idx_count, args.world)[0]
+    mine = partition(units, ctx.bundle_idx_count, args.world, ctx.compute_powers_cost())[0]
     bl = [ctx.random_bundle(b, ci, deg, SEED0 + 1000003 * b + 7919 * ci) for (b, ci, deg) in mine]
     rng = np.random.default_rng(SEED0); ns = ctx.source_power_count
     src = np.stack([np.stack([np.stack([np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in ctx.q[:Lf]]) for _ in range(2)]) for _ in range(ns)]) for _ in range(ctx.bundle_idx_count)])

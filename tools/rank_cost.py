@@ -19,7 +19,7 @@ masks = rng.integers(0, t, (len(units), n), dtype=np.uint64)
 sd = torch.from_numpy(src.view(np.int64)).cuda(); md = torch.from_numpy(masks.view(np.int64)).cuda()
 out = torch.zeros((len(units), 2, n), dtype=torch.int64, device="cuda")
 for world in (1, 2, 4, 8):
-    assign = partition(units, ctx.bundle_idx_count, world)
+    assign = partition(units, ctx.bundle_idx_count, world, ctx.compute_powers_cost())
     worst = 0
     seen = set()
     for r in range(world):                                  # every distinct shard shape once (the worst rank sets the step)

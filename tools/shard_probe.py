@@ -32,7 +32,7 @@ def delta(a, b):
     return {k: b[k] - a[k] for k in a if b[k] != a[k]}
 
 for world in [int(w) for w in args.worlds.split(",")]:
-    assign = partition(units, ctx.bundle_idx_count, world)
+    assign = partition(units, ctx.bundle_idx_count, world, ctx.compute_powers_cost())
     mine = assign[0]
     idx = sorted({u[0] for u in mine})
     sp = [[sd.data_ptr() + ((b * ns + s) * 2 * Lf * n) * 8 for s in range(ns)] for b in idx]
