@@ -1272,12 +1272,12 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             // Powers buffer) precedes the second stream's work; the two walks are queued level by level so that
             // both streams have work from the start
             DagRun rl, rh;
+            const int depth = (int)std::max(sched_low_.levels.size(), sched_high_.levels.size());
             HIP_CHECK(hipEventRecord(ev_main_, st_));
             run_dag(sched_low_, rl, 0, nb, src, on_device, rk, *pw, true, false);
             switch_lane(1);
             HIP_CHECK(hipStreamWaitEvent(st_, ev_main_, 0));
             run_dag(sched_high_, rh, 0, nb, src, on_device, rk, *pw, false, true);
-            const int depth = (int)std::max(sched_low_.levels.size(), sched_high_.levels.size());
             for (int d = 1; d < depth; d++) {
                 switch_lane(0);
                 run_dag(sched_low_, rl, d, nb, src, on_device, rk, *pw, true, false);
@@ -1288,6 +1288,8 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             run_dag(sched_low_, rl, -1, nb, src, on_device, rk, *pw, true, false);
             switch_lane(1);
             run_dag(sched_high_, rh, -1, nb, src, on_device, rk, *pw, false, true);
+            // (starting the high-power chain only when the low-power chain -- the evaluation's critical path -- has finished was
+            //  measured in round 3: level on the whole query, 21 % slower on the N = 8 shard; profiles/r03_ab_fusions.txt)
             HIP_CHECK(hipEventRecord(pw->high_ready, st_));
             if (phase_on_ && cp_span.a && !cp_span.b2) cp_span.b2 = phase_event(st_);
             switch_lane(0);

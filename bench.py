@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="16M-4096", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host-input / host-output measurement (apsu_he_eval_all_ex)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed steps")
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="untimed steps after the timed region whose NTT launches are bracketed by HIP events (roofline sample)")
@@ -375,6 +376,45 @@ def main():
                                                               "transforms per launch of this run; not measured in this run" % cands[-1])
         except (OSError, IndexError, KeyError, ValueError):
             pass
+
+    # ---- the same query with HOST inputs and outputs (rank 0, N=1 only; never `value`) ----------
+    # apsu_he_eval_all_ex: the in-process entry the reference's one-process caller would use (receiver_osn.cpp:290-364); the query
+    # ciphertexts, masks and results cross PCIe inside the timed call.  Own copy of the DB on the same GPU (same seeds).
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_host_io:
+        try:
+            M = apsu_amd.MultiContext(params_json, [local_rank])
+            if rk_host is not None:
+                M.upload_relin_keys(rk_host)
+            for (b, ci, deg) in mine:
+                M.random_bundle(0, b, ci, deg, SEED0 + 1000003 * b + 7919 * ci)
+            flat = [np.ascontiguousarray(src_host[b, s]) for b in range(ctx.bundle_idx_count) for s in range(ns)]
+            mlist = [np.ascontiguousarray(mask_host[unit_pos[(u[0], u[1])]]) for u in mine]
+            want = out_dev[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
+            hio = {}
+            for mode in ("pageable", "pinned"):
+                kw = {}
+                a_src, a_mask = flat, mlist
+                if mode == "pinned":
+                    a_src = [apsu_amd.host_alloc(a.shape) for a in flat]
+                    a_mask = [apsu_amd.host_alloc(a.shape) for a in mlist]
+                    for d_, s_ in zip(a_src + a_mask, flat + mlist):
+                        d_[...] = s_
+                    kw = dict(flags=M.IO_SRC_PINNED | M.IO_MASKS_PINNED | M.IO_OUT_PINNED, out=apsu_amd.host_alloc((len(mine), 2, 1, n)))
+                for _ in range(3):
+                    got = M.eval_all(a_src, a_mask, n, **kw)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    got = M.eval_all(a_src, a_mask, n, **kw)
+                hio[mode + "_ms"] = round((time.perf_counter() - t1) * 100, 4)
+                hio[mode + "_same_bits"] = bool((np.asarray(got) == want).all())
+            hio["note"] = ("apsu_he_eval_all_ex on one device, one query at a time, host wall clock: query ciphertexts (%.1f MB) and masks (%.1f MB) "
+                           "in pageable / page-locked host memory, results (%.1f MB) back to it; kernels read and write page-locked "
+                           "memory in place over PCIe, pageable buffers are staged" % (len(flat) * flat[0].nbytes / 1e6,
+                                                                                        len(mlist) * mlist[0].nbytes / 1e6, want.nbytes / 1e6))
+            result["host_io"] = hio
+            M.close()
+        except Exception as e:                                          # never lose the main line
+            result["host_io"] = {"error": str(e)}
 
     # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
