@@ -70,9 +70,11 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         throw HipError("no HIP device available: the query-evaluation engine has no CPU fallback");
     if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
     // the NTT keeps one limb in a workgroup's LDS: n = 2^logn coefficients with a compiled pass plan (ntt_core.h)
-    if (plan_passes(hp_.logn) == 0)
+    // (32768: the limb is split into two LDS-resident halves around one radix-2 stage over global memory, kernels.hip)
+    const bool split_ntt = hp_.logn == 15;
+    if (plan_passes(hp_.logn) == 0 && !split_ntt)
         throw std::invalid_argument("poly_modulus_degree " + std::to_string(hp_.n) +
-                                    " is not supported by the GPU engine (supported: 64, 256, 1024, 2048, 4096, 8192, 16384)");
+                                    " is not supported by the GPU engine (supported: 64, 256, 1024, 2048, 4096, 8192, 16384, 32768)");
     struct Restore { int prev = -1; ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore;
     { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != device) restore.prev = cur; }
     HIP_CHECK(hipSetDevice(device));
@@ -89,7 +91,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     const int nmod = (int)hp_.ntt.size();
     // twiddles: per modulus [fwd n][dit n][scale n] TwPair
     {
-        std::vector<TwPair> tw((size_t)nmod * 3 * n);
+        std::vector<TwPair> tw((size_t)nmod * 3 * n + (split_ntt ? (size_t)nmod * n : 0));
         for (int m = 0; m < nmod; m++) {
             const NttTablesHost &t = hp_.ntt[m];
             for (size_t k = 0; k < n; k++) {
@@ -97,23 +99,45 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 tw[((size_t)m * 3 + 1) * n + k] = TwPair{ t.dit[k], t.dit_q[k] };
                 tw[((size_t)m * 3 + 2) * n + k] = TwPair{ t.scale[k], t.scale_q[k] };
             }
+            if (split_ntt) {
+                // forward twiddles of the two half transforms: stage s of half h is stage s + 1 of the big transform,
+                // blocks h 2^s ..: W_h[2^s + b] = W[2^(s+1) + h 2^s + b]
+                for (size_t h = 0; h < 2; h++) {
+                    TwPair *dst = tw.data() + (size_t)nmod * 3 * n + ((size_t)m * 2 + h) * (n / 2);
+                    dst[0] = TwPair{ 0, 0 };
+                    for (size_t m2 = 1; m2 < n / 2; m2 <<= 1)
+                        for (size_t b = 0; b < m2; b++) {
+                            const size_t from = 2 * m2 + h * m2 + b;
+                            dst[m2 + b] = TwPair{ t.fwd[from], t.fwd_q[from] };
+                        }
+                }
+            }
         }
         d_tw_.alloc(tw.size() * sizeof(TwPair));
         HIP_CHECK(hipMemcpy(d_tw_.p(), tw.data(), tw.size() * sizeof(TwPair), hipMemcpyHostToDevice));
-        std::vector<NttTable> tabs(nmod);
+        std::vector<NttTable> tabs(split_ntt ? (size_t)nmod * 2 : (size_t)nmod);
         const TwPair *base = reinterpret_cast<const TwPair *>(d_tw_.p());
         for (int m = 0; m < nmod; m++) {
-            tabs[m].q = hp_.ntt[m].mod.value;
-            tabs[m].ninv = hp_.ntt[m].ninv;
-            tabs[m].ninv_q = hp_.ntt[m].ninv_q;
-            tabs[m].r1 = hp_.ntt[m].mod.ratio[1];
-            tabs[m].r0 = hp_.ntt[m].mod.ratio[0];
-            tabs[m].narrow = ntt_is_narrow(hp_.ntt[m].mod.value, hp_.logn) ? 1 : 0;
-            ntt_fold_params(tabs[m].q, tabs[m].fold_k, tabs[m].fold_c);
-            tabs[m].wide_d4 = ntt_wide_d4(tabs[m].q, tabs[m].narrow != 0);
-            tabs[m].fwd = base + ((size_t)m * 3 + 0) * n;
-            tabs[m].dit = base + ((size_t)m * 3 + 1) * n;
-            tabs[m].scale = base + ((size_t)m * 3 + 2) * n;
+            NttTable tb{};
+            tb.q = hp_.ntt[m].mod.value;
+            tb.ninv = hp_.ntt[m].ninv;
+            tb.ninv_q = hp_.ntt[m].ninv_q;
+            tb.r1 = hp_.ntt[m].mod.ratio[1];
+            tb.r0 = hp_.ntt[m].mod.ratio[0];
+            tb.narrow = ntt_is_narrow(hp_.ntt[m].mod.value, split_ntt ? hp_.logn - 1 : hp_.logn) ? 1 : 0;   // stages inside one workgroup
+            ntt_fold_params(tb.q, tb.fold_k, tb.fold_c);
+            tb.wide_d4 = ntt_wide_d4(tb.q, tb.narrow != 0);
+            tb.fwd = base + ((size_t)m * 3 + 0) * n;
+            tb.dit = base + ((size_t)m * 3 + 1) * n;
+            tb.scale = base + ((size_t)m * 3 + 2) * n;
+            if (!split_ntt) { tabs[m] = tb; continue; }
+            // split transform: table 2 m + h for half h; ninv / ninv_q carry the first stage's twiddle psi^brv(1)
+            tb.ninv = hp_.ntt[m].fwd[1];
+            tb.ninv_q = hp_.ntt[m].fwd_q[1];
+            for (size_t h = 0; h < 2; h++) {
+                tb.fwd = base + (size_t)nmod * 3 * n + ((size_t)m * 2 + h) * (n / 2);
+                tabs[(size_t)m * 2 + h] = tb;
+            }
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
@@ -126,6 +150,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_FUSE_EXT")) fuse_ext_ = std::atoi(v) != 0;       // =0: separate extension kernel per DAG level
         fuse_tensor_ = true;
         if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) fuse_tensor_ = std::atoi(v) != 0;
+        if (split_ntt) fuse_tensor_ = false;                     // the fused load belongs to a whole-limb workgroup
         // the inverse transforms in front of the drop-last-limb / mod-down kernels leave their twist to those kernels' constants
         // (the way the unrolled BEHZ finish has taken it since round 2): -0.035 +- 0.020 ms (-1.0 %) on the whole query,
         // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist

@@ -52,18 +52,22 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     }
 }
 
+// split != 0: the launch transforms the two HALVES of limbs twice this size (poly_modulus_degree 32768: one limb is 256 KiB and
+// does not fit a workgroup's LDS).  Block g is half g & 1 of limb g >> 1 and takes table 2 * modulus + half, whose forward
+// twiddles are the big transform's for that half (W_h[2^s + b] = W[2^(s+1) + h 2^s + b]); the first Cooley-Tukey stage runs in
+// front (k_ntt_first_stage), the inverse's last stage and twist behind (k_ntt_last_stage), so the inverse halves are always RAW.
 template <int LOGN, bool INV, int T>
 __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
-                                           const int *__restrict__ modmap, int period)
+                                           const int *__restrict__ modmap, int period, int split)
 {
     constexpr int N = 1 << LOGN;
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
     const int tid = threadIdx.x;
     const size_t g = blockIdx.x;
-    const int mv = modmap[g % (size_t)period];
-    const NttTable tab = tabs[mv & NTT_MAP_MASK];
+    const int mv = modmap[(split ? g >> 1 : g) % (size_t)period];
+    const NttTable tab = tabs[split ? (((mv & NTT_MAP_MASK) << 1) | (int)(g & 1)) : (mv & NTT_MAP_MASK)];
     u64 *p = data + g * N;
-    if (INV && (mv & NTT_MAP_RAW)) {                                            // wave-uniform branches
+    if (INV && ((mv & NTT_MAP_RAW) || split)) {                                 // wave-uniform branches
         if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, false, INV>(lds, p, tab, tid);
         else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, false, INV>(lds, p, tab, tid);
         else ntt_body<LOGN, INV, NTT_WIDE, T, false, INV>(lds, p, tab, tid);
@@ -72,6 +76,53 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);
     else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
     else ntt_body<LOGN, INV, NTT_WIDE, T>(lds, p, tab, tid);
+}
+
+constexpr int EW_T = 256;                                         // threads per workgroup of the coefficient-parallel kernels
+// ---- poly_modulus_degree 32768: one radix-2 stage over global memory around two half-size LDS-resident transforms.
+// Tables: entry 2 m (+ 1) of `tabs`; its ninv / ninv_q fields carry the first stage's twiddle psi^brv(1) (the twist comes
+// from the scale table), dit and scale are the full-size tables.
+constexpr int SPLIT_LOGN = 15;
+// forward, first Cooley-Tukey stage: (x_j, x_{j + n/2}) -> (x + w y, x - w y), canonical; src != nullptr: limb g is gathered from
+// src[g] (residues of another modulus, reduced on load: the key switch's decomposition)
+__global__ __launch_bounds__(EW_T) void k_ntt_first_stage(const u64 *const *__restrict__ src, u64 *__restrict__ data, size_t n,
+                                                          const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x, h = n >> 1;
+    if (k >= h) return;
+    const size_t g = blockIdx.y;
+    const NttTable tab = tabs[(modmap[g % (size_t)period] & NTT_MAP_MASK) << 1];
+    const u64 *in = src ? src[g] : data + g * n;
+    u64 x = in[k], y = in[k + h];
+    if (src) { x = ntt_reduce_any(x, tab); y = ntt_reduce_any(y, tab); }
+    const u64 v = mul_shoup(y, tab.ninv, tab.ninv_q, tab.q);
+    u64 *out = data + g * n;
+    out[k] = addmod(x, v, tab.q);
+    out[k + h] = submod(x, v, tab.q);
+}
+// inverse, last decimation-in-time stage (E_j + w_j O_j, E_j - w_j O_j with w_j = psi^-2j) on the RAW outputs of the two
+// half transforms, then the twist n^-1 psi^-j -- or, for a NTT_MAP_RAW limb, the raw sums for a consumer that applies it
+__global__ __launch_bounds__(EW_T) void k_ntt_last_stage(u64 *__restrict__ data, size_t n, const NttTable *__restrict__ tabs,
+                                                         const int *__restrict__ modmap, int period)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x, h = n >> 1;
+    if (k >= h) return;
+    const size_t g = blockIdx.y;
+    const int mv = modmap[g % (size_t)period];
+    const NttTable tab = tabs[(mv & NTT_MAP_MASK) << 1];
+    u64 *p = data + g * n;
+    const u64 q = tab.q;
+    const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(tab.dit + h + k));
+    const u64 e = ntt_reduce_any(p[k], tab);                                    // [0, q)
+    const u64 o = mul_shoup_lazy(p[k + h], tw[0], tw[1], q);                    // [0, 2q)
+    u64 x0 = e + o, x1 = e + (q << 1) - o;                                      // < 3q, any consumer of RAW values takes them
+    if (!(mv & NTT_MAP_RAW)) {
+        const u64x2 s0 = ldg16(reinterpret_cast<const u64 *>(tab.scale + k)), s1 = ldg16(reinterpret_cast<const u64 *>(tab.scale + k + h));
+        x0 = mul_shoup(x0, s0[0], s0[1], q);
+        x1 = mul_shoup(x1, s1[0], s1[1], q);
+    }
+    p[k] = x0;
+    p[k + h] = x1;
 }
 
 // Forward NTT of gathered limbs: limb g is read from src[g] (residues of another modulus, reduced on load) and written
@@ -95,6 +146,13 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
                        hipStream_t st)
 {
     if (!count) return;
+    if (logn == 15) {                                            // first stage gathers and reduces, the halves are plain transforms
+        const size_t n = (size_t)1 << 15;
+        hipLaunchKernelGGL(k_ntt_first_stage, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)count), dim3(EW_T), 0, st, src, data, n, tabs, modmap, period);
+        hipLaunchKernelGGL((k_ntt<14, false, 1024>), dim3((unsigned)(count * 2)), dim3(1024), 0, st, data, tabs, modmap, period, 1);
+        KERNEL_CHECK();
+        return;
+    }
 #define G_CASE(LN, T) case LN: hipLaunchKernelGGL((k_ntt_gather<LN, T>), dim3((unsigned)count), dim3(T), 0, st, src, data, tabs, modmap, period); break;
     switch (logn) {
     G_CASE(14, 1024) G_CASE(13, 512) G_CASE(12, 256) G_CASE(11, 128) G_CASE(10, 64) G_CASE(8, 64) G_CASE(6, 64)
@@ -169,10 +227,20 @@ void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, s
 
 template <int LOGN, int T>
 static void launch_ntt_t(bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                         hipStream_t st)
+                         hipStream_t st, int split = 0)
 {
-    if (inverse) hipLaunchKernelGGL((k_ntt<LOGN, true, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
-    else hipLaunchKernelGGL((k_ntt<LOGN, false, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period);
+    if (inverse) hipLaunchKernelGGL((k_ntt<LOGN, true, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period, split);
+    else hipLaunchKernelGGL((k_ntt<LOGN, false, T>), dim3((unsigned)count), dim3(T), 0, st, data, tabs, modmap, period, split);
+}
+
+static void launch_ntt_split(bool inverse, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
+                             hipStream_t st)
+{
+    const size_t n = (size_t)1 << SPLIT_LOGN;
+    const dim3 g((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)count);
+    if (!inverse) hipLaunchKernelGGL(k_ntt_first_stage, g, dim3(EW_T), 0, st, src, data, n, tabs, modmap, period);
+    launch_ntt_t<SPLIT_LOGN - 1, 1024>(inverse, data, count * 2, tabs, modmap, period, st, 1);
+    if (inverse) hipLaunchKernelGGL(k_ntt_last_stage, g, dim3(EW_T), 0, st, data, n, tabs, modmap, period);
 }
 
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
@@ -180,6 +248,7 @@ void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable 
 {
     if (!count) return;
     switch (logn) {
+    case SPLIT_LOGN: launch_ntt_split(inverse, nullptr, data, count, tabs, modmap, period, st); break;
     case 14: launch_ntt_t<14, 1024>(inverse, data, count, tabs, modmap, period, st); break;
     case 13: launch_ntt_t<13, 512>(inverse, data, count, tabs, modmap, period, st); break;
     case 12: launch_ntt_t<12, 256>(inverse, data, count, tabs, modmap, period, st); break;
@@ -193,7 +262,6 @@ void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable 
 }
 
 // ============================================================================ coefficient-parallel helpers
-constexpr int EW_T = 256;
 static inline dim3 ew_grid(size_t n, int batch) { return dim3((unsigned)((n + EW_T - 1) / EW_T), (unsigned)batch); }
 
 // K3 (single term): multiply_plain on NTT ct x NTT plaintext (bin_bundle.cpp:147,258,287,320)

@@ -20,6 +20,7 @@ FAMILIES = [
     (8192, [56, 56, 56, 50], 0, 22),        # 16M-4096
     (8192, [50, 50, 50, 38, 30], 0, 26),    # 256M-4096
     (16384, [58, 58, 50, 40], 0, 22),       # beyond the shipped sets: one 1024-thread workgroup per limb, 144 KiB of LDS
+    (32768, [58, 56, 50, 44], 0, 20),       # SEAL's largest ring: a limb is two LDS-resident halves around one global radix-2 stage
 ]
 
 
@@ -179,7 +180,7 @@ def test_ntt_large_batch_streams_correctly():
     G.close()
 
 
-@pytest.mark.parametrize("n", [2048, 8192, 16384])
+@pytest.mark.parametrize("n", [2048, 8192, 16384, 32768])
 def test_ntt_every_prime_width(n):
     # coefficient primes of every width the engine may meet, across the narrow / wide boundary of the lazy butterflies
     # ((4 log n + 1) q < 2^64 up to 58 bits at n = 8192): forward and inverse transforms against the oracle

@@ -66,6 +66,13 @@ def test_ring_size_16384():
                                  felts=5), {0: [9, 4], 1: [7]}, roots_frac=0.01)
 
 
+def test_ring_size_32768():
+    # n = 32768, the largest poly_modulus_degree SEAL (and psu_params.cpp:95-180) accepts: the whole path on the split transform
+    # (two 16384-point halves per limb around one radix-2 stage over global memory), incl. the key switch's gather and RAW outputs
+    run_scenario(common.toy_json(n=32768, coeff_bits=(56, 56, 56, 50), plain_bits=20, ps_low=2, max_items=8, query_powers=(1, 3),
+                                 felts=5), {0: [7, 2], 1: [5]}, roots_frac=0.01)
+
+
 def test_config_100K_1():
     run_scenario(common.param_json("100K-1"), {0: [19, 7, 1]})
 

@@ -16,7 +16,7 @@ for r in rows:
     name = r["Kernel_Name"]
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3      # us
     short = name.split("(")[0].replace("void apsu_he::", "")
-    if "k_ntt" in name:
+    if "k_ntt" in name or "k_intt" in name:
         wg = int(r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r["Workgroup_Size"])
         grid = int(r["Grid_Size_X"] if "Grid_Size_X" in r else r["Grid_Size"])
         agg[(short, grid // wg)].append(dur)

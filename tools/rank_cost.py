@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, apsu_amd
 from apsu_amd.sharding import partition
 from bench import SEED0, WORKLOADS
-cfg = sys.argv[1] if len(sys.argv) > 1 else "16M-4096"
+cfg = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "16M-4096"
+REPEAT = int(os.environ.get("RANK_COST_REPEAT", "1"))            # > 1: that many timed runs of 10 steps per shard, all printed
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", cfg + ".json")).read()
 ctx = apsu_amd.HeContext(js)
+ctx.set_async_results(True)                                     # bench.py's mode: queries queued back to back
 n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
 Lf = first + 1; D = ctx.max_items_per_bin - 1
 units = [(b, ci, deg) for b in range(ctx.bundle_idx_count) for ci, deg in enumerate(WORKLOADS[cfg]["degrees"](D))]
@@ -36,9 +38,14 @@ for world in (1, 2, 4, 8):
             pw = ctx.compute_powers(idx, sp, rk, on_device=True)
             ctx.eval_bundles(bl, pw, rk, mp, out=out.data_ptr(), masks_on_device=True, out_on_device=True)
         for _ in range(3): step()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): step()
-        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 100
+        runs = []
+        for _ in range(REPEAT):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10): step()
+            torch.cuda.synchronize(); runs.append((time.perf_counter() - t0) * 100)
+        ms = sorted(runs)[len(runs) // 2]
+        if REPEAT > 1:
+            print(f"   runs of 10 steps: {' '.join('%.3f' % v for v in runs)}  spread {100 * (max(runs) - min(runs)) / ms:.1f} % of the median", flush=True)
         t1 = time.perf_counter()
         for _ in range(10): pw = ctx.compute_powers(idx, sp, rk, on_device=True)
         ctx.eval_bundles(bl[:1], pw, rk, mp[:1], out=out.data_ptr(), masks_on_device=True, out_on_device=True)

@@ -16,7 +16,7 @@ def agg(path):
     d = collections.defaultdict(lambda: [0.0, 0, 0])
     for r in rows:
         name = r["Kernel_Name"]
-        key = "k_ntt_inv" if ("k_ntt" in name and "true" in name) else "k_ntt_fwd" if "k_ntt" in name else name.split("(")[0].split("::")[-1]
+        key = "k_ntt_inv" if ("k_ntt" in name and "true" in name) else "k_ntt_fwd" if "k_ntt" in name else name.split("(")[0].split("::")[-1]   # (k_intt_tensor stays its own row)
         d[key][0] += float(r["Counter_Value"]); d[key][1] += 1; d[key][2] += int(r["Grid_Size"]) // int(r["Workgroup_Size"])
     return d
 f = agg(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"))
