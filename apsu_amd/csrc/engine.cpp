@@ -155,6 +155,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // (the way the unrolled BEHZ finish has taken it since round 2): -0.035 +- 0.020 ms (-1.0 %) on the whole query,
         // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist
         if (const char *v = std::getenv("APSU_HE_RAW_TWIST")) raw_twist_ = std::atoi(v) != 0;
+        if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
     }
     // level constants
     {
@@ -1714,8 +1715,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
         else w += (size_t)(6 * Ll + 8) * n;
         per_bundle_words = std::max(per_bundle_words, w);
     }
-    size_t budget = (size_t)6 << 30;
-    if (const char *env = std::getenv("APSU_HE_EVAL_WS_BYTES")) budget = std::strtoull(env, nullptr, 10);
+    const size_t budget = eval_ws_budget_;
     int chunk = (int)std::max<size_t>(1, budget / (per_bundle_words * sizeof(u64)));
     chunk = std::min(chunk, count);
 
