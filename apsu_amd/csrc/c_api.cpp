@@ -580,6 +580,9 @@ int apsu_he_wire_result_labels(const uint8_t *buf, size_t size, uint32_t capacit
         for (size_t i = 0; i < p.label_result.size() && i < capacity; i++) { data[i] = p.label_result[i].p; sizes[i] = p.label_result[i].n; }
     });
 }
+int apsu_he_seed_expand(apsu_he_ctx *c, int chain_idx, int count, const uint64_t *seeds, uint64_t *const *dst_device)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->seed_expand(chain_idx, count, seeds, dst_device); }); }
+
 // ---- N3: SEAL's object serialisation (seal_codec.h; UNPINNED)
 struct apsu_he_seal_ctx { std::vector<sealio::Level> chain; size_t n = 0, K = 0; u64 t = 0; };
 static const sealio::Level &seal_level(const apsu_he_seal_ctx *c, int chain_idx)
@@ -647,6 +650,27 @@ int apsu_he_seal_ct_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t s
         if (data) {
             REQUIRE(data_capacity_words >= ct.data.size(), "output buffer too small");
             std::memcpy(data, ct.data.data(), ct.data.size() * sizeof(uint64_t));
+        }
+    });
+}
+int apsu_he_seal_ct_load_unexpanded(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, int *chain_idx, int *is_ntt_form, uint64_t *ct_size,
+                                    uint64_t *coeff_modulus_size, int *was_seeded, uint64_t seed[8], uint64_t *data, size_t data_capacity_words,
+                                    size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        static const std::vector<sealio::Level> none;
+        const sealio::Ciphertext ct = sealio::load_ciphertext(buf, size, c ? c->chain : none, consumed, false);
+        if (chain_idx) *chain_idx = c ? seal_chain_idx(c, ct.parms_id) : -1;
+        if (is_ntt_form) *is_ntt_form = ct.is_ntt_form;
+        if (ct_size) *ct_size = ct.size;
+        if (coeff_modulus_size) *coeff_modulus_size = ct.coeff_modulus_size;
+        if (was_seeded) *was_seeded = ct.seeded ? 1 : 0;
+        if (seed && ct.seeded) std::memcpy(seed, ct.seed, 64);
+        if (data) {
+            const size_t words = ct.seeded ? ct.data.size() / 2 : ct.data.size();       // seeded: c0 only
+            REQUIRE(data_capacity_words >= words, "output buffer too small");
+            std::memcpy(data, ct.data.data(), words * sizeof(uint64_t));
         }
     });
 }

@@ -134,6 +134,12 @@ void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, siz
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
 // out[i] = (the (first + i)-th 32-bit output of SEAL's Blake2xb generator under `seed`) % bound
 void launch_fill_blake2xb(u64 *out, size_t words, const Blake2xbSeed &seed, u64 first, u64 bound, hipStream_t st);
+// N3: c1 of seeded ciphertexts / keys = util::sample_poly_uniform under SEAL's Blake2xb generator (seal_codec.h), dst[L][n] at level lv.
+// rej: [njobs][1 + 8192] u32, zeroed once (the kernels leave the counters at zero); *overflow is set when a ciphertext has more
+// rejected words than the list holds (a modulus within a factor 3 of 2^64: not a SEAL modulus).
+struct SeedJob { Blake2xbSeed seed; u64 *dst; };
+void launch_seed_expand(const SeedJob *jobs, int njobs, const DevLevel *lv, int L, const u64 *max_multiple, size_t n, u32 *rej, int *overflow,
+                        hipStream_t st);
 // N1: BinBundle build (polyn_with_roots per bin, BatchEncoder scatter, monomial detection)
 void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 stride, u32 max_deg, Mod t, u64 *poly, size_t n,
                              hipStream_t st);

@@ -1567,6 +1567,59 @@ size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capa
     return words;
 }
 
+// ============================================================================ N3: seeded objects expanded on the device
+void Engine::seed_expand(int chain_idx, int count, const u64 *seeds, u64 *const *dst)
+{
+    Enter g(this);
+    if (count <= 0) return;
+    if (!seeds || !dst) throw std::invalid_argument("null argument");
+    const bool key_level = chain_idx < 0 || chain_idx == hp_.K - 1;
+    if (!key_level) check_level(chain_idx);
+    const int L = key_level ? hp_.K : chain_idx + 1;
+    if (L > DMAXL) throw std::invalid_argument("too many RNS limbs for the device-side seed expansion");
+    const DevLevel *lv = nullptr;
+    if (key_level && hp_.K - 1 > hp_.first_chain_idx) {
+        // the key level is not a data level: a DevLevel-shaped view that carries its moduli only
+        if (!d_key_level_.p()) {
+            std::vector<unsigned char> raw(sizeof(DevLevel), 0);
+            DevLevel *d = reinterpret_cast<DevLevel *>(raw.data());
+            d->L = hp_.K;
+            for (int j = 0; j < hp_.K; j++) d->q[j] = make_mod(hp_.key_q[j]);
+            d_key_level_.alloc(sizeof(DevLevel));
+            HIP_CHECK(hipMemcpy(d_key_level_.p(), raw.data(), sizeof(DevLevel), hipMemcpyHostToDevice));
+        }
+        lv = reinterpret_cast<const DevLevel *>(d_key_level_.p());
+    } else lv = dlevel(key_level ? hp_.K - 1 : chain_idx);
+    TIER1_SLOTS();
+    job_seq_ = job_seq_base_;
+    std::vector<u64> mm(L);
+    for (int j = 0; j < L; j++) mm[j] = ~(u64)0 - (~(u64)0 % hp_.key_q[j]) - 1;          // util/rlwe.cpp: max_multiple
+    std::vector<SeedJob> jobs(count);
+    for (int i = 0; i < count; i++) {
+        for (int k = 0; k < 8; k++) jobs[i].seed.w[k] = seeds[(size_t)i * 8 + k];
+        jobs[i].dst = dst[i];
+        if (!dst[i]) throw std::invalid_argument("null destination");
+    }
+    const size_t need = ((size_t)count * (1 + 8192) + 1) * sizeof(u32);
+    if (d_seed_rej_.bytes() < need) {
+        sync();
+        d_seed_rej_.alloc(need * 2);
+        HIP_CHECK(hipMemsetAsync(d_seed_rej_.p(), 0, d_seed_rej_.bytes(), st_));
+    }
+    u32 *rej = reinterpret_cast<u32 *>(d_seed_rej_.p());
+    int *overflow = reinterpret_cast<int *>(rej + (size_t)count * (1 + 8192));
+    HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int), st_));
+    { PROF(P_OTHER, 0); launch_seed_expand(upload_jobs(jobs), count, lv, L, upload_jobs(mm), hp_.n, rej, overflow, st_); }
+    int h_overflow = 0;
+    HIP_CHECK(hipMemcpyAsync(&h_overflow, overflow, sizeof(int), hipMemcpyDeviceToHost, st_));
+    sync();
+    if (h_overflow) {
+        HIP_CHECK(hipMemsetAsync(d_seed_rej_.p(), 0, d_seed_rej_.bytes(), st_));
+        sync();
+        throw std::logic_error("seed expansion: more rejected words than the device list holds (modulus too close to 2^64)");
+    }
+}
+
 // ============================================================================ N4: masks, packing, loopback decrypt
 static uint32_t plain_modulus_len(u64 t)
 {

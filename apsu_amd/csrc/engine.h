@@ -128,6 +128,9 @@ public:
     // the same with the reference's generator: SEAL's Blake2xb PRNG under `seed`, starting at its first_value-th 32-bit output
     void mask_generate_blake2xb(const u64 seed[8], u64 first_value, uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host);
     void decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_device, uint32_t count, u64 *values_host, u64 *blocks_host);
+    // N3 on the device: c1 of `count` seeded objects at chain_idx (-1 / K - 1: the key level) = util::sample_poly_uniform under
+    // SEAL's Blake2xb generator seeded with seeds[i][8], written to the DEVICE buffers dst[i] ([L][n] words each)
+    void seed_expand(int chain_idx, int count, const u64 *seeds, u64 *const *dst);
     // test hook: stored form of coefficient d.  kind: 0 = raw mod t (d = 0), 1 = NTT form at pt_level,
     // 2 = pre-lifted + NTT at the high level (coefficient-form a_{i*h}); returns words written
     size_t download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capacity, int *kind);
@@ -271,6 +274,7 @@ private:
                  bool do_low, bool do_high);
     void finish_bundle(Bundle &b, const u64 *raw);     // raw: [degree+1][n] coefficient-form plaintexts mod t (device)
     DevBuf d_slot_map_;
+    DevBuf d_seed_rej_, d_seed_mm_, d_key_level_;   // seed expansion: rejection lists, max_multiple per (level, limb), DevLevel-shaped view of the key level
 
     // profiling state
     struct ProfRec { hipEvent_t a, b; int kind; uint64_t units; };

@@ -547,6 +547,88 @@ void launch_fill_blake2xb(u64 *out, size_t words, const Blake2xbSeed &seed, u64 
     KERNEL_CHECK();
 }
 
+// N3 on the device: util::sample_poly_uniform under SEAL's Blake2xb generator (seal_codec.h) -- the c1 of a seeded ciphertext
+// (Encryptor::encrypt_symmetric -> Serializable<Ciphertext>, sender/apsu/plaintext_powers.cpp:41-46) or of a seeded key.
+// Pass 1 (k_seed_bulk): one lane per 64-byte stream block fills dst[L][n] with the generator's first L*n words reduced mod
+// q_j; a word at or above the largest multiple of q_j below 2^64 - 1 is rejected and its position appended to the job's list.
+// Pass 2 (k_seed_fix, one wave per ciphertext): the rejected positions are put in stream order (rank sort in LDS) and
+// replaced one after the other by fresh draws that continue behind the bulk fill, exactly in SEAL's order; the wave
+// generates 64 stream blocks at a time, every lane follows the same (uniform) control flow and lane 0 writes.
+constexpr u32 SEED_REJ_CAP = 8192;                                // rejected positions per ciphertext the fix-up can hold
+__global__ __launch_bounds__(EW_T) void k_seed_bulk(const SeedJob *__restrict__ jobs, const DevLevel *__restrict__ lv, const u64 *__restrict__ max_multiple,
+                                                    size_t n, u32 *__restrict__ rej)
+{
+    const u64 sb = (u64)blockIdx.x * EW_T + threadIdx.x;
+    const int L = lv->L;
+    if (sb * 8 >= (u64)L * n) return;
+    const SeedJob job = jobs[blockIdx.y];
+    u64 blk[8];
+    blake2xb_stream_block(job.seed, sb, blk);
+    u32 *list = rej + (size_t)blockIdx.y * (1 + SEED_REJ_CAP);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 w = sb * 8 + i;                                 // n is a multiple of 8: the block lies inside one limb
+        const int j = (int)(w / n);
+        if (blk[i] >= max_multiple[j]) {
+            const u32 slot = atomicAdd(list, 1u);
+            if (slot < SEED_REJ_CAP) list[1 + slot] = (u32)w;
+        } else job.dst[w] = barrett64(blk[i], lv->q[j]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_seed_fix(const SeedJob *__restrict__ jobs, const DevLevel *__restrict__ lv, const u64 *__restrict__ max_multiple,
+                                                 size_t n, u32 *__restrict__ rej, int *__restrict__ overflow)
+{
+    __shared__ u32 sorted[SEED_REJ_CAP];
+    __shared__ u64 cache[64 * 8];
+    const SeedJob job = jobs[blockIdx.x];
+    u32 *list = rej + (size_t)blockIdx.x * (1 + SEED_REJ_CAP);
+    const u32 cnt = list[0];
+    const u32 lane = threadIdx.x;
+    if (cnt > SEED_REJ_CAP) { if (lane == 0) *overflow = 1; return; }
+    for (u32 e = lane; e < cnt; e += 64) {                        // rank sort (positions are distinct)
+        const u32 v = list[1 + e];
+        u32 rank = 0;
+        for (u32 k = 0; k < cnt; k++) rank += list[1 + k] < v;
+        sorted[rank] = v;
+    }
+    __syncthreads();
+    u64 next = (u64)lv->L * n;                                    // fresh draws continue behind the bulk fill
+    u64 cache_block = ~(u64)0;                                    // first stream block held in `cache`
+    for (u32 k = 0; k < cnt; k++) {                               // uniform: every lane walks the same list
+        const u32 w = sorted[k];
+        const int j = (int)(w / n);
+        const u64 mm = max_multiple[j];
+        u64 r;
+        do {
+            const u64 b = next >> 3;
+            if (cache_block == ~(u64)0 || b < cache_block || b >= cache_block + 64) {
+                __syncthreads();
+                cache_block = b;
+                u64 blk[8];
+                blake2xb_stream_block(job.seed, b + lane, blk);
+#pragma unroll
+                for (int i = 0; i < 8; i++) cache[lane * 8 + i] = blk[i];
+                __syncthreads();
+            }
+            r = cache[(next - (cache_block << 3))];
+            next++;
+        } while (r >= mm);
+        if (lane == 0) job.dst[w] = barrett64(r, lv->q[j]);
+    }
+    if (lane == 0) list[0] = 0;                                   // ready for the next use of this list
+}
+
+void launch_seed_expand(const SeedJob *jobs, int njobs, const DevLevel *lv, int L, const u64 *max_multiple, size_t n, u32 *rej, int *overflow,
+                        hipStream_t st)
+{
+    if (!njobs) return;
+    const u64 blocks = ((u64)L * n + 7) / 8;
+    hipLaunchKernelGGL(k_seed_bulk, dim3((unsigned)((blocks + EW_T - 1) / EW_T), (unsigned)njobs), dim3(EW_T), 0, st, jobs, lv, max_multiple, n, rej);
+    hipLaunchKernelGGL(k_seed_fix, dim3((unsigned)njobs), dim3(64), 0, st, jobs, lv, max_multiple, n, rej, overflow);
+    KERNEL_CHECK();
+}
+
 // ============================================================================ N1: BinBundle build on the GPU
 // polyn_with_roots (common/apsu/util/interpolate.cpp:27-80) for every bin of a BinBundle.  One WAVE per bin: the
 // monic polynomial lives in registers, coefficient i in lane i % 64, slot i / 64, so multiplying by (x - a) is one

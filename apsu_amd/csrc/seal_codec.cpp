@@ -136,7 +136,7 @@ void blake2b_256(const uint8_t *msg, size_t len, uint64_t out[4])
     for (int i = 0; i < 4; i++) out[i] = h[i];
 }
 
-void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::vector<Level> &chain, Ciphertext &ct)
+void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::vector<Level> &chain, Ciphertext &ct, bool expand = true)
 {
     for (int i = 0; i < 4; i++) ct.parms_id[i] = c.u64();
     ct.is_ntt_form = c.u8();
@@ -166,6 +166,8 @@ void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::
     if (type != 1) bad("unknown generator type in a seeded ciphertext");
     ic.need(64);
     for (int i = 0; i < 8; i++) ct.seed[i] = rd64(ic.here() + 8 * i);
+    ct.seeded = true;
+    if (!expand) return;
     const Level *lv = find_level(chain, ct.parms_id);
     if (!lv) bad("parms_id of a seeded ciphertext is not in this context's modulus chain");
     if (lv->q.size() != ct.coeff_modulus_size) bad("coeff_modulus_size does not match the parms_id's level");
@@ -252,13 +254,13 @@ void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, si
     }
 }
 
-Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed)
+Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed, bool expand)
 {
     if (!buf) bad("null buffer");
     Body b = open_object(buf, size);
     Cursor c{ b.p, b.n };
     Ciphertext ct;
-    parse_ciphertext_members(c, b.h.vmaj, b.h.vmin, chain, ct);
+    parse_ciphertext_members(c, b.h.vmaj, b.h.vmin, chain, ct, expand);
     if (consumed) *consumed = (size_t)b.h.total;
     return ct;
 }

@@ -60,7 +60,9 @@ struct Ciphertext {
 
 // One serialised object of `size` bytes at buf (its header says how many are used: *consumed).  zlib bodies are inflated,
 // zstd is refused ("zstd-compressed SEAL object: not supported in this build").  Throws std::runtime_error on malformed input.
-Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr);
+// expand = false: a seeded object's c1 is left zero and only ct.seed is filled (the caller expands it, e.g. on the device with
+// apsu_he_seed_expand); the chain is then not consulted.
+Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr, bool expand = true);
 // compr: COMPR_NONE or COMPR_ZLIB.  ct.seeded: c1 is NOT written, the seed is (the caller guarantees c1 = sample(seed)).
 std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr);
 

@@ -226,6 +226,11 @@ class HeContext:
             _check(L.apsu_he_phase_read(self.h, 0, None, None, None, None, 1))
         return out
 
+    def seed_expand(self, chain_idx, seeds, dst_ptrs):
+        """apsu_he_seed_expand: seeds [count][8] uint64, dst_ptrs: device pointers ([L][n] words each)"""
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(-1, 8)
+        _check(load_library().apsu_he_seed_expand(self.h, int(chain_idx), len(sd), _p(sd.reshape(-1)), _ptr_array([int(p) for p in dst_ptrs])))
+
     def compute_powers_cost(self):
         """ComputePowers for one bundle index in the partition rule's cost unit (apsu_he_compute_powers_cost)"""
         v = C.c_uint64()

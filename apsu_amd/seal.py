@@ -62,6 +62,21 @@ class SealContext:
         return dict(parms_id=[int(v) for v in pid], chain_idx=ci.value, is_ntt_form=bool(ntt.value), seeded=bool(seeded.value),
                     data=data, consumed=used.value)
 
+    def ct_load_unexpanded(self, buf, L, n):
+        """-> dict(chain_idx, seeded, seed (8 words) or None, data: c0 [L][n] when seeded, else [size][L][n])"""
+        Lb = load_library()
+        keep = _buf(buf)
+        ci, ntt, seeded = C.c_int(), C.c_int(), C.c_int()
+        sz, k = C.c_uint64(), C.c_uint64()
+        seed = (C.c_uint64 * 8)()
+        data = np.zeros(2 * L * n, dtype=np.uint64)
+        used = C.c_size_t()
+        _check(Lb.apsu_he_seal_ct_load_unexpanded(self.h, keep, C.c_size_t(len(buf)), C.byref(ci), C.byref(ntt), C.byref(sz), C.byref(k),
+                                                  C.byref(seeded), seed, data.ctypes.data_as(u64p), C.c_size_t(data.size), C.byref(used)))
+        if seeded.value:
+            return dict(chain_idx=ci.value, seeded=True, seed=[int(v) for v in seed], data=data[:L * n].reshape(L, n), consumed=used.value)
+        return dict(chain_idx=ci.value, seeded=False, seed=None, data=data.reshape(int(sz.value), L, n), consumed=used.value)
+
     def ct_save(self, chain_idx, is_ntt_form, data, seed=None, compr=COMPR_NONE, version=(4, 0)):
         data = np.ascontiguousarray(data, dtype=np.uint64)
         s = (C.c_uint64 * 8)(*[int(w) for w in seed]) if seed is not None else None

@@ -342,6 +342,11 @@ int apsu_he_seal_sample_poly_uniform(const apsu_he_seal_ctx *c, int chain_idx, c
 int apsu_he_seal_ct_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t parms_id[4], int *chain_idx, int *is_ntt_form,
                          uint64_t *ct_size, uint64_t *poly_modulus_degree, uint64_t *coeff_modulus_size, int *was_seeded, uint64_t *data,
                          size_t data_capacity_words, size_t *consumed);
+/* The same WITHOUT expanding a seed: a seeded object yields c0 (L * n words), *was_seeded = 1 and seed[8] -- feed the seed to
+ * apsu_he_seed_expand, which writes c1 into device memory; an unseeded object yields all its words. */
+int apsu_he_seal_ct_load_unexpanded(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, int *chain_idx, int *is_ntt_form,
+                                    uint64_t *ct_size, uint64_t *coeff_modulus_size, int *was_seeded, uint64_t seed[8], uint64_t *data,
+                                    size_t data_capacity_words, size_t *consumed);
 /* Ciphertext::save at that level; seed != NULL writes the seeded form (c1 is NOT written: the caller guarantees it equals
  * apsu_he_seal_sample_poly_uniform(seed)) */
 int apsu_he_seal_ct_save(const apsu_he_seal_ctx *c, int chain_idx, int is_ntt_form, uint64_t ct_size, const uint64_t *data, const uint64_t *seed,
@@ -351,6 +356,11 @@ int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, 
                                  size_t *consumed);
 int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk, const uint64_t *seeds, int compr_mode, int version_major,
                                  int version_minor, uint8_t **out, size_t *out_size);
+/* The seed expansion ON THE DEVICE (needs a GPU context): c1 of `count` seeded objects at chain_idx (-1 / K - 1 = key level)
+ * = util::sample_poly_uniform under SEAL's Blake2xb generator seeded with seeds[i*8 .. i*8+7], written to the device buffers
+ * dst_device[i] ([L][n] words).  Same values as apsu_he_seal_sample_poly_uniform (the host form costs ~0.2 ms per 384 KiB
+ * ciphertext and core; 24 query ciphertexts expand in one launch pair here).  Synchronous. */
+int apsu_he_seed_expand(apsu_he_ctx *ctx, int chain_idx, int count, const uint64_t *seeds, uint64_t *const *dst_device);
 /* round-2 entry points, kept: one unseeded ciphertext without a context (zlib bodies are inflated on load) */
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,

@@ -67,7 +67,28 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
             src[(b, e)] = got["data"]
     G = apsu_amd.HeContext(js)
     rk = G.upload_relin_keys(ksk.reshape(S.rk.shape))
+    # the production wiring: c0 from the message, c1 expanded ON THE DEVICE from the stored seed (apsu_he_seed_expand), the query
+    # never exists expanded on the host; must give the same powers as the host-expanded ciphertexts
+    import torch
+    Lf = first + 1
+    order = [(b, e) for b in S.bundle_indices for e in S.sources]
+    blobs = {(b, e): cts[b] for e, cts in parts_in for b in range(len(cts))}
+    dev = torch.zeros((len(order), 2, Lf, n), dtype=torch.int64, device="cuda")
+    seeds = []
+    for i, key in enumerate(order):
+        u = sc.ct_load_unexpanded(blobs[key], Lf, n)
+        assert u["seeded"] and u["chain_idx"] == first
+        dev[i, 0] = torch.from_numpy(u["data"].view(np.int64)).cuda()
+        seeds.append(u["seed"])
+    G.seed_expand(first, np.array(seeds, dtype=np.uint64), [dev.data_ptr() + (i * 2 + 1) * Lf * n * 8 for i in range(len(order))])
+    assert (dev.cpu().numpy().view(np.uint64) == np.stack([src[k] for k in order])).all()
+    ns = len(S.sources)
+    pw_dev = G.compute_powers(S.bundle_indices, [[dev.data_ptr() + ((bi * ns + si) * 2 * Lf * n) * 8 for si in range(ns)]
+                                                 for bi in range(len(S.bundle_indices))], rk, on_device=True)
     pw = G.compute_powers(S.bundle_indices, [[src[(b, e)] for e in S.sources] for b in S.bundle_indices], rk)
+    for b in S.bundle_indices:
+        for power in S.targets:
+            assert (pw_dev.download(b, power)[0] == pw.download(b, power)[0]).all()
     gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
     out = G.eval_bundles(gb, pw, rk, [b["mask"] for b in S.bundles])
     # ---- the oracle on the same expanded inputs, and the plaintext meaning of every result
@@ -83,5 +104,34 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
         back = wire.parse_result_package(pkg)
         assert back["bundle_idx"] == b["bundle_idx"] and back["cache_idx"] == b["cache_idx"]
         assert (sc.ct_load(back["psu_result"])["data"] == out[i]).all()
+    G.close()
+    sc.close()
+
+
+@pytest.mark.parametrize("bits", [(40, 40, 40, 36), (60, 60, 60, 50), (56, 56, 56, 50)])
+def test_seed_expansion_on_the_device_equals_the_host_codec(bits):
+    """apsu_he_seed_expand (k_seed_bulk + k_seed_fix: SEAL's sample_poly_uniform with its in-stream rejection sampling) against
+    the host codec's expansion (itself held against the Python model in tests/test_seal_codec.py): data levels and the key
+    level, several ciphertexts per call, 60-bit primes for hundreds of rejections per limb"""
+    import torch
+    n = 1024 if bits[0] == 60 else (8192 if bits[0] == 56 else 64)
+    js = common.toy_json(n=n, coeff_bits=bits, plain_bits=17 if n < 8192 else 22)
+    G = apsu_amd.HeContext(js)
+    sc = seal.SealContext(js)
+    rng = np.random.default_rng(bits[0])
+    K = G.K
+    for chain_idx in (G.first_chain_idx, 0, -1):
+        L = K if chain_idx < 0 else chain_idx + 1
+        count = 5
+        seeds = rng.integers(0, 2**63, (count, 8), dtype=np.uint64)
+        out = torch.zeros((count, L, n), dtype=torch.int64, device="cuda")
+        G.seed_expand(chain_idx, seeds, [out.data_ptr() + i * L * n * 8 for i in range(count)])
+        got = out.cpu().numpy().view(np.uint64)
+        for i in range(count):
+            want = sc.sample_poly_uniform(chain_idx, [int(v) for v in seeds[i]], L, n)
+            assert (got[i] == want).all(), (bits, chain_idx, i)
+        for _ in range(2):                                      # the rejection lists are left clean for the next call
+            G.seed_expand(chain_idx, seeds[:2], [out.data_ptr() + i * L * n * 8 for i in range(2)])
+        assert (out.cpu().numpy().view(np.uint64)[:2] == got[:2]).all()
     G.close()
     sc.close()
