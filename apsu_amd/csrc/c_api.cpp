@@ -2,6 +2,7 @@
 // codes the way the reference's callers expect to see SEAL's exceptions.
 #include "../../include/apsu_he.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -726,6 +727,94 @@ int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk,
         wire_out(sealio::save_kswitch_keys(k, (uint8_t)compr_mode), out, out_size);
     });
 }
+// ---- Receiver::RunQuery from the wire (receiver_osn.cpp:160-364 + query.cpp:44-80 + result_package.cpp:29-76), without SEAL
+int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size,
+                              const apsu_he_bundle *const *bundles, int count, const uint64_t *const *masks, int masks_on_device,
+                              int result_compr_mode, uint8_t **packages, size_t *package_sizes)
+{
+    return guarded([&] {
+        REQUIRE(c && sc && request && count >= 0 && (count == 0 || (bundles && masks && packages && package_sizes)), "null argument");
+        Engine &E = *c->eng;
+        const PSUParams *psu = E.psu();
+        REQUIRE(psu, "context was created without PSUParams");
+        const HeParams &hp = E.he();
+        REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
+        const size_t n = hp.n;
+        const int first = hp.first_chain_idx;
+        const size_t Lf = (size_t)first + 1, ct_words = 2 * Lf * n;
+        // Query::Query (receiver/apsu/query.cpp:44-80): relin keys, then one ciphertext per (exponent, bundle index)
+        const wire::QueryRequest q = wire::parse_query_request(request, request_size);
+        const auto &want = psu->query_params.query_powers;
+        if (q.parts.size() != want.size()) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
+        std::vector<const wire::QueryPart *> parts;                    // ascending exponent = the PowersDag's source order
+        for (uint32_t e : want) {
+            const wire::QueryPart *hit = nullptr;
+            for (const auto &p : q.parts) if (p.exponent == e) hit = &p;
+            if (!hit) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
+            if (hit->cts.size() != psu->bundle_idx_count) throw std::invalid_argument("one ciphertext per bundle index expected (query.cpp:69-74)");
+            parts.push_back(hit);
+        }
+        std::unique_ptr<RelinKeys> rk;
+        if (hp.using_keyswitching) {
+            if (!q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
+            const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
+            if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
+            const std::vector<uint64_t> flat = sealio::relin_keys_layout(kk, sc->K, n);
+            rk = E.upload_relin_keys(flat.data());
+        }
+        // the bundle indices the given BinBundles need, ascending
+        std::vector<uint32_t> idx;
+        for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); idx.push_back(bundles[i]->b->bundle_idx); }
+        std::sort(idx.begin(), idx.end());
+        idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+        if (idx.empty()) return;
+        // ciphertexts: c0 (and c1 when the object is not seeded) through page-locked memory, seeded c1 expanded on the device
+        const size_t n_cts = idx.size() * parts.size();
+        DevBuf dev(n_cts * ct_words * sizeof(u64));
+        void *pinned = nullptr;
+        if (hipHostMalloc(&pinned, n_cts * ct_words * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+        struct Unpin { void *p; ~Unpin() { (void)hipHostFree(p); } } unpin{ pinned };
+        u64 *host = static_cast<u64 *>(pinned);
+        std::vector<uint64_t> seeds;
+        std::vector<u64 *> c1;
+        std::vector<const u64 *> src(n_cts);
+        hipStream_t st = E.stream();
+        for (size_t b = 0; b < idx.size(); b++)
+            for (size_t s2 = 0; s2 < parts.size(); s2++) {
+                const size_t k = b * parts.size() + s2;
+                const wire::Span blob = parts[s2]->cts[idx[b]];
+                const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
+                if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
+                    throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
+                u64 *d = dev.u() + k * ct_words;
+                const size_t words = ct.seeded ? ct_words / 2 : ct_words;
+                std::memcpy(host + k * ct_words, ct.data.data(), words * sizeof(u64));
+                if (hipMemcpyAsync(d, host + k * ct_words, words * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) throw HipError("upload of a query ciphertext failed");
+                if (ct.seeded) { seeds.insert(seeds.end(), ct.seed, ct.seed + 8); c1.push_back(d + ct_words / 2); }
+                src[k] = d;
+            }
+        if (!c1.empty()) E.seed_expand(first, (int)c1.size(), seeds.data(), c1.data());
+        std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), src.data(), true, rk.get());
+        std::vector<const Bundle *> bs(count);
+        for (int i = 0; i < count; i++) bs[i] = bundles[i]->b.get();
+        std::vector<u64> out((size_t)count * 2 * n);
+        E.eval_bundles(bs.data(), count, *pw, rk.get(), masks, masks_on_device != 0, out.data(), false);
+        E.wait();                                                       // the device buffers of this call die with it
+        // ResultPackage per BinBundle (receiver_osn.cpp:507-539): the result ciphertext saved at the last level
+        for (int i = 0; i < count; i++) {
+            sealio::Ciphertext rc;
+            std::memcpy(rc.parms_id, seal_level(sc, 0).parms_id, 32);
+            rc.size = 2; rc.poly_modulus_degree = n; rc.coeff_modulus_size = 1;
+            rc.data.assign(out.begin() + (size_t)i * 2 * n, out.begin() + (size_t)(i + 1) * 2 * n);
+            const std::vector<uint8_t> body = sealio::save_ciphertext(rc, (uint8_t)result_compr_mode);
+            wire::ResultPackage rp;
+            rp.bundle_idx = bs[i]->bundle_idx; rp.cache_idx = bs[i]->cache_idx;
+            rp.psu_result = wire::Span{ body.data(), body.size() };
+            wire_out(wire::build_result_package(rp), &packages[i], &package_sizes[i]);
+        }
+    });
+}
+
 // the round-2 entry points (no context: unseeded objects only; zlib bodies are inflated)
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,

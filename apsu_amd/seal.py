@@ -106,3 +106,23 @@ class SealContext:
         _check(load_library().apsu_he_seal_relin_keys_save(self.h, ksk.ctypes.data_as(u64p), sd.ctypes.data_as(u64p) if sd is not None else None,
                                                            int(compr), version[0], version[1], C.byref(out), C.byref(size)))
         return _take(out, size)
+
+
+def run_query_request(ctx, seal_ctx, request, bundles, masks, compr=COMPR_NONE):
+    """apsu_he_run_query_request: framed QueryRequest bytes -> list of framed ResultPackage bytes (one per BinBundle).
+    ctx: HeContext, bundles: its Bundle handles, masks: numpy arrays (host)"""
+    from .engine import _ptr_array
+    L = load_library()
+    keep = _buf(request)
+    cnt = len(bundles)
+    bh = (C.c_void_p * max(1, cnt))(*[b.h for b in bundles])
+    pk = (u8p * max(1, cnt))()
+    sz = (C.c_size_t * max(1, cnt))()
+    mk = [np.ascontiguousarray(m, dtype=np.uint64) for m in masks]
+    _check(L.apsu_he_run_query_request(ctx.h, seal_ctx.h, keep, C.c_size_t(len(request)), bh, cnt, _ptr_array(mk), 0, int(compr), pk, sz))
+    out = []
+    for i in range(cnt):
+        out.append(C.string_at(pk[i], sz[i]))
+        L.apsu_he_wire_buffer_free(pk[i])
+    return out
+

@@ -361,6 +361,17 @@ int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk,
  * dst_device[i] ([L][n] words).  Same values as apsu_he_seal_sample_poly_uniform (the host form costs ~0.2 ms per 384 KiB
  * ciphertext and core; 24 query ciphertexts expand in one launch pair here).  Synchronous. */
 int apsu_he_seed_expand(apsu_he_ctx *ctx, int chain_idx, int count, const uint64_t *seeds, uint64_t *const *dst_device);
+/* Receiver::RunQuery from the wire, without SEAL on the host (receiver_osn.cpp:160-364, query.cpp:44-80, result_package.cpp:29-76):
+ * `request` = the size-prefixed ReceiverOperation{QueryRequest} buffer as ZMQChannel::receive_operation hands it over.  Its
+ * RelinKeys are decoded and uploaded, every query ciphertext is decoded (c0 through page-locked memory, a seeded c1 expanded on
+ * the device), ComputePowers runs for the bundle indices of the given BinBundles, every BinBundle is evaluated with its mask,
+ * and packages[i] / package_sizes[i] receive one size-prefixed ResultPackage per BinBundle (result ciphertext as a SEAL object at
+ * the last level under result_compr_mode; release each with apsu_he_wire_buffer_free).  Errors as the reference raises them:
+ * exponents that do not match the parameters' query_powers, a wrong ciphertext count per exponent, missing RelinKeys -> 
+ * APSU_HE_INVALID_ARGUMENT.  UNPINNED as far as SEAL's object format goes (apsu_he_seal_*). */
+int apsu_he_run_query_request(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, const uint8_t *request, size_t request_size,
+                              const apsu_he_bundle *const *bundles, int count, const uint64_t *const *masks, int masks_on_device,
+                              int result_compr_mode, uint8_t **packages, size_t *package_sizes);
 /* round-2 entry points, kept: one unseeded ciphertext without a context (zlib bodies are inflated on load) */
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,

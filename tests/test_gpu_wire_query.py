@@ -97,6 +97,18 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
     for i, b in enumerate(S.bundles):
         assert (out[i] == common.oracle_eval(S, opw, b)).all()
         assert common.check_semantics(S, b, out[i])[0]
+    # ---- the same in ONE call below the C ABI: request bytes in, ResultPackage bytes out (apsu_he_run_query_request)
+    pkgs = seal.run_query_request(G, sc, msg, gb, [b["mask"] for b in S.bundles], compr=compr)
+    assert len(pkgs) == len(S.bundles)
+    for i, b in enumerate(S.bundles):
+        back = wire.parse_result_package(pkgs[i])
+        assert back["bundle_idx"] == b["bundle_idx"] and back["cache_idx"] == b["cache_idx"] and back["labels"] == []
+        got = sc.ct_load(back["psu_result"])
+        assert got["chain_idx"] == 0 and not got["seeded"] and (got["data"] == out[i]).all()
+    with pytest.raises(ValueError, match="query powers"):            # a part with a foreign exponent (query.cpp:63-68)
+        seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, [(e + 1, c) for e, c in parts]), gb, [b["mask"] for b in S.bundles])
+    with pytest.raises(ValueError, match="relinearization"):
+        seal.run_query_request(G, sc, wire.build_query_request(compr, None, parts), gb, [b["mask"] for b in S.bundles])
     # the response: one ResultPackage per BinBundle, the result ciphertext as a SEAL object at the last level
     for i, b in enumerate(S.bundles):
         body = sc.ct_save(0, False, out[i], compr=compr)
