@@ -123,6 +123,26 @@ int main(int argc, char **argv)
         const uint64_t *mh[1] = { mask_host };
         CHECK(apsu_he_eval_all(m, all_src, mh, out2, -1));
         printf("multi %s (bundle id %d)\n", memcmp(out, out2, 2 * n * 8) == 0 ? "ok" : "MISMATCH", id);
+        /* the same with page-locked query buffers (read and written in place by the kernels) and the reference's phase timers */
+        {
+            const size_t ctw = (size_t)2 * (first + 1) * n;
+            uint64_t *pin_src = NULL, *pin_mask = NULL, *pin_out = NULL;
+            CHECK(apsu_he_host_alloc((size_t)ns * ctw * 8, (void **)&pin_src));
+            CHECK(apsu_he_host_alloc(n * 8, (void **)&pin_mask));
+            CHECK(apsu_he_host_alloc(2 * n * 8, (void **)&pin_out));
+            for (uint32_t s2 = 0; s2 < ns; s2++) memcpy(pin_src + (size_t)s2 * ctw, srcp[s2], ctw * 8);
+            memcpy(pin_mask, mask_host, n * 8);
+            for (uint32_t b = 0; b < info.bundle_idx_count; b++)
+                for (uint32_t s2 = 0; s2 < ns; s2++) all_src[(size_t)b * ns + s2] = pin_src + (size_t)s2 * ctw;
+            const uint64_t *pm[1] = { pin_mask };
+            CHECK(apsu_he_multi_phase_enable(m, 1));
+            CHECK(apsu_he_eval_all_ex(m, all_src, pm, pin_out, -1, APSU_HE_IO_SRC_PINNED | APSU_HE_IO_MASKS_PINNED | APSU_HE_IO_OUT_PINNED, 0));
+            uint64_t cnt[APSU_HE_PHASES]; double avg[APSU_HE_PHASES];
+            CHECK(apsu_he_multi_phase_read(m, cnt, avg, NULL, NULL, 1));
+            printf("pinned %s (%s %.3f ms, %s %.3f ms, %s %.3f ms)\n", memcmp(out, pin_out, 2 * n * 8) == 0 && cnt[0] == 1 ? "ok" : "MISMATCH",
+                   apsu_he_phase_name(0), avg[0], apsu_he_phase_name(1), avg[1], apsu_he_phase_name(2), avg[2]);
+            CHECK(apsu_he_host_free(pin_src)); CHECK(apsu_he_host_free(pin_mask)); CHECK(apsu_he_host_free(pin_out));
+        }
         CHECK(apsu_he_multi_destroy(m));
         free(all_src); free(mask_host); free(out2);
     }
@@ -135,6 +155,23 @@ int main(int argc, char **argv)
         CHECK(apsu_he_wire_parse_result_package(msg, msg_n, &b2, &c2, &blob, &blob_n, NULL, NULL, &nl));
         printf("wire %s (%zu bytes)\n", (b2 == 0 && c2 == 3 && nl == 0 && blob_n == 2 * n * 8 && memcmp(blob, out, blob_n) == 0) ? "ok" : "MISMATCH", msg_n);
         CHECK(apsu_he_wire_buffer_free(msg));
+    }
+
+    /* N3: the result as SEAL would serialise it at the last level (zlib body), loaded back; parms_id of that level */
+    {
+        apsu_he_seal_ctx *sc = NULL;
+        CHECK(apsu_he_seal_ctx_create(json, &sc));
+        uint8_t *blob = NULL; size_t blob_n = 0, used = 0;
+        CHECK(apsu_he_seal_ct_save(sc, 0, 0, 2, out, NULL, APSU_HE_SEAL_COMPR_ZLIB, 4, 0, &blob, &blob_n));
+        uint64_t pid[4], want[4], *back = (uint64_t *)malloc(2 * n * 8);
+        int ci = -9, seeded = -9;
+        CHECK(apsu_he_seal_ct_load(sc, blob, blob_n, pid, &ci, NULL, NULL, NULL, NULL, &seeded, back, 2 * n, &used));
+        CHECK(apsu_he_seal_parms_id(sc, 0, want));
+        printf("seal %s (%zu -> %zu bytes)\n", (ci == 0 && !seeded && used == blob_n && !memcmp(pid, want, 32) && !memcmp(back, out, 2 * n * 8)) ? "ok" : "MISMATCH",
+               2 * n * 8, blob_n);
+        free(back);
+        CHECK(apsu_he_wire_buffer_free(blob));
+        CHECK(apsu_he_seal_ctx_free(sc));
     }
 
     /* error behaviour: too few powers for a bundle index that was not computed */

@@ -44,6 +44,7 @@ def test_c_program_matches_python_binding(tmp_path):
     lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines() if " " in l)
     assert lines["roundtrip"] == "ok" and lines["missing-powers"].startswith("status -1") and "done" in r.stdout
     assert lines["multi"].startswith("ok") and lines["wire"].startswith("ok"), r.stdout
+    assert lines["pinned"].startswith("ok") and "Receiver::RunQuery" in lines["pinned"] and lines["seal"].startswith("ok"), r.stdout
 
     # the same inputs through the Python binding
     G = apsu_amd.HeContext(open(params).read())
