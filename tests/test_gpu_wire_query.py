@@ -105,6 +105,11 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
         assert back["bundle_idx"] == b["bundle_idx"] and back["cache_idx"] == b["cache_idx"] and back["labels"] == []
         got = sc.ct_load(back["psu_result"])
         assert got["chain_idx"] == 0 and not got["seeded"] and (got["data"] == out[i]).all()
+    # unseeded ciphertexts (a querier that saved plain Ciphertext objects) and SEAL 3.6 objects take the same call
+    plain_parts = [(e, [sc.ct_save(first, False, expanded[(b, e)], compr=compr, version=(3, 6)) for b in range(S.p["bundle_idx_count"])])
+                   for e in S.sources]
+    pk2 = seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, plain_parts), gb, [b["mask"] for b in S.bundles], compr=compr)
+    assert pk2 == pkgs
     with pytest.raises(ValueError, match="query powers"):            # a part with a foreign exponent (query.cpp:63-68)
         seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, [(e + 1, c) for e, c in parts]), gb, [b["mask"] for b in S.bundles])
     with pytest.raises(ValueError, match="relinearization"):
