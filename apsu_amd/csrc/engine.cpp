@@ -1829,7 +1829,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 // one index then stay in the same L2).  (Cutting the batch into groups whose database scans overlap the previous
                 // group's VALU-bound tail on a second stream was built and measured in rounds 2 and 3, also with an LDS-DMA
                 // multiply-accumulate that leaves room for an NTT workgroup per CU: slower to level, the chip is power-bound.
-                // tools/microbench/eval_pipeline_experiment.patch, profiles/r03_eval_pipeline.txt.)
+                // profiles/r03_eval_pipeline.txt; the code is in git history at 22dbbd1, engine.cpp:1600-1745.)
                 struct PsBatch {
                     std::vector<int> ids;                               // positions in this chunk
                     std::vector<int> nin, in_off;                       // inner polynomials per BinBundle, prefix offsets

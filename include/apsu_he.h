@@ -64,8 +64,9 @@ typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   
 const char *apsu_he_last_error(void);
 /* 1: tiers 1 and 2, N1, N2, N4.  2 (additive): apsu_he_multi_*, apsu_he_eval_all, apsu_he_partition_bundles, apsu_he_wire_*,
  * apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb.
- * 3: apsu_he_set_eval_pipeline removed (measured-negative scheduling experiment, tools/microbench/); added
- * apsu_he_debug_counters, apsu_he_phase_*, the SEAL object codec apsu_he_wire_seal_*. */
+ * 3: apsu_he_set_eval_pipeline removed (measured-negative scheduling experiment, profiles/r03_eval_pipeline.txt); added
+ * apsu_he_debug_counters, apsu_he_phase_* / apsu_he_multi_phase_*, apsu_he_eval_all_ex + apsu_he_host_alloc, apsu_he_partition_bundles_ex,
+ * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
