@@ -189,8 +189,12 @@ class Model:
         return [[self.negacyclic_mul(l, pl, q) for l, pl, q in zip(p, lifted, self.base(chain_idx))] for p in ct]
 
     def add(self, a, b, chain_idx):
-        return [[[(x + y) % q for x, y in zip(la, lb)] for la, lb, q in zip(pa, pb, self.base(chain_idx))]
+        """Evaluator::add_inplace: operands may differ in size, the longer one's extra polynomials are copied"""
+        if len(a) < len(b):
+            a, b = b, a
+        head = [[[(x + y) % q for x, y in zip(la, lb)] for la, lb, q in zip(pa, pb, self.base(chain_idx))]
                 for pa, pb in zip(a, b)]
+        return head + [[list(l) for l in p] for p in a[len(b):]]
 
     def add_plain(self, ct, pt, chain_idx):          # B7, big-int statement
         q = self.base(chain_idx)
@@ -249,24 +253,27 @@ class Model:
         ea = [self._extend(p, chain_idx) for p in a]
         eb = [self._extend(p, chain_idx) for p in b]
 
+        size = len(a) + len(b) - 1                   # no relinearisation between products: sizes add up (16 at most in SEAL)
+        if size > 16:
+            raise ValueError("invalid size")
+
         def tensor(which, base):
             A = [e[which] for e in ea]
             Bb = [e[which] for e in eb]
-            d = [[], [], []]
+            d = [[] for _ in range(size)]
             for j, m in enumerate(base):
-                d0 = self.negacyclic_mul(A[0][j], Bb[0][j], m)
-                x = self.negacyclic_mul(A[0][j], Bb[1][j], m)
-                y = self.negacyclic_mul(A[1][j], Bb[0][j], m)
-                d2 = self.negacyclic_mul(A[1][j], Bb[1][j], m)
-                d[0].append(d0)
-                d[1].append([(u + v) % m for u, v in zip(x, y)])
-                d[2].append(d2)
+                for I in range(size):
+                    acc = [0] * self.n
+                    for i in range(max(0, I - (len(b) - 1)), min(I, len(a) - 1) + 1):
+                        term = self.negacyclic_mul(A[i][j], Bb[I - i][j], m)
+                        acc = [(u + v) % m for u, v in zip(acc, term)]
+                    d[I].append(acc)
             return d
 
         dq, db = tensor(0, q), tensor(1, Bsk)
         Bprod = prod(B)
         out = []
-        for p in range(3):
+        for p in range(size):
             res = [[0] * self.n for _ in q]
             for k in range(self.n):
                 xq = [dq[p][j][k] * t % q[j] for j in range(len(q))]
@@ -424,12 +431,9 @@ def compute_powers(M, sources, nodes, rk, ps_low_degree):
 
 def eval_plain(M, powers, coeffs, lvl, mask):
     """bin_bundle.cpp:106-174."""
-    result = None
+    result = [[[0] * M.n for _ in M.base(lvl)] for _ in range(2)]      # :132-134: size 2, zero
     for deg in range(1, len(coeffs)):
-        term = M.multiply_plain_ntt(powers[deg], coeffs[deg], lvl)
-        result = term if result is None else M.add(result, term, lvl)
-    if result is None:
-        result = [[[0] * M.n for _ in M.base(lvl)] for _ in range(2)]
+        result = M.add(result, M.multiply_plain_ntt(powers[deg], coeffs[deg], lvl), lvl)
     result = M.transform_from_ntt(result, lvl)
     result = M.add_plain(result, coeffs[0], lvl)
     result = M.add_plain(result, mask, lvl)

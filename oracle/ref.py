@@ -158,6 +158,13 @@ class RefContext:
         lib().ref_square(self.h, _p(a), _p(out), chain_idx)
         return out
 
+    def multiply_sized(self, a, b, chain_idx):
+        """Evaluator::multiply of ciphertexts of any size (no relinearisation in between): size_a + size_b - 1 polynomials"""
+        out = np.empty(self.ct_shape(a.shape[0] + b.shape[0] - 1, chain_idx), dtype=np.uint64)
+        if lib().ref_multiply_sized(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(out), chain_idx):
+            raise ValueError("invalid size")              # Ciphertext::resize beyond SEAL_CIPHERTEXT_SIZE_MAX
+        return out
+
     def relinearize(self, ct3, rk, chain_idx):
         """ct3 [3][L][n] -> returns size-2 ct (copy)."""
         work = np.ascontiguousarray(ct3.copy())
@@ -224,30 +231,44 @@ class RefContext:
         return out
 
     # ---- path drivers
+    CT_SIZE_MAX = 16
+
+    def power_sizes(self, dag_nodes):
+        """{power: polynomials} after ComputePowers (2 with key switching; products keep growing without)"""
+        nodes = np.array(dag_nodes, dtype=np.uint32)
+        sizes = np.zeros(max(nd[0] for nd in dag_nodes) + 1, dtype=np.uint32)
+        if lib().ref_power_sizes(self.h, _vp(nodes), len(dag_nodes), _vp(sizes)) < 0:
+            raise ValueError("invalid size")
+        return {nd[0]: int(sizes[nd[0]]) for nd in dag_nodes}
+
     def compute_powers(self, sources, dag_nodes, rk, ps_low_degree):
         """sources: {power: ct [2][first_L][n] coeff}.  Returns {power: ct} per receiver_osn.cpp:459-487."""
         firstL = self.first + 1
         max_p = max(nd[0] for nd in dag_nodes)
+        cap = 3 if self.using_keyswitching else self.CT_SIZE_MAX
         bufs = {}
         ptrs = (u64p * (max_p + 1))()
         for nd in dag_nodes:
-            b = np.zeros((3, firstL, self.n), dtype=np.uint64)
+            b = np.zeros((cap, firstL, self.n), dtype=np.uint64)
             if nd[0] in sources:
                 b[:2] = sources[nd[0]]
             bufs[nd[0]] = b
             ptrs[nd[0]] = _p(b)
         nodes = np.array(dag_nodes, dtype=np.uint32)
+        sizes = np.zeros(max_p + 1, dtype=np.uint32)
         rkp = _p(rk) if rk is not None else None
-        rc = lib().ref_compute_powers(self.h, ptrs, _vp(nodes), len(dag_nodes), rkp, C.c_uint32(ps_low_degree))
+        rc = lib().ref_compute_powers(self.h, ptrs, _vp(nodes), len(dag_nodes), rkp, C.c_uint32(ps_low_degree),
+                                      None if self.using_keyswitching else _vp(sizes))
         if rc == -3:
-            raise RuntimeError("ComputePowers needs ciphertext products but the parameters do not support relinearization")
+            raise ValueError("invalid size")              # a product beyond SEAL_CIPHERTEXT_SIZE_MAX
         assert rc == 0
         high, low = self.clamp(1), self.clamp(2)
         out = {}
         for nd in dag_nodes:
             p = nd[0]
             lvl = high if (ps_low_degree == 0 or p > ps_low_degree) else low
-            out[p] = np.ascontiguousarray(bufs[p].reshape(-1)[: 2 * (lvl + 1) * self.n].reshape(2, lvl + 1, self.n))
+            sz = 2 if self.using_keyswitching else int(sizes[p])
+            out[p] = np.ascontiguousarray(bufs[p].reshape(-1)[: sz * (lvl + 1) * self.n].reshape(sz, lvl + 1, self.n))
         return out
 
     def _ptr_array(self, arrs):
@@ -256,26 +277,37 @@ class RefContext:
             ptrs[i] = _p(a) if a is not None else None
         return ptrs
 
+    def _sizes_of(self, powers):
+        """None with key switching (every power has size 2), else the sizes array ref_eval* take"""
+        if self.using_keyswitching:
+            return None
+        return np.array([0 if a is None else a.shape[0] for a in powers], dtype=np.uint32)
+
     def eval(self, powers, coeffs, lvl, mask):
         """powers: list indexed by power (0 unused).  coeffs: list of arrays (layout per bin_bundle.cpp ctor)."""
-        out = np.empty((2, 1, self.n), dtype=np.uint64)
+        sizes = self._sizes_of(powers)
+        out = np.empty((2 if sizes is None else self.CT_SIZE_MAX, 1, self.n), dtype=np.uint64)
+        osz = C.c_uint32(0)
         rc = lib().ref_eval(self.h, self._ptr_array(powers), len(powers), self._ptr_array(coeffs), len(coeffs),
-                            lvl, _p(mask), _p(out))
+                            lvl, _p(mask), _p(out), None if sizes is None else _vp(sizes), C.byref(osz))
         if rc:
             raise ValueError("not enough ciphertext powers available")
-        return out
+        return np.ascontiguousarray(out[:osz.value])
 
     def eval_patstock(self, powers, coeffs, ps_low_degree, rk, mask):
-        out = np.empty((2, 1, self.n), dtype=np.uint64)
+        sizes = self._sizes_of(powers)
+        out = np.empty((2 if sizes is None else self.CT_SIZE_MAX, 1, self.n), dtype=np.uint64)
+        osz = C.c_uint32(0)
         rc = lib().ref_eval_patstock(self.h, self._ptr_array(powers), len(powers), self._ptr_array(coeffs),
-                                     len(coeffs), C.c_uint32(ps_low_degree), _p(rk) if rk is not None else None, _p(mask), _p(out))
+                                     len(coeffs), C.c_uint32(ps_low_degree), _p(rk) if rk is not None else None, _p(mask), _p(out),
+                                     None if sizes is None else _vp(sizes), C.byref(osz))
         if rc == -1:
             raise ValueError("not enough ciphertext powers available")
         if rc == -2:
             raise ValueError("ps_low_degree must be greater than 1 and less than the size of batched_coeffs")
         if rc == -3:
-            raise RuntimeError("eval_patstock without key switching leaves a size-3 result (bin_bundle.cpp:238-240,308-310): not supported")
-        return out
+            raise ValueError("invalid size")              # a product beyond SEAL_CIPHERTEXT_SIZE_MAX
+        return np.ascontiguousarray(out[:osz.value])
 
     def plain_chain_idx(self, ps_low_degree):
         return lib().ref_plain_chain_idx(self.h, C.c_uint32(ps_low_degree))

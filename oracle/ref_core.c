@@ -731,49 +731,65 @@ static void behz_finish(const ref_ctx *c, const ref_level *lv, uint64_t *dq, uin
     free(fl);
 }
 
-static void behz_multiply(const ref_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3,
-                          int chain_idx, int is_square)
+/* Evaluator::bfv_multiply for ciphertexts of any size [SEAL-recall]: dest_size = size_a + size_b - 1 (throws when that exceeds
+   SEAL_CIPHERTEXT_SIZE_MAX = 16, Ciphertext::resize); output polynomial I = sum_{i + j = I} a_i b_j formed limb-wise in the NTT
+   domain over q and Bsk, every product reduced before the modular add (behz_ciphertext_product).  size 2 x size 2 is the
+   case with key switching (d0 = a0 b0 ; d1 = a0 b1 + a1 b0 ; d2 = a1 b1). */
+static int behz_multiply(const ref_ctx *c, const uint64_t *a, int sa, const uint64_t *b, int sb, uint64_t *out,
+                         int chain_idx, int is_square)
 {
     const ref_level *lv = LV(c, chain_idx);
     int L = lv->L, nBsk = lv->nB + 1; size_t n = c->n;
-    size_t sq = (size_t)L * n, sb = (size_t)nBsk * n;
-    uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * (4 * (sq + sb) + 3 * (sq + sb)));
-    uint64_t *aq = buf, *ab = aq + 2 * sq, *bq = ab + 2 * sb, *bb = bq + 2 * sq;
-    uint64_t *dq = bb + 2 * sb, *db = dq + 3 * sq;
-    for (int p = 0; p < 2; p++) behz_extend_ntt(c, lv, a + p * sq, aq + p * sq, ab + p * sb);
+    int so = sa + sb - 1;
+    if (sa < 2 || sb < 2 || so > REF_CT_SIZE_MAX) return -1;
+    size_t sq = (size_t)L * n, sb_ = (size_t)nBsk * n;
+    uint64_t *buf = (uint64_t *)calloc((size_t)(sa + sb + so) * (sq + sb_), sizeof(uint64_t));
+    uint64_t *aq = buf, *ab = aq + sa * sq, *bq = ab + sa * sb_, *bb = bq + sb * sq;
+    uint64_t *dq = bb + sb * sb_, *db = dq + so * sq;
+    for (int p = 0; p < sa; p++) behz_extend_ntt(c, lv, a + p * sq, aq + p * sq, ab + p * sb_);
     if (is_square) { bq = aq; bb = ab; }
-    else for (int p = 0; p < 2; p++) behz_extend_ntt(c, lv, b + p * sq, bq + p * sq, bb + p * sb);
-    /* (4) tensor: d0 = a0 b0 ; d1 = a0 b1 + a1 b0 ; d2 = a1 b1 */
+    else for (int p = 0; p < sb; p++) behz_extend_ntt(c, lv, b + p * sq, bq + p * sq, bb + p * sb_);
+    /* (4) tensor */
     for (int base = 0; base < 2; base++) {
         int nl = base ? nBsk : L;
-        size_t sp = base ? sb : sq;
+        size_t sp = base ? sb_ : sq;
         const uint64_t *x = base ? ab : aq, *y = base ? bb : bq;
         uint64_t *d = base ? db : dq;
-        for (int j = 0; j < nl; j++) {
-            const ref_mod *m = base ? &lv->Bsk[j] : &lv->q[j];
-            for (size_t k = 0; k < n; k++) {
-                size_t o = (size_t)j * n + k;
-                uint64_t a0 = x[o], a1 = x[sp + o], b0 = y[o], b1 = y[sp + o];
-                d[o] = ref_mulmod(a0, b0, m);
-                d[sp + o] = addmod(ref_mulmod(a0, b1, m), ref_mulmod(a1, b0, m), m->value);
-                d[2 * sp + o] = ref_mulmod(a1, b1, m);
-            }
+        for (int I = 0; I < so; I++) {
+            int i0 = I - (sb - 1) > 0 ? I - (sb - 1) : 0, i1 = I < sa - 1 ? I : sa - 1;
+            for (int i = i0; i <= i1; i++)
+                for (int j = 0; j < nl; j++) {
+                    const ref_mod *m = base ? &lv->Bsk[j] : &lv->q[j];
+                    for (size_t k = 0; k < n; k++) {
+                        size_t o = (size_t)j * n + k;
+                        d[I * sp + o] = addmod(d[I * sp + o], ref_mulmod(x[i * sp + o], y[(I - i) * sp + o], m), m->value);
+                    }
+                }
         }
     }
-    for (int p = 0; p < 3; p++) behz_finish(c, lv, dq + p * sq, db + p * sb, out3 + p * sq);
+    for (int p = 0; p < so; p++) behz_finish(c, lv, dq + p * sq, db + p * sb_, out + p * sq);
     free(buf);
+    return 0;
 }
 
 /* receiver_osn.cpp:424 ; bin_bundle.cpp:272,301  Evaluator::multiply / multiply_inplace */
 void ref_multiply(const ref_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, int chain_idx)
 {
-    behz_multiply(c, a, b, out3, chain_idx, 0);
+    behz_multiply(c, a, 2, b, 2, out3, chain_idx, 0);
 }
 
 /* receiver_osn.cpp:422  Evaluator::square  (bfv_square: d1 = 2 a0 a1 — identical mod q) */
 void ref_square(const ref_ctx *c, const uint64_t *a, uint64_t *out3, int chain_idx)
 {
-    behz_multiply(c, a, a, out3, chain_idx, 1);
+    behz_multiply(c, a, 2, a, 2, out3, chain_idx, 1);
+}
+
+/* the same for operands that were never relinearised (parameter sets with one coefficient prime: receiver_osn.cpp:427-432
+   skips relinearize_inplace, so powers and bin_bundle.cpp:272,301's operands grow).  out: size_a + size_b - 1 polynomials.
+   Returns -1 where SEAL throws (size above 16).  bfv_square falls back to bfv_multiply for sizes other than 2. */
+int ref_multiply_sized(const ref_ctx *c, const uint64_t *a, int size_a, const uint64_t *b, int size_b, uint64_t *out, int chain_idx)
+{
+    return behz_multiply(c, a, size_a, b, size_b, out, chain_idx, a == b && size_a == size_b);
 }
 
 /* receiver_osn.cpp:431 ; bin_bundle.cpp:309  relinearize_inplace

@@ -126,6 +126,9 @@ void ref_add_plain(const ref_ctx *c, uint64_t *ct, const uint64_t *pt_mod_t, siz
 void ref_multiply(const ref_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3,
                   int chain_idx);                        /* size2 x size2 -> size3 */
 void ref_square(const ref_ctx *c, const uint64_t *a, uint64_t *out3, int chain_idx);
+#define REF_CT_SIZE_MAX 16   /* SEAL_CIPHERTEXT_SIZE_MAX [SEAL-recall util/defines.h] */
+/* any sizes (no relinearisation in between): out has size_a + size_b - 1 polynomials; -1 = SEAL throws (size > 16) */
+int  ref_multiply_sized(const ref_ctx *c, const uint64_t *a, int size_a, const uint64_t *b, int size_b, uint64_t *out, int chain_idx);
 /* relin key layout: [decomp i < K-1][component 2][limb K][n], NTT form */
 void ref_relinearize(const ref_ctx *c, uint64_t *ct3, const uint64_t *rk, int chain_idx);
 void ref_mod_switch_to_next(const ref_ctx *c, uint64_t *ct, int polys, int chain_idx);

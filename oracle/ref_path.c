@@ -82,22 +82,44 @@ static size_t ct_words(const ref_ctx *c, int polys, int chain_idx)
     return (size_t)polys * (chain_idx + 1) * c->n;
 }
 
+/* Size of every target power: 2 with key switching (each product is relinearised, receiver_osn.cpp:430-432); without it
+   (one coefficient prime) a product has size(parent1) + size(parent2) - 1.  sizes[] is indexed by power (entries of powers
+   that are no targets stay untouched).  Returns the largest size, or -1 where SEAL's multiply throws (above 16). */
+int ref_power_sizes(const ref_ctx *c, const ref_dag_node *nodes, int n_nodes, uint32_t *sizes)
+{
+    int max_depth = 0, max_size = 2;
+    for (int i = 0; i < n_nodes; i++) if ((int)nodes[i].depth > max_depth) max_depth = (int)nodes[i].depth;
+    for (int i = 0; i < n_nodes; i++) if (!nodes[i].depth) sizes[nodes[i].power] = 2;
+    for (int d = 1; d <= max_depth; d++)
+        for (int i = 0; i < n_nodes; i++) {
+            if ((int)nodes[i].depth != d) continue;
+            uint32_t s = c->using_keyswitching ? 2 : sizes[nodes[i].p1] + sizes[nodes[i].p2] - 1;
+            if (s > REF_CT_SIZE_MAX) return -1;
+            sizes[nodes[i].power] = s;
+            if ((int)s > max_size) max_size = (int)s;
+        }
+    return max_size;
+}
+
 /* receiver_osn.cpp:395-488.
-   powers[p] (p = power index, 0 unused): caller-allocated buffers of 3 * first_L * n words each
-   for every target power; source powers hold size-2 coefficient-form cts at the first data level.
+   powers[p] (p = power index, 0 unused): caller-allocated buffers for every target power, 3 * first_L * n words each with key
+   switching, REF_CT_SIZE_MAX * first_L * n without; source powers hold size-2 coefficient-form cts at the first data level.
    On return each target power is (per :459-487):
      ps_low_degree == 0     : level high, NTT form
      power <= ps_low_degree : level low,  NTT form
-     power >  ps_low_degree : level high, coefficient form            (size 2 always) */
+     power >  ps_low_degree : level high, coefficient form
+   of size 2 with key switching, of size sizes[p] (ref_power_sizes; required then) without.  -3: SEAL throws (size > 16). */
 int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *nodes, int n_nodes,
-                       const uint64_t *rk, uint32_t ps_low_degree)
+                       const uint64_t *rk, uint32_t ps_low_degree, uint32_t *sizes)
 {
     int first = c->first_chain_idx;
     int max_depth = 0;
     for (int i = 0; i < n_nodes; i++) if ((int)nodes[i].depth > max_depth) max_depth = (int)nodes[i].depth;
-    /* no key switching (one coefficient prime): the reference would carry size-3 products on (:427-432); the powers
-       here are size 2, so products are refused rather than truncated (no shipped parameter set needs them) */
-    if (max_depth > 0 && !c->using_keyswitching) return -3;
+    const int relinearize = c->using_keyswitching;                                        /* :416 */
+    if (!relinearize) {
+        if (sizes) { if (ref_power_sizes(c, nodes, n_nodes, sizes) < 0) return -3; }
+        else if (max_depth > 0) return -1;
+    }
     /* parallel_apply visits a node once both parents are done; any topological order gives
        the same values.  Visit by depth. */
     /* the reference runs one task per DAG node on its thread pool (powers.h:158-278); nodes of equal depth
@@ -108,9 +130,13 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
             if ((int)nodes[i].depth != d) continue;
             const ref_dag_node *nd = &nodes[i];
             uint64_t *prod = powers[nd->power];
-            if (nd->p1 == nd->p2) ref_square(c, powers[nd->p1], prod, first);            /* :422 */
-            else ref_multiply(c, powers[nd->p1], powers[nd->p2], prod, first);           /* :424 */
-            ref_relinearize(c, prod, rk, first);                                         /* :431 */
+            if (relinearize) {
+                if (nd->p1 == nd->p2) ref_square(c, powers[nd->p1], prod, first);        /* :422 */
+                else ref_multiply(c, powers[nd->p1], powers[nd->p2], prod, first);       /* :424 */
+                ref_relinearize(c, prod, rk, first);                                     /* :431 */
+            } else {
+                ref_multiply_sized(c, powers[nd->p1], (int)sizes[nd->p1], powers[nd->p2], (int)sizes[nd->p2], prod, first);
+            }
         }
     }
     int high = ref_clamp_chain_idx(c, 1), low = ref_clamp_chain_idx(c, 2);                /* :451-454 */
@@ -118,10 +144,11 @@ int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *
     for (int i = 0; i < n_nodes; i++) {
         uint32_t power = nodes[i].power;
         uint64_t *ct = powers[power];
+        int polys = (!relinearize && sizes) ? (int)sizes[power] : 2;
         int lvl = first;
         int target = (!ps_low_degree || power > ps_low_degree) ? high : low;
-        while (lvl > target) { ref_mod_switch_to_next(c, ct, 2, lvl); lvl--; }            /* :463,471,478 */
-        if (!ps_low_degree || power <= ps_low_degree) ref_transform_to_ntt(c, ct, 2, lvl); /* :467,475 */
+        while (lvl > target) { ref_mod_switch_to_next(c, ct, polys, lvl); lvl--; }        /* :463,471,478 */
+        if (!ps_low_degree || power <= ps_low_degree) ref_transform_to_ntt(c, ct, polys, lvl); /* :467,475 */
     }
     return 0;
 }
@@ -148,90 +175,107 @@ static const uint64_t *load_coeff(uint64_t *scratch, const uint64_t *stored, siz
 
 /* bin_bundle.cpp:106-174.  powers[d] for d=1..degree at level `lvl` in NTT form.
    coeffs[0]: n words mod t (coefficient form); coeffs[d>0]: (lvl+1)*n words NTT form.
-   out: 2*n words at the last level.  Returns 0 / -1 (not enough powers). */
+   sizes: polynomials of every power (NULL: 2 each, the case with key switching).  out: *out_size * n words at the last level
+   (capacity: 2 * n words without sizes, REF_CT_SIZE_MAX * n with).  Returns 0 / -1 (not enough powers). */
 int ref_eval(const ref_ctx *c, uint64_t *const *powers, int n_powers, const uint64_t *const *coeffs,
-             int n_coeffs, int lvl, const uint64_t *mask, uint64_t *out)
+             int n_coeffs, int lvl, const uint64_t *mask, uint64_t *out, const uint32_t *sizes, uint32_t *out_size)
 {
     if (n_powers < (n_coeffs > 2 ? n_coeffs : 2)) return -1;                              /* :116-118 */
-    size_t n = c->n, w = ct_words(c, 2, lvl);
-    uint64_t *result = (uint64_t *)calloc(w, sizeof(uint64_t));
+    const int cap = sizes ? REF_CT_SIZE_MAX : 2;
+    size_t n = c->n, w = ct_words(c, cap, lvl);
+    uint64_t *result = (uint64_t *)calloc(w, sizeof(uint64_t));                           /* :132-134 size 2, zero */
+    int rs = 2;
     uint64_t *temp = (uint64_t *)malloc(w * sizeof(uint64_t));
     uint64_t *scratch = (uint64_t *)malloc((size_t)(lvl + 1) * n * sizeof(uint64_t));
     for (int deg = 1; deg < n_coeffs; deg++) {
+        const int ps = sizes ? (int)sizes[deg] : 2;
         const uint64_t *co = load_coeff(scratch, coeffs[deg], (size_t)(lvl + 1) * n);     /* :143 */
-        ref_multiply_plain_ntt(c, powers[deg], co, temp, 2, lvl);                         /* :147 */
-        ref_add(c, result, temp, 2, lvl);                                                 /* :148 */
+        ref_multiply_plain_ntt(c, powers[deg], co, temp, ps, lvl);                        /* :147 */
+        ref_add(c, result, temp, ps, lvl);       /* :148 add_inplace: the longer operand's extra polynomials are copied = added to zero */
+        if (ps > rs) rs = ps;
     }
-    ref_transform_from_ntt(c, result, 2, lvl);                                            /* :154 */
+    ref_transform_from_ntt(c, result, rs, lvl);                                           /* :154 */
     ref_add_plain(c, result, load_coeff(scratch, coeffs[0], n), n, lvl);                  /* :159 */
     ref_add_plain(c, result, mask, n, lvl);                                               /* :162 */
-    while (lvl > 0) { ref_mod_switch_to_next(c, result, 2, lvl); lvl--; }                 /* :168-170 */
-    ref_clear_irrelevant_bits(c, result, 2);                                              /* :171 */
-    memcpy(out, result, 2 * n * sizeof(uint64_t));
+    while (lvl > 0) { ref_mod_switch_to_next(c, result, rs, lvl); lvl--; }                /* :168-170 */
+    ref_clear_irrelevant_bits(c, result, rs);                                             /* :171 */
+    memcpy(out, result, (size_t)rs * n * sizeof(uint64_t));
+    if (out_size) *out_size = (uint32_t)rs;
     free(result); free(temp); free(scratch);
     return 0;
 }
 
-/* bin_bundle.cpp:192-360 */
+/* bin_bundle.cpp:192-360; sizes / out / out_size as in ref_eval.  -3: a product would exceed SEAL's largest ciphertext. */
 int ref_eval_patstock(const ref_ctx *c, uint64_t *const *powers, int n_powers,
                       const uint64_t *const *coeffs, int n_coeffs, uint32_t ps_low_degree,
-                      const uint64_t *rk, const uint64_t *mask, uint64_t *out)
+                      const uint64_t *rk, const uint64_t *mask, uint64_t *out, const uint32_t *sizes, uint32_t *out_size)
 {
     if (n_powers < (n_coeffs > 2 ? n_coeffs : 2)) return -1;                              /* :204-206 */
     size_t degree = (size_t)n_coeffs - 1;
     if (ps_low_degree <= 1 || ps_low_degree >= degree) return -2;                         /* :209-213 */
-    /* Without key switching (one coefficient prime) the reference skips relinearize_inplace (:308-310) and its
-       result stays a size-3 ciphertext.  This restatement and the engine's ABI carry size-2 results (2*n words),
-       so that case is refused explicitly instead of dropping c2.  No shipped parameter set reaches it (every
-       single-prime set has ps_low_degree 0). */
-    if (!c->using_keyswitching) return -3;
+    /* Without key switching (one coefficient prime) the reference skips relinearize_inplace (:308-310): the result keeps
+       the size of the largest product (at least 3, :238-240), and the powers themselves are longer than 2 (`sizes`). */
+    if (!c->using_keyswitching && !sizes) return -1;
     int high = ref_clamp_chain_idx(c, 1);                                                 /* :220 */
     int low = ref_plain_chain_idx(c, ps_low_degree);      /* level of low powers & NTT plaintexts */
     size_t n = c->n;
     size_t h = (size_t)ps_low_degree + 1, H = degree / h;                                 /* :225-227 */
-    size_t wl = ct_words(c, 2, low), wh3 = ct_words(c, 3, high), wh2 = ct_words(c, 2, high);
+    const int cap = sizes ? REF_CT_SIZE_MAX : 3;
+#define SZ(p) (sizes ? (int)sizes[p] : 2)
+    size_t wl = ct_words(c, cap, low), wh = ct_words(c, cap, high);
     size_t ptw = (size_t)(low + 1) * n;
 
-    uint64_t *result = (uint64_t *)calloc(wh3, sizeof(uint64_t));                         /* :238-240 */
-    uint64_t *temp = (uint64_t *)malloc((wl > wh3 ? wl : wh3) * sizeof(uint64_t));
-    uint64_t *temp_in = (uint64_t *)malloc((wl > wh3 ? wl : wh3) * sizeof(uint64_t));
-    uint64_t *prod = (uint64_t *)malloc(wh3 * sizeof(uint64_t));
+    uint64_t *result = (uint64_t *)calloc(wh, sizeof(uint64_t));                          /* :238-240 size 3, zero */
+    int rs = 3;
+    uint64_t *temp = (uint64_t *)malloc((wl > wh ? wl : wh) * sizeof(uint64_t));
+    uint64_t *temp_in = (uint64_t *)malloc((wl > wh ? wl : wh) * sizeof(uint64_t));
+    uint64_t *prod = (uint64_t *)malloc(wh * sizeof(uint64_t));
     uint64_t *scratch = (uint64_t *)malloc(ptw * sizeof(uint64_t));
+    int rc = 0;
 
-    for (size_t i = 1; i <= H; i++) {                                                     /* :248-304 */
+    for (size_t i = 1; i <= H && !rc; i++) {                                              /* :248-304 */
         size_t jmax = (i < H) ? h - 1 : degree % h;
         if (i == H && jmax == 0) break;                                                   /* :279 */
+        int s_in = 2;
+        if (sizes) memset(temp_in, 0, wl * sizeof(uint64_t));      /* later terms may be longer than the first (add_inplace copies) */
         for (size_t j = 1; j <= jmax; j++) {
             const uint64_t *co = load_coeff(scratch, coeffs[i * h + j], ptw);             /* :252,281 */
-            ref_multiply_plain_ntt(c, powers[j], co, temp, 2, low);                       /* :258,287 */
-            if (j == 1) memcpy(temp_in, temp, wl * sizeof(uint64_t));
-            else ref_add(c, temp_in, temp, 2, low);                                       /* :264,293 */
+            ref_multiply_plain_ntt(c, powers[j], co, temp, SZ(j), low);                   /* :258,287 */
+            if (j == 1) memcpy(temp_in, temp, ct_words(c, SZ(1), low) * sizeof(uint64_t));
+            else ref_add(c, temp_in, temp, SZ(j), low);                                   /* :264,293 */
+            if (SZ(j) > s_in) s_in = SZ(j);
         }
-        ref_transform_from_ntt(c, temp_in, 2, low);                                       /* :268,297 */
-        for (int l = low; l > high; l--) ref_mod_switch_to_next(c, temp_in, 2, l);        /* :269,298 */
-        ref_multiply(c, temp_in, powers[i * h], prod, high);                              /* :272,301 */
-        ref_add(c, result, prod, 3, high);                                                /* :273,303 */
+        ref_transform_from_ntt(c, temp_in, s_in, low);                                    /* :268,297 */
+        for (int l = low; l > high; l--) ref_mod_switch_to_next(c, temp_in, s_in, l);     /* :269,298 */
+        const int sp = s_in + SZ(i * h) - 1;
+        if (ref_multiply_sized(c, temp_in, s_in, powers[i * h], SZ(i * h), prod, high)) { rc = -3; break; }   /* :272,301 */
+        ref_add(c, result, prod, sp, high);                                               /* :273,303 */
+        if (sp > rs) rs = sp;
     }
-    ref_relinearize(c, result, rk, high);                                                 /* :308-310 */
+    if (rc) { free(result); free(temp); free(temp_in); free(prod); free(scratch); return rc; }
+    if (c->using_keyswitching) { ref_relinearize(c, result, rk, high); rs = 2; }          /* :308-310 */
 
     for (size_t j = 1; j < h; j++) {                                                      /* :314-324 */
         const uint64_t *co = load_coeff(scratch, coeffs[j], ptw);
-        ref_multiply_plain_ntt(c, powers[j], co, temp, 2, low);
-        ref_transform_from_ntt(c, temp, 2, low);
-        for (int l = low; l > high; l--) ref_mod_switch_to_next(c, temp, 2, l);
-        ref_add(c, result, temp, 2, high);
+        ref_multiply_plain_ntt(c, powers[j], co, temp, SZ(j), low);
+        ref_transform_from_ntt(c, temp, SZ(j), low);
+        for (int l = low; l > high; l--) ref_mod_switch_to_next(c, temp, SZ(j), l);
+        ref_add(c, result, temp, SZ(j), high);
+        if (SZ(j) > rs) rs = SZ(j);
     }
     for (size_t i = 1; i <= H; i++) {                                                     /* :328-337 */
         const uint64_t *co = load_coeff(scratch, coeffs[i * h], n);
-        ref_multiply_plain_coeff(c, powers[i * h], co, n, temp, 2, high);
-        ref_add(c, result, temp, 2, high);
+        ref_multiply_plain_coeff(c, powers[i * h], co, n, temp, SZ(i * h), high);
+        ref_add(c, result, temp, SZ(i * h), high);
+        if (SZ(i * h) > rs) rs = SZ(i * h);
     }
     ref_add_plain(c, result, load_coeff(scratch, coeffs[0], n), n, high);                 /* :345 */
     ref_add_plain(c, result, mask, n, high);                                              /* :346 */
-    (void)wh2;
-    for (int l = high; l > 0; l--) ref_mod_switch_to_next(c, result, 2, l);               /* :354-356 */
-    ref_clear_irrelevant_bits(c, result, 2);                                              /* :357 */
-    memcpy(out, result, 2 * n * sizeof(uint64_t));
+    for (int l = high; l > 0; l--) ref_mod_switch_to_next(c, result, rs, l);              /* :354-356 */
+    ref_clear_irrelevant_bits(c, result, rs);                                             /* :357 */
+    memcpy(out, result, (size_t)rs * n * sizeof(uint64_t));
+    if (out_size) *out_size = (uint32_t)rs;
+#undef SZ
     free(result); free(temp); free(temp_in); free(prod); free(scratch);
     return 0;
 }

@@ -11,15 +11,18 @@ typedef struct { uint32_t power, depth, p1, p2; } ref_dag_node;   /* powers.h:53
 int ref_create_powers_set(uint32_t ps_low_degree, uint32_t target_degree, uint32_t *out, int cap);
 int ref_powers_dag_configure(const uint32_t *sources, int ns, const uint32_t *targets, int nt,
                              ref_dag_node *nodes);
+/* sizes: polynomials per target power, indexed by power; required when the parameters have no key switching and the
+   PowersDag has products (buffers then hold REF_CT_SIZE_MAX polynomials), may be NULL otherwise */
+int ref_power_sizes(const ref_ctx *c, const ref_dag_node *nodes, int n_nodes, uint32_t *sizes);
 int ref_compute_powers(const ref_ctx *c, uint64_t **powers, const ref_dag_node *nodes, int n_nodes,
-                       const uint64_t *rk, uint32_t ps_low_degree);
+                       const uint64_t *rk, uint32_t ps_low_degree, uint32_t *sizes);
 int ref_plain_chain_idx(const ref_ctx *c, uint32_t ps_low_degree);
 int ref_coeff_is_ntt(uint32_t ps_low_degree, uint32_t i);
 int ref_eval(const ref_ctx *c, uint64_t *const *powers, int n_powers, const uint64_t *const *coeffs,
-             int n_coeffs, int lvl, const uint64_t *mask, uint64_t *out);
+             int n_coeffs, int lvl, const uint64_t *mask, uint64_t *out, const uint32_t *sizes, uint32_t *out_size);
 int ref_eval_patstock(const ref_ctx *c, uint64_t *const *powers, int n_powers,
                       const uint64_t *const *coeffs, int n_coeffs, uint32_t ps_low_degree,
-                      const uint64_t *rk, const uint64_t *mask, uint64_t *out);
+                      const uint64_t *rk, const uint64_t *mask, uint64_t *out, const uint32_t *sizes, uint32_t *out_size);
 
 /* ---- harness-only pieces (other party / DB build), needed to make inputs & check outputs ---- */
 typedef struct { uint64_t s[4]; } ref_rng;
