@@ -55,7 +55,7 @@ template <class F> static int guarded(F &&fn)
 extern "C" {
 
 const char *apsu_he_last_error(void) { return g_last_error.c_str(); }
-int apsu_he_abi_version(void) { return 3; }
+int apsu_he_abi_version(void) { return 4; }
 
 int apsu_he_create(const char *json, int device, apsu_he_ctx **out)
 {
@@ -116,6 +116,7 @@ int apsu_he_get_info(const apsu_he_ctx *ctx, apsu_he_info *out)
             out->target_power_count = (uint32_t)ctx->eng->dag().target_powers().size();
             out->powers_dag_depth = ctx->eng->dag().depth();
         }
+        out->result_polys = ctx->eng->result_polys();
     });
 }
 
@@ -153,6 +154,8 @@ int apsu_he_multiply(apsu_he_ctx *c, const uint64_t *a, const uint64_t *b, uint6
 { return guarded([&] { REQUIRE(c && a && b && out3, "null argument"); c->eng->multiply(a, b, out3, ci); }); }
 int apsu_he_square(apsu_he_ctx *c, const uint64_t *a, uint64_t *out3, int ci)
 { return guarded([&] { REQUIRE(c && a && out3, "null argument"); c->eng->multiply(a, a, out3, ci); }); }
+int apsu_he_multiply_sized(apsu_he_ctx *c, const uint64_t *a, int size_a, const uint64_t *b, int size_b, uint64_t *out, int ci)
+{ return guarded([&] { REQUIRE(c && a && b && out, "null argument"); c->eng->multiply_sized(a, size_a, b, size_b, out, ci); }); }
 int apsu_he_relinearize(apsu_he_ctx *c, uint64_t *ct3, const apsu_he_relin *rk, int ci)
 { return guarded([&] { REQUIRE(c && ct3 && rk, "null argument"); c->eng->relinearize(ct3, *rk->rk, ci); }); }
 int apsu_he_mod_switch_to_next(apsu_he_ctx *c, uint64_t *ct, int polys, int ci)
@@ -253,6 +256,10 @@ int apsu_he_decrypt_decode(apsu_he_ctx *c, const uint64_t *sk_ntt, const uint64_
 { return guarded([&] { REQUIRE(c && sk_ntt && (cts || !count), "null argument"); c->eng->decrypt_decode(sk_ntt, cts, cts_on_device != 0, count, values, blocks); }); }
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree)
 { return guarded([&] { REQUIRE(b && degree, "null argument"); *degree = b->b->degree; }); }
+int apsu_he_bundle_result_size(const apsu_he_ctx *c, const apsu_he_bundle *b, uint32_t *polys)
+{ return guarded([&] { REQUIRE(c && b && polys, "null argument"); *polys = c->eng->result_size(*b->b); }); }
+int apsu_he_power_size(const apsu_he_ctx *c, uint32_t power, uint32_t *polys)
+{ return guarded([&] { REQUIRE(c && polys, "null argument"); *polys = c->eng->power_size(power); }); }
 int apsu_he_bundle_free(apsu_he_bundle *b) { return guarded([&] { delete b; }); }
 int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes)
 { return guarded([&] { REQUIRE(b && db_bytes, "null argument"); *db_bytes = b->b->db_bytes(); }); }
@@ -797,15 +804,16 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
         std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), src.data(), true, rk.get());
         std::vector<const Bundle *> bs(count);
         for (int i = 0; i < count; i++) bs[i] = bundles[i]->b.get();
-        std::vector<u64> out((size_t)count * 2 * n);
+        const size_t R = E.result_polys();                                // 2 with key switching; longer results without
+        std::vector<u64> out((size_t)count * R * n);
         E.eval_bundles(bs.data(), count, *pw, rk.get(), masks, masks_on_device != 0, out.data(), false);
         E.wait();                                                       // the device buffers of this call die with it
         // ResultPackage per BinBundle (receiver_osn.cpp:507-539): the result ciphertext saved at the last level
         for (int i = 0; i < count; i++) {
             sealio::Ciphertext rc;
             std::memcpy(rc.parms_id, seal_level(sc, 0).parms_id, 32);
-            rc.size = 2; rc.poly_modulus_degree = n; rc.coeff_modulus_size = 1;
-            rc.data.assign(out.begin() + (size_t)i * 2 * n, out.begin() + (size_t)(i + 1) * 2 * n);
+            rc.size = E.result_size(*bs[i]); rc.poly_modulus_degree = n; rc.coeff_modulus_size = 1;
+            rc.data.assign(out.begin() + (size_t)i * R * n, out.begin() + ((size_t)i * R + rc.size) * n);
             const std::vector<uint8_t> body = sealio::save_ciphertext(rc, (uint8_t)result_compr_mode);
             wire::ResultPackage rp;
             rp.bundle_idx = bs[i]->bundle_idx; rp.cache_idx = bs[i]->cache_idx;

@@ -159,6 +159,9 @@ bool launch_drop_behz_ext(const DevLevel *lv, int L, int nB, const u64 *in, size
                           hipStream_t st, bool raw = false);
 struct TensorJob { const u64 *a, *b; u64 *d; };   // a,b: [2][E][n] ext-NTT ; d: [3][E][n]
 void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batch, hipStream_t st);
+// operands of any size: a: [sa][E][n], b: [sb][E][n] ext-NTT ; d: [sa + sb - 1][E][n]   (no key switching: products are never relinearised)
+struct TensorConvJob { const u64 *a, *b; u64 *d; int sa, sb; };
+void launch_tensor_conv(const DevLevel *lv, const TensorConvJob *jobs, size_t n, int njobs, hipStream_t st);
 // The same for a sum of products sharing one output (eval_patstock's sum over i): a, b: [terms][2][E][n];
 // dq: [terms][3][L][n] per-term q limbs; bs: [3][nBsk][n] Bsk limbs summed over the terms
 struct TensorSumJob { const u64 *a, *b; u64 *dq, *bs; int terms; int pad; };

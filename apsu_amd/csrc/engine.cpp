@@ -337,6 +337,27 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (!dag_.configure(psu_.query_params.query_powers, targets))
             throw std::invalid_argument("failed to configure PowersDag");
         build_schedule();
+        // polynomials per target power: 2 with key switching; without it a product has size(parent1) + size(parent2) - 1
+        const uint32_t max_power = *dag_.target_powers().rbegin();
+        nks_size_.assign(max_power + 1, 0);
+        for (uint32_t p : dag_.target_powers()) nks_size_[p] = 2;
+        nks_ = !hp_.using_keyswitching && dag_.depth() > 0;
+        if (nks_) {
+            uint32_t widest = 2;
+            for (const auto &nd : sched_.nodes) {                 // slot order: parents come first
+                const uint32_t a = nks_size_[sched_.slot_power[nd[1]]], b = nks_size_[sched_.slot_power[nd[2]]];
+                const uint32_t sz = std::min<uint32_t>(a + b - 1, 2 * CT_SIZE_MAX);        // (kept finite; anything above the limit throws)
+                nks_size_[sched_.slot_power[nd[0]]] = sz;
+                widest = std::max(widest, sz);
+            }
+            nks_oversize_ = widest > CT_SIZE_MAX;
+            nks_S_ = (std::min(widest, CT_SIZE_MAX) + 1) & ~1u;
+        }
+        if (!hp_.using_keyswitching)                              // (eval_patstock alone already leaves three polynomials)
+            for (uint32_t deg = 0; deg <= psu_.table_params.max_items_per_bin; deg++) {
+                const uint32_t r = result_size_for(deg);
+                if (r <= CT_SIZE_MAX) result_polys_ = std::max(result_polys_, r);
+            }
     }
     size_t init = 4096 * n * sizeof(u64);          // 256 MiB at n = 8192; grows on demand
     if (const char *env = std::getenv("APSU_HE_ARENA_BYTES")) init = std::strtoull(env, nullptr, 10);
@@ -1224,11 +1245,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     if (!has_psu_) throw std::logic_error("context was created without PSUParams");
     if (nb <= 0) throw std::invalid_argument("no bundle indices given");
     if (hp_.using_keyswitching && dag_.depth() > 0 && !rk) throw std::invalid_argument("relinearization keys are required");
-    // one coefficient prime = no key switching: the reference then leaves every product at size 3 (receiver_osn.cpp:427-432)
-    // and multiplies size-3 ciphertexts further; this engine holds size-2 powers, so that case is refused, not truncated.
-    // Every shipped single-prime parameter set sends all powers as sources (depth 0).
-    if (!hp_.using_keyswitching && dag_.depth() > 0)
-        throw std::logic_error("ComputePowers needs ciphertext products but the parameters do not support relinearization");
+    // one coefficient prime = no key switching: the reference then leaves every product unrelinearised (receiver_osn.cpp:427-432)
+    // and multiplies the longer ciphertexts further: a path of its own (every shipped single-prime set has depth 0)
+    if (nks_) return compute_powers_nks(bundle_indices, nb, src, on_device);
     const Sched &s = sched_;
     const size_t n = hp_.n;
     job_seq_base_ = 0;                                       // job-cache slots 0..255: ComputePowers
@@ -1348,10 +1367,10 @@ void Engine::download_power(const Powers &pw, uint32_t bundle_idx, uint32_t powe
         if (power % (ps + 1) != 0 || power / (ps + 1) > pw.n_high) throw std::invalid_argument("power not available");
         idx = power / (ps + 1) - 1;
     }
-    const size_t words = (size_t)2 * (lvl + 1) * hp_.n;
+    const size_t words = (size_t)power_size(power) * (lvl + 1) * hp_.n;               // the stored slot may be zero-padded beyond that
     if (capacity_words < words) throw std::invalid_argument("output buffer too small");
     sync();
-    const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * words;
+    const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * pw.polys * (lvl + 1) * hp_.n;
     HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
     if (chain_idx) *chain_idx = lvl;
     if (is_ntt) *is_ntt = low ? 1 : 0;
@@ -1747,11 +1766,18 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             if (b.degree && b.pt_level != low) throw std::logic_error("plaintext level does not match the powers");
         }
     }
-    // Without key switching the reference leaves eval_patstock's result at size 3 (bin_bundle.cpp:238-240,308-310); this
-    // ABI returns size-2 results (2*n words), so that combination is refused instead of silently dropping c2.  No
-    // shipped parameter set reaches it: every single-prime set has ps_low_degree 0.
-    if (any_ps && !hp_.using_keyswitching)
-        throw std::logic_error("eval_patstock without key switching yields a size-3 ciphertext, which this interface does not return");
+    // Without key switching the reference leaves eval_patstock's result unrelinearised (bin_bundle.cpp:238-240,308-310) and
+    // the powers themselves may be longer than two polynomials: a path of its own
+    if (pw.polys != (nks_ ? nks_S_ : 2u)) throw std::invalid_argument("ciphertext powers do not belong to this context");
+    if (nks_ || (any_ps && !hp_.using_keyswitching)) {
+        eval_bundles_nks(bundles, count, pw, masks, masks_on_device, out, out_on_device, out_rows);
+        if (phase_on_ && ev_span.a) {
+            ev_span.b = phase_event(st_);
+            phase_spans_.push_back(ev_span);
+            if (query_start_) { if (query_end_) phase_pool_.push_back(query_end_); query_end_ = phase_event(st_); }
+        }
+        return;
+    }
     if (any_ps && !rk) throw std::invalid_argument("relinearization keys are required");
 
     // powers are stored bundle-index major ([idx][power][2][L][n]): one index's powers are contiguous
@@ -2093,6 +2119,281 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             else mark_inflight();
         });
     }
+}
+
+// ============================================================================ no key switching: ciphertexts of any size
+// One coefficient prime = SEALContext::using_keyswitching() false: Receiver::ComputePowers skips relinearize_inplace
+// (receiver_osn.cpp:416,430-432) and eval_patstock does too (bin_bundle.cpp:308-310).  Every product then has
+// size(a) + size(b) - 1 polynomials (Evaluator::bfv_multiply; Ciphertext::resize throws above SEAL_CIPHERTEXT_SIZE_MAX = 16),
+// add_inplace takes the longer operand's size, multiply_plain / the transforms act on every polynomial.  There is one level
+// (chain index 0, one limb), so no modulus switching.  Stored powers are zero-padded to a common even polynomial count
+// (Powers::polys): the multiply-accumulate kernel handles a pair of polynomials per job, and a zero polynomial contributes
+// zero to every sum, so only the SIZES are bookkeeping (power_size / result_size) -- the numbers are exact.
+// Plain compositions of the per-polynomial kernels; nothing here is tuned (no shipped parameter set has products with one prime).
+
+uint32_t Engine::power_size(uint32_t power) const
+{
+    if (!has_psu_) throw std::invalid_argument("context has no PSUParams");
+    if (power >= nks_size_.size() || !nks_size_[power]) throw std::invalid_argument("power not available");
+    return nks_size_[power];
+}
+
+// size of BatchedPlaintextPolyn::eval / eval_patstock's result for a BinBundle of this degree (bin_bundle.cpp:132-134 starts at
+// size 2, :238-240 at size 3); values above CT_SIZE_MAX mean SEAL throws inside the evaluation
+uint32_t Engine::result_size_for(uint32_t degree) const
+{
+    if (hp_.using_keyswitching) return 2;
+    const uint32_t ps = psu_.query_params.ps_low_degree, h = ps + 1;
+    auto sz = [&](uint32_t p) { return p < nks_size_.size() ? nks_size_[p] : 0u; };
+    if (!(ps > 1 && ps < degree)) {                          // receiver_osn.cpp:520-522 -> eval
+        uint32_t r = 2;
+        for (uint32_t d = 1; d <= degree; d++) r = std::max(r, sz(d));
+        return r;
+    }
+    const uint32_t H = degree / h, rem = degree % h;
+    uint32_t r = 3, low_all = 2;
+    for (uint32_t j = 1; j <= ps; j++) low_all = std::max(low_all, sz(j));
+    for (uint32_t i = 1; i <= H; i++) {
+        const uint32_t cnt = i < H ? ps : rem;
+        if (!cnt) break;
+        uint32_t s_in = 2;
+        for (uint32_t j = 1; j <= cnt; j++) s_in = std::max(s_in, sz(j));
+        r = std::max(r, s_in + sz(i * h) - 1);               // :272,301
+    }
+    r = std::max(r, low_all);                                // :314-324
+    for (uint32_t i = 1; i <= H; i++) r = std::max(r, sz(i * h));    // :328-337
+    return r;
+}
+
+uint32_t Engine::result_size(const Bundle &b) const
+{
+    if (!has_psu_) throw std::invalid_argument("context has no PSUParams");
+    return result_size_for(b.degree);
+}
+
+void Engine::d_multiply_sized(const u64 *ea, int sa, const u64 *eb, int sb, u64 *out, int chain_idx)
+{
+    const size_t n = hp_.n, L = chain_idx + 1;
+    const size_t E = hlevel(chain_idx).L + hlevel(chain_idx).nB + 1;
+    const int so = sa + sb - 1, so3 = (so + 2) / 3 * 3;        // the finish kernels take polynomials three at a time
+    u64 *d = ws((size_t)so3 * E * n), *o = ws((size_t)so3 * L * n);
+    if (so3 > so) HIP_CHECK(hipMemsetAsync(d + (size_t)so * E * n, 0, (size_t)(so3 - so) * E * n * sizeof(u64), st_));
+    std::vector<TensorConvJob> tj{ TensorConvJob{ ea, eb, d, sa, sb } };
+    { PROF(P_TENSOR, 0); launch_tensor_conv(dlevel(chain_idx), upload_jobs(tj), n, 1, st_); }
+    d_ntt(d, (size_t)so3 * E, map_ext_fin(chain_idx), (int)E, true);
+    std::vector<FinishJob> fj;
+    for (int t = 0; t < so3 / 3; t++) fj.push_back(FinishJob{ d + (size_t)3 * t * E * n, o + (size_t)3 * t * L * n, 1, 0 });
+    { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
+    D2D(out, o, (size_t)so * L * n);
+}
+
+void Engine::multiply_sized(const u64 *a, int sa, const u64 *b, int sb, u64 *out, int chain_idx)
+{
+    Enter g(this);
+    TIER1_SLOTS();
+    check_level(chain_idx);
+    if (sa < 2 || sb < 2 || sa + sb - 1 > (int)CT_SIZE_MAX) throw std::invalid_argument("invalid size");      // Ciphertext::resize
+    const size_t n = hp_.n, L = chain_idx + 1;
+    const size_t E = hlevel(chain_idx).L + hlevel(chain_idx).nB + 1;
+    const bool square = (a == b && sa == sb);
+    WITH_ARENA({
+        u64 *in = ws((size_t)(sa + (square ? 0 : sb)) * L * n);
+        H2D(in, a, (size_t)sa * L * n);
+        if (!square) H2D(in + (size_t)sa * L * n, b, (size_t)sb * L * n);
+        const int np = sa + (square ? 0 : sb);
+        u64 *ext = ws((size_t)np * E * n);
+        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, in, L * n, 1, ext, n, np, st_); }
+        d_ntt(ext, (size_t)np * E, map_ext(chain_idx), (int)E, false);
+        u64 *o = ws((size_t)(sa + sb - 1) * L * n);
+        d_multiply_sized(ext, sa, square ? ext : ext + (size_t)sa * E * n, sb, o, chain_idx);
+        D2H(out, o, (size_t)(sa + sb - 1) * L * n);
+        sync();
+    });
+}
+
+std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device)
+{
+    if (nks_oversize_)          // Evaluator::multiply -> Ciphertext::resize: std::invalid_argument("invalid size or poly_modulus_degree")
+        throw std::invalid_argument("invalid size: a product of unrelinearized ciphertext powers exceeds SEAL's largest ciphertext");
+    const Sched &s = sched_;
+    const size_t n = hp_.n, S = nks_S_, P = s.slot_power.size();
+    const size_t E = hlevel(0).L + hlevel(0).nB + 1;
+    job_seq_base_ = 0;
+    auto pw = std::make_unique<Powers>();
+    pw->nb = nb;
+    pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
+    pw->low_level = pw->high_level = 0;
+    pw->n_low = (uint32_t)s.low_powers.size();
+    pw->n_high = (uint32_t)s.high_powers.size();
+    pw->polys = (uint32_t)S;
+    counters_[C_POWERS_ALLOC]++;
+    pw->low.alloc((size_t)pw->n_low * nb * S * n * sizeof(u64));
+    if (pw->n_high) {
+        pw->high.alloc((size_t)pw->n_high * nb * S * n * sizeof(u64));
+        pw->hext.alloc((size_t)pw->n_high * nb * S * E * n * sizeof(u64));
+    }
+    PhaseSpan cp_span;
+    if (phase_on_) {
+        phase_close_query();
+        cp_span.phase = PH_COMPUTE_POWERS;
+        cp_span.a = phase_event(st_);
+        query_start_ = phase_event(st_);
+    }
+    WITH_ARENA({
+        if (cp_span.b) { phase_pool_.push_back(cp_span.b); cp_span.b = nullptr; }                  // a retry after arena growth
+        // slot-major like the key-switching walk: [slot][bundle index][S polys]; coefficient form and extended + NTT form
+        u64 *coef = ws(P * nb * S * n), *ext = ws(P * nb * S * E * n);
+        HIP_CHECK(hipMemsetAsync(coef, 0, P * nb * S * n * sizeof(u64), st_));
+        auto coef_ptr = [&](int slot, int b) { return coef + ((size_t)slot * nb + b) * S * n; };
+        auto ext_ptr = [&](int slot, int b) { return ext + ((size_t)slot * nb + b) * S * E * n; };
+        int si = 0;
+        for (auto &kv : dag_.nodes()) {                                                            // receiver_osn.cpp:304-317
+            if (!kv.second.is_source()) continue;
+            for (int b = 0; b < nb; b++) {
+                const u64 *sp = src[(size_t)b * dag_.source_count() + si];
+                if (on_device) D2D(coef_ptr(s.slot_of[kv.first], b), sp, 2 * n);
+                else H2D(coef_ptr(s.slot_of[kv.first], b), sp, 2 * n);
+            }
+            si++;
+        }
+        // BEHZ extension + NTT of every polynomial of the slots [s0, s1) (zero padding extends to zero)
+        auto extend = [&](int s0, int s1) {
+            if (s1 <= s0) return;
+            { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(0), hlevel(0).L, hlevel(0).nB, coef_ptr(s0, 0), S * n, (int)S, ext_ptr(s0, 0), n, (s1 - s0) * nb, st_); }
+            d_ntt(ext_ptr(s0, 0), (size_t)(s1 - s0) * nb * S * E, map_ext(0), (int)E, false);
+        };
+        extend(s.levels[0].s0, s.levels[0].s1);
+        for (size_t d = 1; d < s.levels.size(); d++) {
+            const size_t mark = arena_off_;
+            for (const auto &nd : s.nodes) {                                                       // :418-433, one product per node and index
+                if (nd[0] < s.levels[d].s0 || nd[0] >= s.levels[d].s1) continue;
+                const int sa = (int)nks_size_[s.slot_power[nd[1]]], sb = (int)nks_size_[s.slot_power[nd[2]]];
+                for (int b = 0; b < nb; b++) {
+                    d_multiply_sized(ext_ptr(nd[1], b), sa, ext_ptr(nd[2], b), sb, coef_ptr(nd[0], b), 0);
+                    arena_off_ = mark;                                                             // stream order makes the reuse safe
+                }
+            }
+            extend(s.levels[d].s0, s.levels[d].s1);
+        }
+        // :458-487: no level below the first one; low powers (all of them without Paterson-Stockmeyer) go to NTT form
+        for (size_t i = 0; i < s.low_powers.size(); i++)
+            for (int b = 0; b < nb; b++)
+                D2D(pw->low.u() + ((size_t)b * pw->n_low + i) * S * n, coef_ptr(s.slot_of[s.low_powers[i]], b), S * n);
+        d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * S, 0, false);
+        for (size_t i = 0; i < s.high_powers.size(); i++)
+            for (int b = 0; b < nb; b++) {
+                D2D(pw->high.u() + ((size_t)b * pw->n_high + i) * S * n, coef_ptr(s.slot_of[s.high_powers[i]], b), S * n);
+                D2D(pw->hext.u() + ((size_t)b * pw->n_high + i) * S * E * n, ext_ptr(s.slot_of[s.high_powers[i]], b), S * E * n);
+            }
+        if (phase_on_ && cp_span.a) cp_span.b = phase_event(st_);
+        sync();                                              // the workspace is reused by the next call; nothing here is latency-critical
+    });
+    if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
+    return pw;
+}
+
+void Engine::eval_bundles_nks(const Bundle *const *bundles, int count, const Powers &pw, const u64 *const *masks, bool masks_on_device,
+                              u64 *out, bool out_on_device, u64 *const *out_rows)
+{
+    const size_t n = hp_.n, S = pw.polys, R = result_polys_;
+    const size_t E = hlevel(0).L + hlevel(0).nB + 1;
+    const uint32_t l = psu_.query_params.ps_low_degree, h = l + 1;
+    auto even = [](uint32_t v) { return (v + 1) & ~1u; };
+    auto sz = [&](uint32_t p) { return nks_size_[p]; };
+    std::vector<uint32_t> rs(count);
+    for (int i = 0; i < count; i++) {
+        rs[i] = result_size_for(bundles[i]->degree);
+        if (rs[i] > CT_SIZE_MAX)                             // Evaluator::multiply inside eval_patstock would throw
+            throw std::invalid_argument("invalid size: a Paterson-Stockmeyer product exceeds SEAL's largest ciphertext");
+    }
+    WITH_ARENA({
+        u64 *res = out_rows ? nullptr : (out_on_device ? out : ws((size_t)count * R * n));
+        auto res_ptr = [&](int i) { return out_rows ? out_rows[i] : res + (size_t)i * R * n; };
+        u64 *mask_d = nullptr;
+        if (!masks_on_device) {
+            mask_d = ws((size_t)count * n);
+            for (int i = 0; i < count; i++) H2D(mask_d + (size_t)i * n, masks[i], n);
+        }
+        auto low_ptr = [&](int b) { return pw.low.u() + (size_t)b * pw.n_low * S * n; };            // power 1 of bundle-index slot b
+        auto hext_ptr = [&](uint32_t i, int b) { return pw.hext.u() + ((size_t)b * pw.n_high + (i - 1)) * S * E * n; };
+        const size_t base_mark = arena_off_;
+        for (int x = 0; x < count; x++) {
+            arena_off_ = base_mark;                                                                 // stream order makes the reuse safe
+            const Bundle &b = *bundles[x];
+            const int bs = pw.slot_of(b.bundle_idx);
+            const uint32_t RS = even(rs[x]);
+            u64 *result = ws((size_t)RS * n);                                                       // coefficient form
+            std::vector<MacStream> ms;
+            // every stream: pairs of polynomials (2k, 2k+1) of the powers, terms 1..cnt of a run of NTT-form plaintexts
+            auto low_streams = [&](const u64 *pt, u32 cnt, uint32_t polys, u64 *acc) {
+                for (uint32_t pp = 0; pp < even(polys) / 2; pp++)
+                    ms.push_back(MacStream{ pt, low_ptr(bs) + (size_t)pp * 2 * n, acc + (size_t)pp * 2 * n, cnt, (u32)n, (u32)(S * n), (u32)n, (u32)n, 0, 1 });
+            };
+            auto size_upto = [&](uint32_t cnt) { uint32_t v = 2; for (uint32_t j = 1; j <= cnt; j++) v = std::max(v, sz(j)); return v; };
+            if (!b.use_ps) {                                                                        // bin_bundle.cpp:106-174
+                if (b.degree) {
+                    low_streams(b.ntt.u(), b.degree, rs[x], result);                                // :140-149
+                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
+                    d_ntt_ct(result, RS, 0, true);                                                  // :154
+                } else {
+                    HIP_CHECK(hipMemsetAsync(result, 0, (size_t)RS * n * sizeof(u64), st_));
+                }
+            } else {                                                                                // bin_bundle.cpp:192-360
+                const uint32_t H = b.H, nin = H - (b.r == 0 ? 1 : 0);
+                // one multiply-accumulate launch and one inverse transform for: the inner polynomials (:258-264,287-293), the
+                // i = 0 block sum_j C^j a_j (:314-324; the sum of the terms' inverse transforms is the transform of the sum,
+                // and there is no modulus switch to round per term), and sum_i C^{ih} a_{ih} (:328-337, exact)
+                std::vector<uint32_t> s_in(nin + 1, 2);
+                std::vector<u64 *> inner(nin + 1, nullptr);
+                size_t words = 0;
+                for (uint32_t i = 1; i <= nin; i++) { s_in[i] = size_upto(i < H ? l : b.r); words += (size_t)even(s_in[i]) * n; }
+                const uint32_t s_low = size_upto(l);
+                uint32_t s_high = 2;
+                for (uint32_t i = 1; i <= H; i++) s_high = std::max(s_high, sz(i * h));
+                u64 *blk = ws(words + (size_t)(even(s_low) + even(s_high)) * n);
+                u64 *cur = blk;
+                for (uint32_t i = 1; i <= nin; i++) {
+                    inner[i] = cur;
+                    low_streams(b.ntt.u() + (size_t)i * l * n, i < H ? l : b.r, s_in[i], cur);
+                    cur += (size_t)even(s_in[i]) * n;
+                }
+                u64 *lowsum = cur, *cf = cur + (size_t)even(s_low) * n;
+                low_streams(b.ntt.u(), l, s_low, lowsum);
+                for (uint32_t pp = 0; pp < even(s_high) / 2; pp++)
+                    ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs) + (size_t)pp * 2 * E * n, cf + (size_t)pp * 2 * n, H, (u32)n,
+                                            (u32)(S * E * n), (u32)(E * n), (u32)n, 0, 1 });
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
+                d_ntt_ct(blk, (words / n) + even(s_low) + even(s_high), 0, true);                   // :268,297,321 and the product's transform
+                HIP_CHECK(hipMemsetAsync(result, 0, (size_t)RS * n * sizeof(u64), st_));            // :238-240
+                for (uint32_t i = 1; i <= nin; i++) {                                               // :272-273,301-303
+                    const size_t mark = arena_off_;
+                    const int sa = (int)s_in[i], sb = (int)sz(i * h), so = sa + sb - 1;
+                    u64 *iext = ws((size_t)sa * E * n), *prod = ws((size_t)so * n);
+                    { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(0), hlevel(0).L, hlevel(0).nB, inner[i], n, 1, iext, n, sa, st_); }
+                    d_ntt(iext, (size_t)sa * E, map_ext(0), (int)E, false);
+                    d_multiply_sized(iext, sa, hext_ptr(i, bs), sb, prod, 0);
+                    { PROF(P_OTHER, 0); launch_add(dlevel(0), result, prod, so, n, 1, st_); }
+                    arena_off_ = mark;
+                }
+                { PROF(P_OTHER, 0); launch_add(dlevel(0), result, lowsum, (int)s_low, n, 1, st_); }
+                { PROF(P_OTHER, 0); launch_add(dlevel(0), result, cf, (int)s_high, n, 1, st_); }
+            }
+            // :159-171 / :345-357: add_plain(a_0), add_plain(mask) on the first polynomial; one level, so no modulus switch;
+            // clear the irrelevant bits of every polynomial.  Row layout: rs[x] polynomials, zeros up to R.
+            u64 *row = res_ptr(x);
+            const u64 *mk = masks_on_device ? masks[x] : mask_d + (size_t)x * n;
+            std::vector<EpiJob> ej{ EpiJob{ result, nullptr, nullptr, b.a0.u(), mk, row } };
+            { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), 0, upload_jobs(ej), n, hp_.irrelevant_bit_count, n, 1, st_); }
+            if (rs[x] > 2) {
+                D2D(row + 2 * n, result + 2 * n, (size_t)(rs[x] - 2) * n);
+                { PROF(P_OTHER, 0); launch_clear_bits(row + 2 * n, (size_t)(rs[x] - 2) * n, hp_.irrelevant_bit_count, st_); }
+            }
+            if (R > rs[x]) HIP_CHECK(hipMemsetAsync(row + (size_t)rs[x] * n, 0, (R - rs[x]) * n * sizeof(u64), st_));
+        }
+        if (!out_rows && !out_on_device) D2H(out, res, (size_t)count * R * n);
+        sync();
+        inflight_count_ = 0;
+    });
 }
 
 } // namespace apsu_he

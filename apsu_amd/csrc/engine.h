@@ -68,6 +68,9 @@ struct Powers {
     std::vector<uint32_t> bundle_indices;
     int low_level = 0, high_level = 0;
     uint32_t n_low = 0, n_high = 0;              // PS: l low powers, H high powers; no PS: all in `low`
+    uint32_t polys = 2;                          // polynomials stored per power (the "2" of the layouts below).  More than 2 only without
+                                                 // key switching: products are never relinearised, every power is stored zero-padded to
+                                                 // the longest one's size rounded up to even (Engine::power_size gives the real sizes)
     DevBuf low;                                  // [idx][power-1][2][Ll][n]   NTT form
     DevBuf high;                                 // [idx][i-1][2][Lh][n]       coefficient form (power i*h)
     DevBuf hext;                                 // [idx][i-1][2][Eh][n]       extended + NTT form of the same
@@ -102,6 +105,8 @@ public:
     void add(u64 *acc, const u64 *x, int polys, int chain_idx);
     void add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx);
     void multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx);
+    // Evaluator::multiply for operands of any size (nothing relinearised in between): out has size_a + size_b - 1 polynomials
+    void multiply_sized(const u64 *a, int size_a, const u64 *b, int size_b, u64 *out, int chain_idx);
     void relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx);
     void mod_switch_to_next(u64 *ct, int polys, int chain_idx);
     void clear_irrelevant_bits(u64 *ct, int polys);
@@ -143,6 +148,16 @@ public:
     // out + i * 2n -- rows of another device's buffer (peer access) or of page-locked host memory are written in place.
     void eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
                       const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device, u64 *const *out_rows = nullptr);
+
+    // Parameter sets with one coefficient prime have no key switching: the reference then never relinearises
+    // (receiver_osn.cpp:416,430-432 ; bin_bundle.cpp:308-310), so powers and results have more than two polynomials.
+    // power_size: polynomials of a target power after ComputePowers; result_size: of one BinBundle's result;
+    // result_polys: the largest result_size over all degrees = polynomials per row of eval_bundles' output (2 with key switching).
+    static constexpr uint32_t CT_SIZE_MAX = 16;          // SEAL_CIPHERTEXT_SIZE_MAX: Ciphertext::resize throws beyond it
+    uint32_t power_size(uint32_t power) const;
+    uint32_t result_size(const Bundle &b) const;
+    uint32_t result_size_for(uint32_t degree) const;
+    uint32_t result_polys() const { return result_polys_; }
 
     // introspection for tests
     size_t workspace_bytes() const { return arena_.bytes(); }
@@ -203,6 +218,18 @@ private:
     // the mod-down; returns false when the level has no unrolled extension and the caller must run launch_behz_ext itself)
     bool d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out = nullptr, int n_ext = 0);
     void check_level(int chain_idx) const;
+    // BEHZ steps 4-8 for operands given as ext-NTT polynomials [size][E][n]; out: [sa + sb - 1][L][n], coefficient form
+    void d_multiply_sized(const u64 *ea, int sa, const u64 *eb, int sb, u64 *out, int chain_idx);
+    // ComputePowers / eval / eval_patstock without key switching and with products (ciphertexts of any size): plain
+    // compositions of the per-polynomial kernels, not tuned -- no shipped parameter set reaches them
+    std::unique_ptr<Powers> compute_powers_nks(const uint32_t *bundle_indices, int nb, const u64 *const *src, bool on_device);
+    void eval_bundles_nks(const Bundle *const *bundles, int count, const Powers &pw, const u64 *const *masks, bool masks_on_device,
+                          u64 *out, bool out_on_device, u64 *const *out_rows);
+    bool nks_ = false;                // no key switching AND the PowersDag has products
+    bool nks_oversize_ = false;       // some product exceeds CT_SIZE_MAX polynomials: ComputePowers throws like SEAL's multiply
+    std::vector<uint32_t> nks_size_;  // polynomials per target power (index = power; 0 = no target)
+    uint32_t nks_S_ = 2;              // polynomials stored per power (largest size, rounded up to even)
+    uint32_t result_polys_ = 2;
 
     HeParams hp_;
     PSUParams psu_;

@@ -1011,6 +1011,36 @@ void launch_tensor(const DevLevel *lv, const TensorJob *jobs, size_t n, int batc
     KERNEL_CHECK();
 }
 
+// Step (4) for ciphertexts of any size (parameter sets without key switching never relinearise, receiver_osn.cpp:430-432, so
+// operands keep growing): d_I = sum_{i + j = I} a_i b_j, limb-wise, every product reduced before the modular add
+// (Evaluator::bfv_multiply's behz_ciphertext_product).  Not a hot path: no shipped parameter set reaches it.
+__global__ __launch_bounds__(EW_T) void k_tensor_conv(const DevLevel *__restrict__ lv, const TensorConvJob *__restrict__ jobs, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (k >= n) return;
+    const TensorConvJob job = jobs[blockIdx.y];
+    const int E = lv->E;
+    const size_t ps = (size_t)E * n;
+    const int so = job.sa + job.sb - 1;
+    for (int e = 0; e < E; e++) {
+        const Mod m = lv->ext[e];
+        const size_t o = e * n + k;
+        for (int I = 0; I < so; I++) {
+            const int i0 = I - (job.sb - 1) > 0 ? I - (job.sb - 1) : 0, i1 = I < job.sa - 1 ? I : job.sa - 1;
+            u64 acc = 0;
+            for (int i = i0; i <= i1; i++) acc = addmod(acc, mulmod(job.a[i * ps + o], job.b[(I - i) * ps + o], m), m.q);
+            job.d[I * ps + o] = acc;
+        }
+    }
+}
+
+void launch_tensor_conv(const DevLevel *lv, const TensorConvJob *jobs, size_t n, int njobs, hipStream_t st)
+{
+    if (!njobs) return;
+    hipLaunchKernelGGL(k_tensor_conv, ew_grid(n, njobs), dim3(EW_T), 0, st, lv, jobs, n);
+    KERNEL_CHECK();
+}
+
 // Step (4) for a SUM of products (eval_patstock's sum over i): the q limbs of every term are kept (their canonical
 // coefficient-form residues are needed per term by the finish), the Bsk limbs are summed here in the NTT domain.
 // e0 = L: only the Bsk sums (the per-term q limbs are formed by k_intt_tensor on load).

@@ -294,7 +294,7 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
     const bool src_dev = flags & IO_SRC_ON_DEVICE, mask_dev = flags & IO_MASKS_ON_DEVICE;
     if ((src_dev || mask_dev) && (in_slot < 0 || in_slot >= (int)devs_.size())) throw std::invalid_argument("input device slot out of range");
     const auto t_begin = std::chrono::steady_clock::now();
-    const size_t n = hp_.n, row = 2 * n;
+    const size_t n = hp_.n, row = (size_t)devs_[0]->eng->result_polys() * n;     // 2n with key switching (Engine::result_polys)
     const uint32_t ns = devs_[0]->eng->dag().source_count();
     const size_t src_words = (size_t)2 * (hp_.first_chain_idx + 1) * n;
     const int out_device = out_slot >= 0 ? devs_[out_slot]->device : -1;

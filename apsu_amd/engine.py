@@ -32,7 +32,7 @@ class _Info(C.Structure):
         ("ps_low_degree", C.c_uint32), ("max_items_per_bin", C.c_uint32),
         ("bundle_idx_count", C.c_uint32), ("items_per_bundle", C.c_uint32),
         ("source_power_count", C.c_uint32), ("target_power_count", C.c_uint32),
-        ("powers_dag_depth", C.c_uint32), ("reserved", C.c_uint32),
+        ("powers_dag_depth", C.c_uint32), ("result_polys", C.c_uint32),
     ]
 
 
@@ -141,14 +141,15 @@ class Powers:
         self._ctx, self.h, self.bundle_indices = ctx, handle, list(bundle_indices)
 
     def download(self, bundle_idx, power):
-        """-> (ct [2][L][n], chain_idx, is_ntt) in the form receiver_osn.cpp:459-487 leaves it."""
+        """-> (ct [size][L][n], chain_idx, is_ntt) in the form receiver_osn.cpp:459-487 leaves it (size 2 with key switching)."""
         ctx = self._ctx
-        buf = np.empty(2 * (ctx.first_chain_idx + 1) * ctx.n, dtype=np.uint64)
+        sz = ctx.power_size(power)
+        buf = np.empty(sz * (ctx.first_chain_idx + 1) * ctx.n, dtype=np.uint64)
         ci, ntt = C.c_int(), C.c_int()
         _check(load_library().apsu_he_powers_download(ctx.h, self.h, bundle_idx, power, _p(buf), C.c_size_t(buf.size),
                                                      C.byref(ci), C.byref(ntt)))
         L = ci.value + 1
-        return buf[: 2 * L * ctx.n].reshape(2, L, ctx.n).copy(), ci.value, bool(ntt.value)
+        return buf[: sz * L * ctx.n].reshape(sz, L, ctx.n).copy(), ci.value, bool(ntt.value)
 
     def __del__(self):
         try:
@@ -186,6 +187,7 @@ class HeContext:
         self.bundle_idx_count = int(info.bundle_idx_count)
         self.source_power_count = int(info.source_power_count)
         self.irrelevant_bit_count = int(info.irrelevant_bit_count)
+        self.result_polys = int(info.result_polys) or 2
 
     def close(self):
         if getattr(self, "h", None):
@@ -295,6 +297,24 @@ class HeContext:
         out = np.empty((3, chain_idx + 1, self.n), dtype=np.uint64)
         _check(load_library().apsu_he_square(self.h, _p(a), _p(out), chain_idx))
         return out
+
+    def multiply_sized(self, a, b, chain_idx):
+        """Evaluator::multiply of ciphertexts that were never relinearised: size_a + size_b - 1 polynomials"""
+        out = np.empty((a.shape[0] + b.shape[0] - 1, chain_idx + 1, self.n), dtype=np.uint64)
+        _check(load_library().apsu_he_multiply_sized(self.h, _p(a), a.shape[0], _p(b), b.shape[0], _p(out), chain_idx))
+        return out
+
+    def power_size(self, power):
+        """polynomials of a target power after ComputePowers (2 with key switching)"""
+        v = C.c_uint32()
+        _check(load_library().apsu_he_power_size(self.h, C.c_uint32(power), C.byref(v)))
+        return v.value
+
+    def result_size(self, bundle):
+        """polynomials of one BinBundle's result (2 with key switching)"""
+        v = C.c_uint32()
+        _check(load_library().apsu_he_bundle_result_size(self.h, bundle.h, C.byref(v)))
+        return v.value
 
     def relinearize(self, ct3, rk, chain_idx):
         work = np.ascontiguousarray(ct3.copy())
@@ -441,11 +461,12 @@ class HeContext:
         return Powers(self, h, bundle_indices)
 
     def eval_bundles(self, bundles, powers, rk, masks, out=None, masks_on_device=False, out_on_device=False):
-        """ProcessBinBundleCache for every bundle: returns [count][2][1][n] (host) unless out is a device pointer."""
+        """ProcessBinBundleCache for every bundle: returns [count][2][1][n] (host) unless out is a device pointer.
+        Without key switching a row has result_polys polynomials, result i being its first result_size(bundle i) ones."""
         count = len(bundles)
         hs = (C.c_void_p * count)(*[b.h for b in bundles])
         if not out_on_device:
-            out = np.empty((count, 2, 1, self.n), dtype=np.uint64)
+            out = np.empty((count, self.result_polys, 1, self.n), dtype=np.uint64)
             outp = _p(out)
         else:
             outp = C.c_void_p(int(out))

@@ -56,7 +56,10 @@ typedef struct {
     uint64_t coeff_modulus[8];
     /* PSUParams-derived (zero when created without PSUParams) */
     uint32_t ps_low_degree, max_items_per_bin, bundle_idx_count, items_per_bundle;
-    uint32_t source_power_count, target_power_count, powers_dag_depth, reserved;
+    uint32_t source_power_count, target_power_count, powers_dag_depth;
+    uint32_t result_polys;           /* polynomials per row of apsu_he_eval_bundles' output: 2 with key switching; more only for
+                                      * parameter sets with ONE coefficient prime, whose products are never relinearised
+                                      * (receiver_osn.cpp:416,430-432 ; bin_bundle.cpp:238-240,308-310)   (ABI 4; was `reserved`) */
 } apsu_he_info;
 
 typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   /* powers.h:53-77 */
@@ -66,7 +69,9 @@ const char *apsu_he_last_error(void);
  * apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb.
  * 3: apsu_he_set_eval_pipeline removed (measured-negative scheduling experiment, profiles/r03_eval_pipeline.txt); added
  * apsu_he_debug_counters, apsu_he_phase_* / apsu_he_multi_phase_*, apsu_he_eval_all_ex + apsu_he_host_alloc, apsu_he_partition_bundles_ex,
- * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768. */
+ * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768.
+ * 4 (additive): ciphertexts of more than two polynomials for parameter sets without key switching -- apsu_he_multiply_sized,
+ * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -102,6 +107,10 @@ int apsu_he_add_plain(apsu_he_ctx *ctx, uint64_t *ct, const uint64_t *pt_mod_t, 
 int apsu_he_multiply(apsu_he_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out3, int chain_idx);
 /* Evaluator::square                                        receiver_osn.cpp:422 */
 int apsu_he_square(apsu_he_ctx *ctx, const uint64_t *a, uint64_t *out3, int chain_idx);
+/* Evaluator::multiply for operands that were never relinearised (one coefficient prime: receiver_osn.cpp:424 with :430-432
+ * skipped ; bin_bundle.cpp:272,301): out has size_a + size_b - 1 polynomials; APSU_HE_INVALID_ARGUMENT beyond SEAL's largest
+ * ciphertext (16 polynomials), where SEAL throws */
+int apsu_he_multiply_sized(apsu_he_ctx *ctx, const uint64_t *a, int size_a, const uint64_t *b, int size_b, uint64_t *out, int chain_idx);
 /* Evaluator::relinearize_inplace (size 3 -> size 2, in place in the first two polys)
  *                                                          receiver_osn.cpp:431 ; bin_bundle.cpp:309 */
 int apsu_he_relinearize(apsu_he_ctx *ctx, uint64_t *ct3, const apsu_he_relin *rk, int chain_idx);
@@ -171,6 +180,11 @@ int apsu_he_decrypt_decode(apsu_he_ctx *ctx, const uint64_t *sk_ntt, const uint6
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);
 int apsu_he_bundle_download(apsu_he_ctx *ctx, const apsu_he_bundle *b, uint32_t degree, uint64_t *out, size_t capacity_words,
                             size_t *words, int *kind);
+/* Polynomials of a target power after ComputePowers and of one BinBundle's result: 2 with key switching.  Without it
+ * (one coefficient prime) the reference never relinearises: a product has size(parent1) + size(parent2) - 1 polynomials,
+ * eval's result the size of its longest power, eval_patstock's the size of its longest product (at least 3). */
+int apsu_he_power_size(const apsu_he_ctx *ctx, uint32_t power, uint32_t *polys);
+int apsu_he_bundle_result_size(const apsu_he_ctx *ctx, const apsu_he_bundle *b, uint32_t *polys);
 int apsu_he_bundle_free(apsu_he_bundle *b);
 int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes);
 /* Receiver::ComputePowers for n_bundle_idx bundle indices at once (receiver_osn.cpp:320-328,395-488).
@@ -181,13 +195,15 @@ int apsu_he_compute_powers(apsu_he_ctx *ctx, const uint32_t *bundle_indices, int
                            const uint64_t *const *src_cts, int src_on_device, const apsu_he_relin *rk,
                            apsu_he_powers **out);
 int apsu_he_powers_free(apsu_he_powers *p);
-/* test hook: copy one computed power back (form/level per receiver_osn.cpp:459-487); words = 2*(level+1)*n */
+/* test hook: copy one computed power back (form/level per receiver_osn.cpp:459-487); words = apsu_he_power_size * (level+1) * n */
 int apsu_he_powers_download(apsu_he_ctx *ctx, const apsu_he_powers *p, uint32_t bundle_idx, uint32_t power,
                             uint64_t *out, size_t capacity_words, int *chain_idx, int *is_ntt);
 /* Receiver::ProcessBinBundleCache -> BatchedPlaintextPolyn::eval / eval_patstock for `count`
  * BinBundles (receiver_osn.cpp:490-540 ; bin_bundle.cpp:106-174,192-360).  masks[i] = random_plain
  * (n coefficients mod t, receiver_osn.cpp:217-284).  out_cts: count * 2 * n words, result i at
- * out_cts + i*2*n, last level, irrelevant bits cleared.  *_on_device: pointers are device pointers. */
+ * out_cts + i*2*n, last level, irrelevant bits cleared.  *_on_device: pointers are device pointers.
+ * Parameter sets without key switching: rows of apsu_he_info.result_polys * n words, result i = its first
+ * apsu_he_bundle_result_size polynomials, zeros behind them. */
 int apsu_he_eval_bundles(apsu_he_ctx *ctx, const apsu_he_bundle *const *bundles, int count, const apsu_he_powers *powers,
                          const apsu_he_relin *rk, const uint64_t *const *masks, int masks_on_device, uint64_t *out_cts,
                          int out_on_device);

@@ -393,30 +393,6 @@ def test_powers_outlive_their_context():
     G2.close()
 
 
-def test_single_prime_with_products_is_refused_not_truncated():
-    """K = 1 (no key switching): the reference would carry size-3 ciphertexts (receiver_osn.cpp:427-432,
-    bin_bundle.cpp:238-240,308-310); this interface returns size-2 results, so those combinations raise"""
-    js = common.toy_json(n=64, coeff_bits=(60,), plain_bits=17, ps_low=2, max_items=7, query_powers=(1, 2, 3, 6))
-    S = common.make_scenario(js, {0: [7]})
-    G = apsu_amd.HeContext(js)
-    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], None)       # depth 0: every target is a source
-    b = S.bundles[0]
-    gb = G.upload_bundle(0, 0, b["coeffs"], b["flags"])
-    with pytest.raises(apsu_amd.ApsuHeError):                                  # eval_patstock would leave size 3
-        G.eval_bundles([gb], pw, None, [b["mask"]])
-    with pytest.raises(RuntimeError):
-        common.oracle_eval(S, common.oracle_powers(S), b)
-    G.close()
-    js2 = common.toy_json(n=64, coeff_bits=(60,), plain_bits=17, ps_low=0, max_items=4, query_powers=(1, 2))
-    S2 = common.make_scenario(js2, {0: []})
-    G2 = apsu_amd.HeContext(js2)
-    with pytest.raises(apsu_amd.ApsuHeError):                                  # products without relinearization
-        G2.compute_powers([0], [[S2.src[0][e] for e in S2.sources]], None)
-    with pytest.raises(RuntimeError):
-        common.oracle_powers(S2)
-    G2.close()
-
-
 def test_summed_finish_guard_uses_the_widest_limb():
     """30-bit first prime next to 60-bit ones with 16 products per BinBundle: 16 * q_1 >= 2^64, so the summed-Bsk finish
     (integer sums of per-term residues of EVERY limb) must not be taken; compared with the oracle's per-term order"""
