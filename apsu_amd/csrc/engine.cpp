@@ -1769,7 +1769,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     // Without key switching the reference leaves eval_patstock's result unrelinearised (bin_bundle.cpp:238-240,308-310) and
     // the powers themselves may be longer than two polynomials: a path of its own
     if (pw.polys != (nks_ ? nks_S_ : 2u)) throw std::invalid_argument("ciphertext powers do not belong to this context");
-    if (nks_ || (any_ps && !hp_.using_keyswitching)) {
+    if (nks_ || result_polys_ > 2) {                        // every BinBundle of such a set: the rows are result_polys_ polynomials apart
         eval_bundles_nks(bundles, count, pw, masks, masks_on_device, out, out_on_device, out_rows);
         if (phase_on_ && ev_span.a) {
             ev_span.b = phase_event(st_);

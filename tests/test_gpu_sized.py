@@ -129,3 +129,67 @@ def test_products_beyond_seals_largest_ciphertext_raise():
     with pytest.raises(ValueError, match="invalid size"):            # APSU_HE_INVALID_ARGUMENT = std::invalid_argument, as from SEAL
         G.compute_powers([0], [[S.src[0][e] for e in S.sources]], None)
     G.close()
+
+
+def test_patstock_product_beyond_the_limit_raises_for_that_bundle_only():
+    # powers up to 10 polynomials are fine; a full BinBundle multiplies an inner polynomial of 9 by C^9 of 10 -> 18 > 16
+    js = common.toy_json(n=64, coeff_bits=(60,), plain_bits=17, ps_low=8, max_items=17, query_powers=(1,))
+    S = common.make_scenario(js, {0: [17, 9, 12]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], None)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    with pytest.raises(ValueError):
+        common.oracle_eval(S, opw, S.bundles[0])
+    with pytest.raises(ValueError, match="invalid size"):
+        G.eval_bundles(gb[:1], pw, None, [S.bundles[0]["mask"]])
+    out = G.eval_bundles(gb[1:], pw, None, [b["mask"] for b in S.bundles[1:]])
+    for i, b in enumerate(S.bundles[1:]):
+        exp = common.oracle_eval(S, opw, b)
+        assert G.result_size(gb[1 + i]) == exp.shape[0] and (out[i][:exp.shape[0]] == exp).all() and not out[i][exp.shape[0]:].any()
+    G.close()
+
+
+def test_framed_query_without_relin_keys_returns_longer_ciphertexts():
+    """apsu_he_run_query_request for a single-prime set: no RelinKeys in the QueryRequest (sender_osn.cpp:223-227 only creates them
+    when key switching exists), ResultPackages whose SEAL ciphertexts carry every polynomial of the unrelinearised result"""
+    from apsu_amd import seal, wire
+    js = common.toy_json(n=256, coeff_bits=(58,), plain_bits=13, ps_low=2, max_items=8, query_powers=(1, 3), felts=7)
+    S = common.make_scenario(js, {0: [8, 4], 1: [7]})
+    opw = common.oracle_powers(S)
+    sc = seal.SealContext(js)
+    parts = [(e, [sc.ct_save(0, False, S.src[b][e], compr=seal.COMPR_ZLIB) for b in range(S.p["bundle_idx_count"])]) for e in S.sources]
+    msg = wire.build_query_request(seal.COMPR_ZLIB, None, parts)
+    G = apsu_amd.HeContext(js)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    pkgs = seal.run_query_request(G, sc, msg, gb, [b["mask"] for b in S.bundles], compr=seal.COMPR_ZLIB)
+    for i, b in enumerate(S.bundles):
+        exp = common.oracle_eval(S, opw, b)
+        back = wire.parse_result_package(pkgs[i])
+        got = sc.ct_load(back["psu_result"])
+        assert back["bundle_idx"] == b["bundle_idx"] and got["chain_idx"] == 0 and not got["is_ntt_form"]
+        assert got["data"].shape == exp.shape and (got["data"] == exp).all()
+    G.close()
+    sc.close()
+
+
+def test_multi_device_handle_carries_longer_rows():
+    """apsu_he_eval_all for a single-prime set: rows of result_polys polynomials (devices {0, 0} rehearse the two-device path)"""
+    js = common.toy_json(n=256, coeff_bits=(58,), plain_bits=13, ps_low=2, max_items=8, query_powers=(1, 3), felts=7)
+    S = common.make_scenario(js, {0: [8, 4, 2], 1: [7, 8]})
+    G = apsu_amd.HeContext(js)
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], None)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    want = G.eval_bundles(gb, pw, None, [b["mask"] for b in S.bundles])
+    flat = [S.src[b][e] for b in range(S.p["bundle_idx_count"]) for e in S.sources]
+    units = [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+    for devs in ([0], [0, 0]):
+        M = apsu_amd.MultiContext(js, devs)
+        slots = apsu_amd.partition_bundles(units, S.p["bundle_idx_count"], len(devs))
+        for i, b in enumerate(S.bundles):
+            M.upload_bundle(slots[i], b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"])
+        out = np.zeros((len(S.bundles), G.result_polys, 1, G.n), dtype=np.uint64)
+        got = M.eval_all(flat, [b["mask"] for b in S.bundles], G.n, out=out)
+        assert (got == want).all(), devs
+        M.close()
+    G.close()
