@@ -205,6 +205,13 @@ int apsu_he_db_build_bundle(apsu_he_ctx *c, uint32_t bundle_idx, uint32_t cache_
         *out = b;
     });
 }
+int apsu_he_algebraize_items(apsu_he_ctx *c, const uint8_t *items, size_t count, int items_on_device, uint64_t *felts, int felts_on_device)
+{
+    return guarded([&] {
+        REQUIRE(c && (!count || (items && felts)), "null argument");
+        c->eng->algebraize_items(items, count, items_on_device != 0, felts, felts_on_device != 0);
+    });
+}
 int apsu_he_bundle_download(apsu_he_ctx *c, const apsu_he_bundle *b, uint32_t degree, uint64_t *out, size_t capacity_words,
                             size_t *words, int *kind)
 {

@@ -145,6 +145,8 @@ void launch_polyn_with_roots(const u64 *roots, const u32 *counts, u32 bins, u32 
                              hipStream_t st);
 void launch_scatter_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st);
 void launch_gather_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n, int batch, hipStream_t st);
+// N1: algebraize_item for `count` 16-byte items -> out[count][felts]; bpf = bits per field element, item_bits = felts * bpf
+void launch_algebraize(const unsigned char *items, size_t count, u32 felts, u32 bpf, u32 item_bits, u64 *out, hipStream_t st);
 // N4: item -> 128-bit block packing for PEQT, and the rounding step of the querier's decryption
 void launch_pack_blocks(const u64 *values, size_t n, u32 items, u32 felts, u32 len, u64 *out, int batch, hipStream_t st);
 void launch_decrypt_round(const u64 *ct, size_t ct_stride, const u64 *v, u64 q0, u64 t, u64 *out, size_t n, int batch, hipStream_t st);

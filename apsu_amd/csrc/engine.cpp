@@ -1480,6 +1480,27 @@ std::unique_ptr<Bundle> Engine::build_bundle(uint32_t bundle_idx, uint32_t cache
 }
 
 // ---- N2: BinBundle image ------------------------------------------------------------------------------------
+void Engine::algebraize_items(const unsigned char *items, size_t count, bool items_on_device, u64 *out, bool out_on_device)
+{
+    Enter g(this);
+    if (!has_psu_) throw std::logic_error("context was created without PSUParams");
+    if (!count) return;
+    TIER1_SLOTS();
+    const u32 felts = psu_.item_params.felts_per_item, bpf = psu_.item_bit_count_per_felt, bits = psu_.item_bit_count;
+    WITH_ARENA({
+        const unsigned char *src = items;
+        if (!items_on_device) {
+            u64 *d = ws((count * 16 + 7) / 8);
+            HIP_CHECK(hipMemcpyAsync(d, items, count * 16, hipMemcpyHostToDevice, st_));
+            src = reinterpret_cast<const unsigned char *>(d);
+        }
+        u64 *dst = out_on_device ? out : ws(count * felts);
+        { PROF(P_OTHER, 0); launch_algebraize(src, count, felts, bpf, bits, dst, st_); }
+        if (!out_on_device) D2H(out, dst, count * felts);
+        sync();
+    });
+}
+
 namespace {
 struct ImageHeader {                     // little-endian, 256 bytes
     char magic[8];                       // "APSUHEB1"

@@ -122,6 +122,9 @@ public:
     // (bin_bundle.cpp:366-430,934-1026): roots[bin * stride + r], r < counts[bin], are the field elements of a bin.
     std::unique_ptr<Bundle> build_bundle(uint32_t bundle_idx, uint32_t cache_idx, const u64 *roots, const uint32_t *counts,
                                          uint32_t bins, uint32_t stride);
+    // N1, one step earlier: algebraize_item (common/apsu/util/db_encoding.cpp:209-256,360-366) for `count` hashed items of 16 bytes:
+    // out[count][felts_per_item], felt j = bits [j*b, (j+1)*b) of the item's first item_bit_count bits, b = bit_count(t) - 1
+    void algebraize_items(const unsigned char *items, size_t count, bool items_on_device, u64 *out, bool out_on_device);
     // N2: engine-native image of a BinBundle cache (raw limb arrays), replacing the flatbuffers +
     // SEAL-serialised blobs of ReceiverDB::save/Load (receiver_db.cpp:1182-1429) for the GPU-resident DB.
     size_t bundle_image_size(const Bundle &b) const;

@@ -736,6 +736,32 @@ void launch_gather_slots(const u64 *in, const u32 *slot_map, u64 *out, size_t n,
     KERNEL_CHECK();
 }
 
+// N1: algebraize_item (common/apsu/util/db_encoding.cpp:209-256,360-366): felt j of an item = bits [j*bpf, j*bpf + bpf) of its
+// first item_bits bits, the item read as a little-endian bit string (bit k = bit k%8 of byte k/8); one thread per felt
+__global__ __launch_bounds__(EW_T) void k_algebraize(const unsigned char *__restrict__ items, size_t count, u32 felts, u32 bpf, u32 item_bits,
+                                                     u64 *__restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (idx >= count * felts) return;
+    const size_t it = idx / felts;
+    const u32 j = (u32)(idx % felts);
+    const unsigned char *p = items + it * 16;
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { lo |= (u64)p[b] << (8 * b); hi |= (u64)p[8 + b] << (8 * b); }
+    const u32 off = j * bpf;
+    const u32 take = off >= item_bits ? 0 : (item_bits - off < bpf ? item_bits - off : bpf);
+    u64 v = off >= 64 ? hi >> (off - 64) : (off ? (lo >> off) | (hi << (64 - off)) : lo);
+    out[idx] = take ? v & (~(u64)0 >> (64 - take)) : 0;
+}
+
+void launch_algebraize(const unsigned char *items, size_t count, u32 felts, u32 bpf, u32 item_bits, u64 *out, hipStream_t st)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_algebraize, dim3((unsigned)((count * felts + EW_T - 1) / EW_T)), dim3(EW_T), 0, st, items, count, felts, bpf, item_bits, out);
+    KERNEL_CHECK();
+}
+
 // N4: vec_to_oc_block (receiver_osn.cpp:53-73): the felts of one item packed into a 128-bit block for the PEQT step,
 // out[item] = (lower, higher).  len = bit length of the plain modulus as the reference computes it; the odd-felt
 // branch shifts the upper half by len/2 - 1 (not len/2) exactly as the reference does; 64-bit shifts wrap.

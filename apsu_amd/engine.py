@@ -10,6 +10,7 @@ Errors: APSU_HE_INVALID_ARGUMENT -> ValueError (std::invalid_argument in the ref
 everything else -> ApsuHeError (std::runtime_error / std::logic_error).
 """
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -170,7 +171,9 @@ class HeContext:
                 with open(psu_params_json) as f:
                     psu_params_json = f.read()
             _check(L.apsu_he_create(psu_params_json.encode(), device, C.byref(h)))
+            self.felts_per_item = int(json.loads(psu_params_json)["item_params"]["felts_per_item"])
         else:
+            self.felts_per_item = 0
             q = np.array(coeff_modulus, dtype=np.uint64)
             _check(L.apsu_he_create_raw(C.c_uint64(n), _p(q), len(q), C.c_uint64(plain_modulus), device, C.byref(h)))
         self.h = h
@@ -360,6 +363,16 @@ class HeContext:
         deg = C.c_uint32()
         _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
         return Bundle(self, h, bundle_idx, cache_idx, deg.value)
+
+    def algebraize_items(self, items):
+        """util::algebraize_item for items [count][16] uint8 -> felts [count][felts_per_item] (db_encoding.cpp:209-256,360-366)"""
+        items = np.ascontiguousarray(items, dtype=np.uint8).reshape(-1, 16)
+        if not self.felts_per_item:
+            raise ApsuHeError("context was created without PSUParams")
+        out = np.empty((items.shape[0], self.felts_per_item), dtype=np.uint64)
+        _check(load_library().apsu_he_algebraize_items(self.h, items.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(items.shape[0]), 0,
+                                                       _p(out), 0))
+        return out
 
     def save_bundle(self, bundle):
         """-> bytes: engine-native image of the BinBundle cache (ReceiverDB::save counterpart)"""

@@ -71,7 +71,8 @@ const char *apsu_he_last_error(void);
  * apsu_he_debug_counters, apsu_he_phase_* / apsu_he_multi_phase_*, apsu_he_eval_all_ex + apsu_he_host_alloc, apsu_he_partition_bundles_ex,
  * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768.
  * 4 (additive): ciphertexts of more than two polynomials for parameter sets without key switching -- apsu_he_multiply_sized,
- * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before. */
+ * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before.
+ * apsu_he_algebraize_items (N1: item -> field elements). */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -175,6 +176,11 @@ int apsu_he_mask_generate_blake2xb(apsu_he_ctx *ctx, const uint64_t seed[8], uin
                                    uint64_t *values, uint64_t *blocks);
 int apsu_he_decrypt_decode(apsu_he_ctx *ctx, const uint64_t *sk_ntt, const uint64_t *cts, int cts_on_device, uint32_t count,
                            uint64_t *values, uint64_t *blocks);
+/* N1, one step earlier: util::algebraize_item (common/apsu/util/db_encoding.cpp:209-256,360-366; called at
+ * receiver_db.cpp:296-298 on every OPRF'd item) for `count` hashed items of 16 bytes each: felts[i * felts_per_item + j] =
+ * bits [j*b, (j+1)*b) of item i's first item_bit_count bits, read as a little-endian bit string, b = bit_count(plain_modulus) - 1.
+ * These are the roots apsu_he_db_build_bundle takes once the host has placed them into bins.  (ABI 4) */
+int apsu_he_algebraize_items(apsu_he_ctx *ctx, const uint8_t *items, size_t count, int items_on_device, uint64_t *felts, int felts_on_device);
 /* test hooks: degree of the batched polynomial; stored form of coefficient `degree`
  * (kind 0: raw mod t [n]; 1: NTT form [(plain_level+1)*n]; 2: pre-lifted + NTT at the high level [(high+1)*n]) */
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);

@@ -224,6 +224,16 @@ class RefContext:
             lib().ref_vec_to_oc_block(_p(values[i * felts_per_item:]), C.c_size_t(felts_per_item), C.c_uint64(self.t), _p(out[i]))
         return out
 
+    def algebraize_items(self, items, felts_per_item):
+        """items [count][16] uint8 -> [count][felts_per_item] (util::algebraize_item with item_bit_count = felts * (bits(t) - 1))"""
+        items = np.ascontiguousarray(items, dtype=np.uint8).reshape(-1, 16)
+        bits = felts_per_item * (int(self.t).bit_length() - 1)
+        out = np.zeros((items.shape[0], felts_per_item), dtype=np.uint64)
+        for i in range(items.shape[0]):
+            k = lib().ref_algebraize_item(items[i].ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_uint32(bits), C.c_uint64(self.t), _p(out[i]))
+            assert k == felts_per_item
+        return out
+
     def polyn_with_roots(self, roots):
         roots = np.ascontiguousarray(roots, dtype=np.uint64)
         out = np.empty(roots.size + 1, dtype=np.uint64)

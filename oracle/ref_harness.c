@@ -220,3 +220,30 @@ void ref_polyn_with_roots(const ref_ctx *c, const uint64_t *roots, size_t count,
         len++;
     }
 }
+
+/* common/apsu/util/db_encoding.cpp:209-256 (bits_to_field_elts) as called by algebraize_item (:360-366) on the first
+   item_bit_count bits of a 16-byte hashed item: every field element takes the next bits_per_felt = bit_count(mod) - 1 bits
+   (the last one what is left) of the bit string -- bit k of the string is bit k % 8 of byte k / 8 -- into the low bits of a
+   little-endian 8-byte value.  Restated bit by bit (the reference copies byte fragments, copy_with_bit_offset :150-207).
+   Returns the number of field elements, ceil(item_bit_count / bits_per_felt). */
+int ref_algebraize_item(const unsigned char item[16], uint32_t item_bit_count, uint64_t plain_modulus, uint64_t *felts)
+{
+    int mod_bits = 0;
+    for (uint64_t v = plain_modulus; v; v >>= 1) mod_bits++;
+    if (mod_bits < 2 || !item_bit_count || item_bit_count > 128) return -1;
+    uint32_t bits_per_felt = (uint32_t)mod_bits - 1;
+    uint32_t num_felts = (item_bit_count + bits_per_felt - 1) / bits_per_felt;
+    uint32_t left = item_bit_count, src = 0;
+    for (uint32_t j = 0; j < num_felts; j++) {
+        uint32_t copy = left < bits_per_felt ? left : bits_per_felt;
+        uint64_t f = 0;
+        for (uint32_t k = 0; k < copy; k++) {
+            uint32_t bit = src + k;
+            if ((item[bit >> 3] >> (bit & 7)) & 1) f |= (uint64_t)1 << k;
+        }
+        felts[j] = f;
+        src += bits_per_felt;
+        left -= copy;
+    }
+    return (int)num_felts;
+}

@@ -45,6 +45,8 @@ void ref_batch_decode(const ref_ctx *c, const uint64_t *pt_mod_t, uint64_t *valu
 /* receiver/apsu/receiver_osn.cpp:53-73 (vec_to_oc_block): the felts of one item packed into a 128-bit block;
  * out[0] = low 64 bits ("lower"), out[1] = high 64 bits ("higher") of oc::toBlock(higher, lower) */
 void ref_vec_to_oc_block(const uint64_t *in, size_t felts_per_item, uint64_t plain_modulus, uint64_t out[2]);
+/* common/apsu/util/db_encoding.cpp:209-256,360-366 (algebraize_item): felts of one 16-byte item; returns their count */
+int ref_algebraize_item(const unsigned char item[16], uint32_t item_bit_count, uint64_t plain_modulus, uint64_t *felts);
 /* common/apsu/util/interpolate.cpp:63-80 ; out has count+1 entries, degree ascending */
 void ref_polyn_with_roots(const ref_ctx *c, const uint64_t *roots, size_t count, uint64_t *out);
 

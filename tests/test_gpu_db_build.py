@@ -191,3 +191,21 @@ def test_build_spans_several_register_slots_and_the_serial_fallback():
         for d in sorted({0, 1, 2, 62, 63, 64, 65, 128, 199, 200, 4000, 6143, 6144, 8098, max(counts) - 1, max(counts)} & set(range(max(counts) + 1))):
             got, kind = G.bundle_coeff(gb, d)
             assert (got == coeffs[d]).all(), "max_items %d coefficient %d" % (max_items, d)
+
+
+@pytest.mark.parametrize("cfg", ["toy", "16M-4096", "1M-1024-com", "single-prime"])
+def test_algebraize_items_matches_oracle(cfg):
+    """N1, one step before the bins: util::algebraize_item (db_encoding.cpp:209-256,360-366) on the GPU"""
+    import json
+    js = {"toy": common.toy_json(), "single-prime": common.toy_json(n=64, coeff_bits=(60,), plain_bits=9, felts=10, ps_low=0, max_items=4)}.get(cfg) \
+        or common.param_json(cfg)
+    felts = json.loads(js)["item_params"]["felts_per_item"]
+    G = apsu_amd.HeContext(js)
+    C = ref.RefContext.from_params(ref.load_params(js))
+    rng = np.random.default_rng(11)
+    items = rng.integers(0, 256, (1000, 16), dtype=np.uint8)
+    items[0], items[1] = 0, 255
+    got = G.algebraize_items(items)
+    assert got.shape == (1000, felts) and (got == C.algebraize_items(items, felts)).all()
+    assert G.algebraize_items(items[:0]).shape == (0, felts)
+    G.close()

@@ -69,3 +69,25 @@ def test_sized_multiply_is_the_ring_product_and_size_limit():
     assert C.multiply_sized(wide, wide[:8], 0).shape[0] == 16
     with pytest.raises(ValueError):
         C.multiply_sized(wide, wide, 0)
+
+
+def test_algebraize_item_is_the_little_endian_bit_split():
+    """util::algebraize_item (db_encoding.cpp:209-256,360-366): field element j = bits [j*b, (j+1)*b) of the item as one
+    little-endian 128-bit integer, b = bits(t) - 1; joining them gives back the first item_bit_count bits"""
+    rng = np.random.default_rng(5)
+    for n, bits, plain_bits, felts in ((64, (40, 40, 36), 17, 5), (64, (40, 40, 36), 17, 8), (256, (58,), 13, 7), (64, (60,), 9, 10)):
+        C = ref.RefContext(n, list(bits), 0, plain_bits)
+        b = int(C.t).bit_length() - 1
+        items = rng.integers(0, 256, (50, 16), dtype=np.uint8)
+        items[0] = 0
+        items[1] = 255
+        got = C.algebraize_items(items, felts)
+        for it, row in zip(items, got):
+            v = int.from_bytes(bytes(it), "little")
+            assert [int(x) for x in row] == [(v >> (j * b)) & ((1 << b) - 1) for j in range(felts)]
+            assert sum(int(x) << (j * b) for j, x in enumerate(row)) == v & ((1 << (felts * b)) - 1)
+            assert all(int(x) < C.t for x in row)
+    # known answer: the item 0x0123456789abcdef fedcba9876543210 (bytes 10 32 54 ... ef cd ab ...), 16-bit field elements
+    C = ref.RefContext(64, [40, 40, 36], 0, 17)
+    item = np.frombuffer(bytes.fromhex("1032547698badcfeefcdab8967452301"), dtype=np.uint8)
+    assert [hex(int(x)) for x in C.algebraize_items(item, 5)[0]] == ["0x3210", "0x7654", "0xba98", "0xfedc", "0xcdef"]
