@@ -9,6 +9,7 @@ fallback: loading fails loudly if the library is missing, and context creation f
 from .engine import (  # noqa: F401
     ApsuHeError,
     Bundle,
+    DbFile,
     HeContext,
     MultiContext,
     Powers,

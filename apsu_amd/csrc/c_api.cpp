@@ -8,6 +8,7 @@
 #include <new>
 #include <string>
 
+#include "db_file.h"
 #include "engine.h"
 #include "multi.h"
 #include "wire.h"
@@ -338,6 +339,58 @@ int apsu_he_eval_bundles(apsu_he_ctx *c, const apsu_he_bundle *const *bundles, i
     });
 }
 
+// ---- N2: the whole database in one file (db_file.h)
+struct apsu_he_db_file { std::unique_ptr<DbFile> f; };
+int apsu_he_db_file_save(apsu_he_ctx *c, const char *path, const apsu_he_bundle *const *bundles, int count)
+{
+    return guarded([&] {
+        REQUIRE(c && path && bundles && count > 0, "null argument");
+        std::vector<Engine *> engs(count, c->eng.get());
+        std::vector<const Bundle *> bs(count);
+        for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); bs[i] = bundles[i]->b.get(); }
+        db_file_save(path, engs.data(), bs.data(), (size_t)count);
+    });
+}
+int apsu_he_db_file_open(const char *path, apsu_he_db_file **out)
+{
+    return guarded([&] {
+        REQUIRE(path && out, "null argument");
+        auto h = std::make_unique<apsu_he_db_file>();
+        h->f = std::make_unique<DbFile>(path);
+        *out = h.release();
+    });
+}
+int apsu_he_db_file_close(apsu_he_db_file *f) { return guarded([&] { delete f; }); }
+int apsu_he_db_file_count(const apsu_he_db_file *f, int *count, uint64_t *file_bytes)
+{
+    return guarded([&] {
+        REQUIRE(f && count, "null argument");
+        *count = (int)f->f->count();
+        if (file_bytes) *file_bytes = f->f->file_bytes();
+    });
+}
+int apsu_he_db_file_entry(const apsu_he_db_file *f, int i, uint32_t *bundle_idx, uint32_t *cache_idx, uint32_t *degree, uint64_t *image_bytes)
+{
+    return guarded([&] {
+        REQUIRE(f && i >= 0 && (size_t)i < f->f->count(), "entry out of range");
+        const DbFileEntry &e = f->f->entry((size_t)i);
+        if (bundle_idx) *bundle_idx = e.bundle_idx;
+        if (cache_idx) *cache_idx = e.cache_idx;
+        if (degree) *degree = e.degree;
+        if (image_bytes) *image_bytes = e.bytes;
+    });
+}
+int apsu_he_db_file_load(apsu_he_ctx *c, const apsu_he_db_file *f, int i, apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && f && out && i >= 0 && (size_t)i < f->f->count(), "bad argument");
+        f->f->check_parameters(*c->eng);
+        auto b = new apsu_he_bundle;
+        try { b->b = f->f->load(*c->eng, (size_t)i); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
+
 // ---- several GPUs behind one handle (multi.h)
 int apsu_he_partition_bundles(uint32_t bundle_idx_count, int n_devices, const uint32_t *bundle_idx, const uint32_t *cache_idx,
                               const uint32_t *degree, int count, int *device_slot)
@@ -408,6 +461,16 @@ int apsu_he_multi_db_random_bundle(apsu_he_multi *m, int device_slot, uint32_t b
         *bundle_id = m->m->random_bundle(device_slot, bundle_idx, cache_idx, degree, seed);
     });
 }
+int apsu_he_multi_db_load_file(apsu_he_multi *m, const apsu_he_db_file *f, int *n_loaded)
+{
+    return guarded([&] {
+        REQUIRE(m && f, "null argument");
+        const int k = m->m->load_file(*f->f);
+        if (n_loaded) *n_loaded = k;
+    });
+}
+int apsu_he_multi_db_save_file(apsu_he_multi *m, const char *path)
+{ return guarded([&] { REQUIRE(m && path, "null argument"); m->m->save_file(path); }); }
 int apsu_he_multi_db_clear(apsu_he_multi *m) { return guarded([&] { REQUIRE(m, "null argument"); m->m->clear_bundles(); }); }
 int apsu_he_eval_all(apsu_he_multi *m, const uint64_t *const *src_cts, const uint64_t *const *masks, uint64_t *out_cts, int out_device_slot)
 {

@@ -139,6 +139,44 @@ int MultiEngine::random_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx
     return id;
 }
 
+int MultiEngine::load_file(const DbFile &f)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    f.check_parameters(*devs_[0]->eng);
+    std::vector<ShardUnit> units(f.count());
+    for (size_t i = 0; i < f.count(); i++) units[i] = ShardUnit{ f.entry(i).bundle_idx, f.entry(i).cache_idx, f.entry(i).degree };
+    const PowersDag &dag = devs_[0]->eng->dag();
+    const uint64_t cp_cost = 110u * (uint64_t)(dag.target_powers().size() - dag.source_count());   // apsu_he_compute_powers_cost
+    const std::vector<int> slot = partition_units(units, psu_.bundle_idx_count, (int)devs_.size(), cp_cost);
+    std::vector<std::vector<size_t>> mine(devs_.size());
+    for (size_t i = 0; i < units.size(); i++) mine[slot[i]].push_back(i);
+    const int base = (int)where_.size();
+    std::vector<std::vector<std::unique_ptr<Bundle>>> loaded(devs_.size());
+    run_all([&](Dev &d) {
+        size_t me = 0;
+        for (size_t k = 0; k < devs_.size(); k++) if (devs_[k].get() == &d) me = k;
+        for (size_t i : mine[me]) loaded[me].push_back(f.load(*d.eng, i));
+    });
+    // all shards are on their devices: register in table order (a failed load above leaves the handle unchanged)
+    std::vector<size_t> next(devs_.size(), 0);
+    for (size_t i = 0; i < units.size(); i++) {
+        Dev &d = *devs_[slot[i]];
+        d.bundles.push_back(std::move(loaded[slot[i]][next[slot[i]]++]));
+        d.ids.push_back(base + (int)i);
+        where_.push_back({ slot[i], (int)d.bundles.size() - 1 });
+    }
+    return (int)units.size();
+}
+
+void MultiEngine::save_file(const std::string &path)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    std::vector<Engine *> engs;
+    std::vector<const Bundle *> bs;
+    for (const auto &w : where_) { engs.push_back(devs_[w.first]->eng.get()); bs.push_back(devs_[w.first]->bundles[w.second].get()); }
+    db_file_save(path, engs.data(), bs.data(), bs.size());
+}
+
 void MultiEngine::clear_bundles()
 {
     std::lock_guard<std::mutex> g(mu_);

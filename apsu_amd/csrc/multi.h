@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 
+#include "db_file.h"
 #include "engine.h"
 #include "sharding.h"
 
@@ -33,6 +34,11 @@ public:
     int upload_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs, const u64 *const *coeff_ptrs,
                       const unsigned char *is_ntt);
     int random_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree, u64 seed);
+    // N2: the whole DB from / to one file (db_file.h).  load_file places the file's BinBundles with the partition rule (spill pass
+    // included) and every device reads its own shard from the shared mapping, all devices at once; ids = the file's table order,
+    // appended to whatever is registered already.  Returns the number of BinBundles loaded.
+    int load_file(const DbFile &f);
+    void save_file(const std::string &path);                      // every registered BinBundle, in id order
     int bundle_count() const { return (int)where_.size(); }
     int bundle_device(int id) const { return where_.at(id).first; }
     void clear_bundles();

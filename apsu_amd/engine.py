@@ -374,6 +374,16 @@ class HeContext:
                                                        _p(out), 0))
         return out
 
+    def save_db_file(self, path, bundles):
+        """the whole DB (these BinBundles, in this order) into one mmap-able file (ReceiverDB::save counterpart)"""
+        hs = (C.c_void_p * len(bundles))(*[b.h for b in bundles])
+        _check(load_library().apsu_he_db_file_save(self.h, os.fsencode(path), hs, len(bundles)))
+
+    def load_db_file(self, path, only=None):
+        """-> [Bundle] of the file's BinBundles (all, or the table positions in `only`), loaded onto this context's device"""
+        with DbFile(path) as f:
+            return [f.load(self, i) for i in (range(len(f)) if only is None else only)]
+
     def save_bundle(self, bundle):
         """-> bytes: engine-native image of the BinBundle cache (ReceiverDB::save counterpart)"""
         size = C.c_uint64()
@@ -489,6 +499,49 @@ class HeContext:
         return out
 
 
+class DbFile:
+    """a database file opened with mmap: the table, and BinBundles loaded one by one (apsu_he_db_file_*)"""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        _check(load_library().apsu_he_db_file_open(os.fsencode(path), C.byref(self.h)))
+        cnt, size = C.c_int(), C.c_uint64()
+        _check(load_library().apsu_he_db_file_count(self.h, C.byref(cnt), C.byref(size)))
+        self.count, self.file_bytes = cnt.value, size.value
+
+    def __len__(self):
+        return self.count
+
+    def entry(self, i):
+        """-> (bundle_idx, cache_idx, degree, image_bytes)"""
+        b, c, d, sz = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _check(load_library().apsu_he_db_file_entry(self.h, int(i), C.byref(b), C.byref(c), C.byref(d), C.byref(sz)))
+        return b.value, c.value, d.value, sz.value
+
+    def load(self, ctx, i):
+        h = C.c_void_p()
+        _check(load_library().apsu_he_db_file_load(ctx.h, self.h, int(i), C.byref(h)))
+        b, c, d, _ = self.entry(i)
+        return Bundle(ctx, h, b, c, d)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().apsu_he_db_file_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def partition_bundles(units, bundle_idx_count, n_devices, compute_powers_cost=0):
     """apsu_he_partition_bundles(_ex): units [(bundle_idx, cache_idx, degree)] -> device slot per unit (no GPU needed)"""
     cnt = len(units)
@@ -551,6 +604,17 @@ class MultiContext:
     def clear_bundles(self):
         _check(load_library().apsu_he_multi_db_clear(self.h))
         self.n_bundles = 0
+
+    def load_db_file(self, path):
+        """every BinBundle of the file onto the handle's devices (partition rule, each device reads its own shard) -> count"""
+        with DbFile(path) as f:
+            k = C.c_int()
+            _check(load_library().apsu_he_multi_db_load_file(self.h, f.h, C.byref(k)))
+        self.n_bundles += k.value
+        return k.value
+
+    def save_db_file(self, path):
+        _check(load_library().apsu_he_multi_db_save_file(self.h, os.fsencode(path)))
 
     IO_SRC_PINNED, IO_MASKS_PINNED, IO_OUT_PINNED, IO_SRC_ON_DEVICE, IO_MASKS_ON_DEVICE, IO_GATHER_RCCL = 1, 2, 4, 8, 16, 32
 

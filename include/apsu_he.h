@@ -72,7 +72,8 @@ const char *apsu_he_last_error(void);
  * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768.
  * 4 (additive): ciphertexts of more than two polynomials for parameter sets without key switching -- apsu_he_multiply_sized,
  * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before.
- * apsu_he_algebraize_items (N1: item -> field elements). */
+ * apsu_he_algebraize_items (N1: item -> field elements); apsu_he_db_file_* / apsu_he_multi_db_load_file / _save_file (N2: the whole DB
+ * in one mmap-able file). */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -181,6 +182,20 @@ int apsu_he_decrypt_decode(apsu_he_ctx *ctx, const uint64_t *sk_ntt, const uint6
  * bits [j*b, (j+1)*b) of item i's first item_bit_count bits, read as a little-endian bit string, b = bit_count(plain_modulus) - 1.
  * These are the roots apsu_he_db_build_bundle takes once the host has placed them into bins.  (ABI 4) */
 int apsu_he_algebraize_items(apsu_he_ctx *ctx, const uint8_t *items, size_t count, int items_on_device, uint64_t *felts, int felts_on_device);
+/* N2 for the whole database -- the counterpart of ReceiverDB::save / Load (receiver/apsu/receiver_db.cpp:1182-1429) for a DB
+ * that lives in HBM as raw limb arrays: ONE file per parameter set = header with the parameter fingerprint, a table
+ * (bundle index, cache index, degree, offset, size) and the BinBundle images above at 4096-byte aligned offsets.  The file is
+ * mapped (mmap), so a process touches only the BinBundles it loads, each array going to the device with one copy from the
+ * mapping: a device of a node reads its shard of a 75 GiB database, not the file.  apsu_he_db_file_save writes to path + ".tmp"
+ * and renames.  A file written for other parameters, truncated or with a damaged table / image is refused
+ * (APSU_HE_INVALID_ARGUMENT).  (ABI 4) */
+typedef struct apsu_he_db_file apsu_he_db_file;
+int apsu_he_db_file_save(apsu_he_ctx *ctx, const char *path, const apsu_he_bundle *const *bundles, int count);
+int apsu_he_db_file_open(const char *path, apsu_he_db_file **out);
+int apsu_he_db_file_close(apsu_he_db_file *f);
+int apsu_he_db_file_count(const apsu_he_db_file *f, int *count, uint64_t *file_bytes);
+int apsu_he_db_file_entry(const apsu_he_db_file *f, int i, uint32_t *bundle_idx, uint32_t *cache_idx, uint32_t *degree, uint64_t *image_bytes);
+int apsu_he_db_file_load(apsu_he_ctx *ctx, const apsu_he_db_file *f, int i, apsu_he_bundle **out);
 /* test hooks: degree of the batched polynomial; stored form of coefficient `degree`
  * (kind 0: raw mod t [n]; 1: NTT form [(plain_level+1)*n]; 2: pre-lifted + NTT at the high level [(high+1)*n]) */
 int apsu_he_bundle_degree(const apsu_he_bundle *b, uint32_t *degree);
@@ -244,6 +259,11 @@ int apsu_he_multi_db_upload_bundle(apsu_he_multi *m, int device_slot, uint32_t b
                                    const uint64_t *const *coeff_ptrs, const uint8_t *is_ntt, int *bundle_id);
 int apsu_he_multi_db_random_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t degree,
                                    uint64_t seed, int *bundle_id);
+/* the whole file onto the handle's devices: BinBundles placed by apsu_he_partition_bundles_ex's rule (spill pass included), every
+ * device reading its own shard from the shared mapping, all devices at once; bundle ids = the file's table order (appended to
+ * what is registered already).  apsu_he_multi_db_save_file writes every registered BinBundle, in id order, into one file. */
+int apsu_he_multi_db_load_file(apsu_he_multi *m, const apsu_he_db_file *f, int *n_loaded);
+int apsu_he_multi_db_save_file(apsu_he_multi *m, const char *path);
 int apsu_he_multi_db_clear(apsu_he_multi *m);
 /* One query on all devices (receiver_osn.cpp:304-364): src_cts[b * source_power_count + s] = host ciphertext of source
  * power s (ascending) of bundle index b, for EVERY bundle index (each device uploads the ones it needs); masks[id] = n

@@ -209,3 +209,65 @@ def test_algebraize_items_matches_oracle(cfg):
     assert got.shape == (1000, felts) and (got == C.algebraize_items(items, felts)).all()
     assert G.algebraize_items(items[:0]).shape == (0, felts)
     G.close()
+
+
+def test_database_file_round_trip_and_rejections(tmp_path):
+    """N2 for the whole DB (ReceiverDB::save / Load counterpart): one mmap-able file, BinBundles loaded one by one, by shard, or
+    onto the devices of a multi-device handle; same evaluation results; damaged / foreign files are refused"""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 5, 3], 1: [8, 0]})
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    want = G.eval_bundles(gb, pw, rk, masks)
+    path = str(tmp_path / "db.apsuhe")
+    G.save_db_file(path, gb)
+    with apsu_amd.DbFile(path) as f:
+        assert len(f) == len(gb) and f.file_bytes % 4096 == 0
+        assert [f.entry(i)[:3] for i in range(len(f))] == [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+        assert all(f.entry(i)[3] == len(G.save_bundle(gb[i])) for i in range(len(f)))
+    # a fresh context (another process would do the same): everything, then only a shard
+    G2 = apsu_amd.HeContext(js)
+    rk2 = G2.upload_relin_keys(S.rk)
+    pw2 = G2.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk2)
+    back = G2.load_db_file(path)
+    assert [(b.bundle_idx, b.cache_idx, b.degree) for b in back] == [(b.bundle_idx, b.cache_idx, b.degree) for b in gb]
+    assert (G2.eval_bundles(back, pw2, rk2, masks) == want).all()
+    shard = G2.load_db_file(path, only=[1, 3])
+    assert (G2.eval_bundles(shard, pw2, rk2, [masks[1], masks[3]]) == want[[1, 3]]).all()
+    # the multi-device handle places the file's BinBundles itself ({0, 0} rehearses two devices); ids = table order
+    flat = [S.src[b][e] for b in range(S.p["bundle_idx_count"]) for e in S.sources]
+    for devs in ([0], [0, 0]):
+        M = apsu_amd.MultiContext(js, devs)
+        M.upload_relin_keys(S.rk)
+        assert M.load_db_file(path) == len(gb)
+        assert (M.eval_all(flat, masks, G.n) == want).all(), devs
+        again = str(tmp_path / ("again%d.apsuhe" % len(devs)))
+        M.save_db_file(again)
+        assert open(again, "rb").read() == open(path, "rb").read()
+        M.close()
+    # refusals
+    raw = bytearray(open(path, "rb").read())
+    def refused(mutated, name):
+        p = str(tmp_path / name)
+        open(p, "wb").write(mutated)
+        with pytest.raises(ValueError):
+            G2.load_db_file(p)
+    refused(raw[:len(raw) - 4096], "truncated")
+    refused(b"NOTADBFL" + bytes(raw[8:]), "magic")
+    bad = bytearray(raw); bad[256 + 8] ^= 1                       # table entry: degree
+    refused(bad, "table")
+    bad = bytearray(raw); bad[len(raw) - 5000] ^= 0x40            # payload of the last image (or its padding: then the header's size check)
+    with apsu_amd.DbFile(path) as f:
+        off = 4096 * ((256 + 32 * len(f) + 4095) // 4096)
+    bad = bytearray(raw); bad[off + 300] ^= 0x40                  # first image's payload: the image checksum
+    refused(bad, "payload")
+    other = apsu_amd.HeContext(common.toy_json(max_items=12))
+    with pytest.raises(ValueError, match="different parameters"):
+        other.load_db_file(path)
+    with pytest.raises(apsu_amd.ApsuHeError):
+        G2.load_db_file(str(tmp_path / "missing"))
+    for c in (G, G2, other):
+        c.close()

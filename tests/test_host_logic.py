@@ -449,3 +449,41 @@ def test_ntt_final_reduction_fold_and_barrett(emu):
     assert folded >= 10                                           # the 48..61-bit primes do take the fold
     assert emu.emu_reduce_any(C.c_uint64(0xfffffffff70001), x.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 1) == 56
     assert emu.emu_reduce_any(C.c_uint64(0x3e4001), x.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 1) == 0
+
+
+def test_database_file_reader_refuses_malformed_files_without_a_gpu(tmp_path):
+    """apsu_he_db_file_open only maps and validates (header, table checksum, offsets inside the file): no device involved"""
+    import struct
+    import apsu_amd
+
+    def opened(data, name):
+        p = tmp_path / name
+        p.write_bytes(data)
+        return apsu_amd.DbFile(str(p))
+
+    def fnv(b):
+        h = 1469598103934665603
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & (2**64 - 1)
+        return h
+
+    def image(count, entries, total):
+        table = b"".join(struct.pack("<4I2Q", *e) for e in entries)
+        hd = b"APSUHED1" + struct.pack("<4Q", 256, 256, count, total) + bytes(88 + 16) + struct.pack("<Q", fnv(table))
+        body = hd + bytes(256 - len(hd)) + table
+        return body + bytes(total - len(body))
+
+    ok = image(2, [(0, 0, 3, 0, 4096, 1000), (1, 0, 5, 0, 8192, 4096)], 12288)
+    f = opened(ok, "ok")
+    assert len(f) == 2 and f.entry(1) == (1, 0, 5, 4096) and f.file_bytes == 12288
+    f.close()
+    for name, data in (("short", ok[:100]), ("magic", b"X" + ok[1:]), ("truncated", ok[:8192]),
+                       ("table", ok[:256 + 8] + b"\x07" + ok[256 + 9:]),
+                       ("outside", image(1, [(0, 0, 3, 0, 8192, 4097)], 12288)),
+                       ("unaligned", image(1, [(0, 0, 3, 0, 4100, 16)], 12288)),
+                       ("in-table", image(1, [(0, 0, 3, 0, 0, 16)], 12288)),
+                       ("count", image(2**40, [], 4096))):
+        with pytest.raises(ValueError):
+            opened(data, name)
+    with pytest.raises(apsu_amd.ApsuHeError):
+        apsu_amd.DbFile(str(tmp_path / "missing"))
