@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include "apsu_he.h"
 
@@ -172,6 +173,34 @@ int main(int argc, char **argv)
         free(back);
         CHECK(apsu_he_wire_buffer_free(blob));
         CHECK(apsu_he_seal_ctx_free(sc));
+    }
+
+    /* N2: the database (here: the one BinBundle) into a file, mapped and loaded back -- the same query result; N1: an item's field elements */
+    {
+        char path[64];
+        snprintf(path, sizeof(path), "/tmp/apsu_he_demo_%d.db", (int)getpid());
+        CHECK(apsu_he_db_file_save(ctx, path, bl, 1));
+        apsu_he_db_file *f = NULL;
+        CHECK(apsu_he_db_file_open(path, &f));
+        int cnt = 0; uint64_t fbytes = 0; uint32_t fb = 9, fc = 9, fd = 0;
+        CHECK(apsu_he_db_file_count(f, &cnt, &fbytes));
+        CHECK(apsu_he_db_file_entry(f, 0, &fb, &fc, &fd, NULL));
+        apsu_he_bundle *again = NULL;
+        CHECK(apsu_he_db_file_load(ctx, f, 0, &again));
+        CHECK(apsu_he_db_file_close(f));
+        remove(path);
+        uint64_t *out3 = (uint64_t *)malloc(2 * n * 8);
+        const apsu_he_bundle *bl3[1] = { again };
+        CHECK(apsu_he_eval_bundles(ctx, bl3, 1, pw, rk, ml, 1, out3, 0));
+        printf("dbfile %s (%d BinBundle, %llu bytes)\n", (cnt == 1 && fb == 0 && fc == 0 && fd == info.max_items_per_bin - 1 && !memcmp(out, out3, 2 * n * 8)) ? "ok" : "MISMATCH",
+               cnt, (unsigned long long)fbytes);
+        free(out3);
+        CHECK(apsu_he_bundle_free(again));
+        uint8_t item[16];
+        for (int i = 0; i < 16; i++) item[i] = (uint8_t)(0x10 * (i % 8) + 0x0f - i);
+        uint64_t felts[32];
+        CHECK(apsu_he_algebraize_items(ctx, item, 1, 0, felts, 0));
+        printf("felts %016llx\n", (unsigned long long)fnv(felts, 2 * 8));
     }
 
     /* error behaviour: too few powers for a bundle index that was not computed */

@@ -45,6 +45,7 @@ def test_c_program_matches_python_binding(tmp_path):
     assert lines["roundtrip"] == "ok" and lines["missing-powers"].startswith("status -1") and "done" in r.stdout
     assert lines["multi"].startswith("ok") and lines["wire"].startswith("ok"), r.stdout
     assert lines["pinned"].startswith("ok") and "Receiver::RunQuery" in lines["pinned"] and lines["seal"].startswith("ok"), r.stdout
+    assert lines["dbfile"].startswith("ok (1 BinBundle"), r.stdout
 
     # the same inputs through the Python binding
     G = apsu_amd.HeContext(open(params).read())
@@ -73,3 +74,5 @@ def test_c_program_matches_python_binding(tmp_path):
     assert lines["blocks"] == fnv(blocks)
     out = G.eval_bundles([bundle], pw, rk, [buf.data_ptr()], masks_on_device=True)
     assert lines["result"] == fnv(out)
+    item = np.array([0x10 * (i % 8) + 0x0f - i for i in range(16)], dtype=np.uint8)
+    assert lines["felts"] == fnv(G.algebraize_items(item)[0, :2])
