@@ -1,9 +1,11 @@
 // See seal_codec.h.  UNPINNED restatement of Microsoft SEAL's object serialisation; host code only.
 #include "seal_codec.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -22,6 +24,42 @@ void wr64(std::vector<uint8_t> &b, uint64_t v) { for (int i = 0; i < 8; i++) b.p
 constexpr size_t MAX_BODY = (size_t)1 << 30;                    // inflated size cap (zip bombs)
 
 struct Header { uint8_t vmaj = 0, vmin = 0, compr = 0; uint64_t total = 0; };
+
+// Zstandard, SEAL's default compr_mode when it is built with SEAL_USE_ZSTD (the default of its CMake): loaded at run time from the
+// system's libzstd.so.1 -- the image has the library but not its headers, and the codec must not require it.  Only the stable
+// one-shot compressor and the streaming decompressor are used (a SEAL writer streams its frame, ztools.cpp; any single frame is
+// what its reader takes).  [SEAL-recall: one zstd frame of the member bytes, like the one deflate stream of compr zlib.]
+struct Zstd {
+    struct InBuf { const void *src; size_t size, pos; };          // ZSTD_inBuffer
+    struct OutBuf { void *dst; size_t size, pos; };               // ZSTD_outBuffer
+    void *lib = nullptr;
+    size_t (*compress_bound)(size_t) = nullptr;
+    size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    void *(*create_dstream)() = nullptr;
+    size_t (*free_dstream)(void *) = nullptr;
+    size_t (*init_dstream)(void *) = nullptr;
+    size_t (*decompress_stream)(void *, OutBuf *, InBuf *) = nullptr;
+    bool ok = false;
+    Zstd()
+    {
+        for (const char *name : { "libzstd.so.1", "libzstd.so" }) if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) return;
+        compress_bound = reinterpret_cast<decltype(compress_bound)>(dlsym(lib, "ZSTD_compressBound"));
+        compress = reinterpret_cast<decltype(compress)>(dlsym(lib, "ZSTD_compress"));
+        is_error = reinterpret_cast<decltype(is_error)>(dlsym(lib, "ZSTD_isError"));
+        create_dstream = reinterpret_cast<decltype(create_dstream)>(dlsym(lib, "ZSTD_createDStream"));
+        free_dstream = reinterpret_cast<decltype(free_dstream)>(dlsym(lib, "ZSTD_freeDStream"));
+        init_dstream = reinterpret_cast<decltype(init_dstream)>(dlsym(lib, "ZSTD_initDStream"));
+        decompress_stream = reinterpret_cast<decltype(decompress_stream)>(dlsym(lib, "ZSTD_decompressStream"));
+        ok = compress_bound && compress && is_error && create_dstream && free_dstream && init_dstream && decompress_stream;
+    }
+};
+const Zstd &zstd()
+{
+    static const Zstd z;                                          // (thread-safe initialisation; the handle stays open)
+    return z;
+}
 
 Header read_header(const uint8_t *p, size_t avail)
 {
@@ -57,7 +95,32 @@ Body open_object(const uint8_t *buf, size_t size)
     const uint8_t *stored = buf + 16;
     const size_t stored_n = (size_t)b.h.total - 16;
     if (b.h.compr == COMPR_NONE) { b.p = stored; b.n = stored_n; return b; }
-    if (b.h.compr == COMPR_ZSTD) bad("zstd-compressed SEAL object: not supported in this build (no zstd); have the peer use zlib or none");
+    if (b.h.compr == COMPR_ZSTD) {
+        const Zstd &z = zstd();
+        if (!z.ok) bad("zstd-compressed SEAL object, and libzstd.so.1 is not on this system; have the peer use zlib or none");
+        void *ds = z.create_dstream();
+        if (!ds) bad("zstd initialisation failed");
+        struct Free { const Zstd &z; void *ds; ~Free() { z.free_dstream(ds); } } guard{ z, ds };
+        if (z.is_error(z.init_dstream(ds))) bad("zstd initialisation failed");
+        Zstd::InBuf in{ stored, stored_n, 0 };
+        b.owned.resize(std::max<size_t>(4096, stored_n * 4));
+        size_t have = 0, rc = 1;
+        while (in.pos < in.size || rc != 0) {
+            if (have == b.owned.size()) {
+                if (b.owned.size() >= MAX_BODY) bad("inflated object too large");
+                b.owned.resize(std::min(MAX_BODY, b.owned.size() * 2));
+            }
+            Zstd::OutBuf out{ b.owned.data() + have, b.owned.size() - have, 0 };
+            const size_t in_before = in.pos;
+            rc = z.decompress_stream(ds, &out, &in);
+            if (z.is_error(rc)) bad("corrupt zstd stream");
+            have += out.pos;
+            if (rc != 0 && in.pos == in.size && out.pos == 0 && in.pos == in_before) bad("corrupt zstd stream (truncated frame)");
+        }
+        b.owned.resize(have);
+        b.p = b.owned.data(); b.n = have;
+        return b;
+    }
     if (b.h.compr != COMPR_ZLIB) bad("unknown compression mode");
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
@@ -94,7 +157,17 @@ std::vector<uint8_t> close_object(const std::vector<uint8_t> &members, uint8_t v
         out.insert(out.end(), members.begin(), members.end());
         return out;
     }
-    if (compr != COMPR_ZLIB) throw std::invalid_argument("unsupported compression mode for saving (none or zlib)");
+    if (compr == COMPR_ZSTD) {
+        const Zstd &z = zstd();
+        if (!z.ok) throw std::runtime_error("zstd requested, and libzstd.so.1 is not on this system");
+        std::vector<uint8_t> f(z.compress_bound(members.size()));
+        const size_t k = z.compress(f.data(), f.size(), members.data(), members.size(), 3 /* ZSTD_CLEVEL_DEFAULT */);
+        if (z.is_error(k)) throw std::runtime_error("zstd compression failed");
+        write_header(out, vmaj, vmin, COMPR_ZSTD, 16 + k);
+        out.insert(out.end(), f.begin(), f.begin() + k);
+        return out;
+    }
+    if (compr != COMPR_ZLIB) throw std::invalid_argument("unsupported compression mode for saving (none, zlib or zstd)");
     uLongf cap = compressBound((uLong)members.size());
     std::vector<uint8_t> z(cap);
     if (compress2(z.data(), &cap, members.data(), (uLong)members.size(), Z_DEFAULT_COMPRESSION) != Z_OK) throw std::runtime_error("zlib deflate failed");

@@ -9,12 +9,13 @@
 //   querier: Encryptor::encrypt_symmetric -> Serializable<Ciphertext> (c1 replaced by the seed of the PRNG that sampled it)
 //            sender/apsu/plaintext_powers.cpp:41-46 ; KeyGenerator::create_relin_keys -> Serializable<RelinKeys> sender_osn.cpp:223-227
 //            both saved with compr_mode_default (zstd if SEAL was built with it, else zlib) common/apsu/seal_object.h:183-196
+//            -- all three modes are read and written here
 //   DB side: SEALObject::load / extract -> Ciphertext::load expands the seed  receiver/apsu/query.cpp:44-80
 //
 // Layout restated (all integers little-endian):
 //   SEALHeader (16 B): magic 0xA15E u16 | header_size 0x10 u8 | version major u8 | minor u8 | compr_mode u8 (0 none, 1 zlib,
 //                      2 zstd) | reserved u16 | size u64 (header + body as stored)
-//   body as stored   : the member bytes; with zlib ONE deflate stream (zlib format) of them
+//   body as stored   : the member bytes; with zlib ONE deflate stream (zlib format) of them, with zstd ONE zstd frame
 //   Ciphertext       : parms_id 4 x u64 | is_ntt_form u8 | size u64 | poly_modulus_degree u64 | coeff_modulus_size u64 |
 //                      correction_factor u64 (version 4.x) | scale f64 | DynArray  [| UniformRandomGeneratorInfo  if seeded]
 //                      seeded: the DynArray holds c0 only (size/2 of the words); c1 = sample_poly_uniform(PRNG(seed))
@@ -58,12 +59,13 @@ struct Ciphertext {
     std::vector<uint64_t> data;          // [size][coeff_modulus_size][poly_modulus_degree], expanded
 };
 
-// One serialised object of `size` bytes at buf (its header says how many are used: *consumed).  zlib bodies are inflated,
-// zstd is refused ("zstd-compressed SEAL object: not supported in this build").  Throws std::runtime_error on malformed input.
+// One serialised object of `size` bytes at buf (its header says how many are used: *consumed).  zlib and zstd bodies are inflated
+// (zstd through the system's libzstd.so.1, loaded at run time; refused with a clear message where that is absent).
+// Throws std::runtime_error on malformed input.
 // expand = false: a seeded object's c1 is left zero and only ct.seed is filled (the caller expands it, e.g. on the device with
 // apsu_he_seed_expand); the chain is then not consulted.
 Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr, bool expand = true);
-// compr: COMPR_NONE or COMPR_ZLIB.  ct.seeded: c1 is NOT written, the seed is (the caller guarantees c1 = sample(seed)).
+// compr: COMPR_NONE, COMPR_ZLIB or COMPR_ZSTD.  ct.seeded: c1 is NOT written, the seed is (the caller guarantees c1 = sample(seed)).
 std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr);
 
 struct KSwitchKeys {

@@ -364,7 +364,8 @@ int apsu_he_wire_result_labels(const uint8_t *buf, size_t size, uint32_t capacit
  * the reference or this image can confirm it, the tests hold it against an independent Python model only (zlib and the BLAKE2b
  * core are pinned by python's zlib / hashlib).  Covers what the reference really puts on the wire
  * (sender/apsu/plaintext_powers.cpp:41-46, sender_osn.cpp:223-227,488, receiver/apsu/query.cpp:44-80, seal_object.h:161-219):
- *   - SEALHeader + body, compr_mode none or zlib (zstd is refused with a clear message: no zstd in this build);
+ *   - SEALHeader + body, compr_mode none, zlib or zstd (zstd through the system's libzstd.so.1, loaded at run time; refused with a
+ *     clear message where that library is absent);
  *   - seeded ciphertexts (Serializable<Ciphertext> of encrypt_symmetric): c1 is expanded from the stored seed with SEAL's
  *     Blake2xb generator and util::sample_poly_uniform;
  *   - KSwitchKeys / RelinKeys (seeded or not) into the [decomp][2][K][n] array apsu_he_relin_upload takes;

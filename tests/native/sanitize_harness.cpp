@@ -87,7 +87,7 @@ int main(int argc, char **argv)
         ct.size = 2; ct.coeff_modulus_size = 2; ct.poly_modulus_degree = 64;
         ct.data.resize(2 * 2 * 64);
         for (size_t i = 0; i < ct.data.size(); i++) ct.data[i] = rnd() % kq[(i / 64) % 2];
-        for (uint8_t compr : { sealio::COMPR_NONE, sealio::COMPR_ZLIB }) {
+        for (uint8_t compr : { sealio::COMPR_NONE, sealio::COMPR_ZLIB, sealio::COMPR_ZSTD }) {
             const std::vector<uint8_t> eb = sealio::save_ciphertext(ct, compr);
             if (sealio::load_ciphertext(eb.data(), eb.size(), chain).data != ct.data) return 12;
             rej += fuzz(eb, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 8000);

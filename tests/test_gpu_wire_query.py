@@ -28,7 +28,7 @@ def reseed_ciphertext(C, sk, ct, a_new):
     return np.stack([c0, a_new])
 
 
-@pytest.mark.parametrize("compr", [seal.COMPR_ZLIB, seal.COMPR_NONE])
+@pytest.mark.parametrize("compr", [seal.COMPR_ZLIB, seal.COMPR_NONE, seal.COMPR_ZSTD])
 def test_framed_seeded_query_runs_through_the_engine(compr):
     js = common.toy_json()
     S = common.make_scenario(js, {0: [11, 5], 1: [8]})

@@ -15,7 +15,7 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "sanitize_harness")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
            os.path.join(ROOT, "tests", "native", "sanitize_harness.cpp")] + \
-          [os.path.join(SRC, f) for f in ("wire.cpp", "seal_codec.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-lz", "-o", exe]
+          [os.path.join(SRC, f) for f in ("wire.cpp", "seal_codec.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-lz", "-ldl", "-o", exe]
     subprocess.check_call(cmd)
     params = [os.path.join(ROOT, "tests", "params", f + ".json") for f in ("100K-1", "1M-1024-com", "1M-4096-32", "256M-4096")]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")

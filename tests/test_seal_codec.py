@@ -24,8 +24,72 @@ MAGIC = b"\x5e\xa1\x10"
 
 
 # ---------------------------------------------------------------------------------------------- the Python model
+def _zstd():
+    """the system's libzstd through ctypes (python has no zstd module here): the test's own compressor, one-shot and streamed"""
+    import ctypes as C
+    try:
+        z = C.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    z.ZSTD_decompress.restype = C.c_size_t
+    z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    z.ZSTD_createCStream.restype = C.c_void_p
+    z.ZSTD_freeCStream.argtypes = [C.c_void_p]
+    z.ZSTD_compressStream2.restype = C.c_size_t
+    z.ZSTD_compressStream2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    return z
+
+
+def zstd_compress(data, streamed=False):
+    import ctypes as C
+    z = _zstd()
+    cap = z.ZSTD_compressBound(len(data)) + 64
+    dst = C.create_string_buffer(cap)
+    if not streamed:
+        k = z.ZSTD_compress(dst, cap, data, len(data), 3)
+        assert not z.ZSTD_isError(k)
+        return dst.raw[:k]
+
+    class Buf(C.Structure):
+        _fields_ = [("p", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+    # the way a SEAL writer does it (ztools.cpp [SEAL-recall]): a compression stream fed in chunks, no pledged source size, ZSTD_e_end last
+    cs = z.ZSTD_createCStream()
+    src = C.create_string_buffer(bytes(data), len(data))
+    out = Buf(C.cast(dst, C.c_void_p), cap, 0)
+    chunk = 1000
+    at = 0
+    while True:
+        take = min(chunk, len(data) - at)
+        last = at + take == len(data)
+        inb = Buf(C.cast(C.addressof(src) + at, C.c_void_p), take, 0)
+        while True:
+            rem = z.ZSTD_compressStream2(cs, C.byref(out), C.byref(inb), 2 if last else 0)        # ZSTD_e_end / ZSTD_e_continue
+            assert not z.ZSTD_isError(rem)
+            if (last and rem == 0) or (not last and inb.pos == inb.size):
+                break
+        at += take
+        if last:
+            break
+    z.ZSTD_freeCStream(cs)
+    return dst.raw[:out.pos]
+
+
+def zstd_decompress(frame, size):
+    import ctypes as C
+    z = _zstd()
+    dst = C.create_string_buffer(size)
+    k = z.ZSTD_decompress(dst, size, frame, len(frame))
+    assert not z.ZSTD_isError(k) and k == size
+    return dst.raw
+
+
 def obj(members, compr=0, version=(4, 0)):
-    stored = zlib.compress(members) if compr == 1 else members
+    stored = zlib.compress(members) if compr == 1 else (zstd_compress(members) if compr == 2 else members)
     return MAGIC + bytes([version[0], version[1], compr, 0, 0]) + struct.pack("<Q", 16 + len(stored)) + stored
 
 
@@ -137,6 +201,38 @@ def test_ciphertext_plain_and_seeded_both_directions(ctx, version, compr):
     assert got["seeded"] and (got["data"] == sdata).all()
     assert ctx.ct_save(L - 1, False, sdata, seed=seed, compr=compr, version=version) == sblob
     assert len(sblob) < len(blob) or compr == 1
+
+
+@pytest.mark.skipif(_zstd() is None, reason="libzstd.so.1 is not on this system")
+def test_zstd_objects_both_directions(ctx):
+    """compr_mode zstd -- SEAL's default when built with it -- through the system's libzstd (loaded at run time by the codec):
+    one-shot and streamed frames in, frames out that the library itself inflates to the model's member bytes"""
+    rng = np.random.default_rng(21)
+    L = 2
+    pid = parms_id(N, Q[:L], T)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q[:L]]) for _ in range(2)])
+    seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+    sdata = np.stack([data[0], sample_poly_uniform(seed, Q[:L], N)])
+    for version in ((4, 0), (3, 6)):
+        for members, want, sd in ((ct_members(pid, False, data, version), data, None), (ct_members(pid, False, sdata, version, seed=seed), sdata, seed)):
+            for streamed in (False, True):
+                stored = zstd_compress(members, streamed)
+                blob = MAGIC + bytes([version[0], version[1], 2, 0, 0]) + struct.pack("<Q", 16 + len(stored)) + stored
+                got = ctx.ct_load(blob + b"tail")
+                assert got["consumed"] == len(blob) and got["seeded"] == (sd is not None) and (got["data"] == want).all()
+            mine = ctx.ct_save(L - 1, False, want, seed=sd, compr=2, version=version)
+            assert mine[:8] == MAGIC + bytes([version[0], version[1], 2, 0, 0]) and struct.unpack_from("<Q", mine, 8)[0] == len(mine)
+            assert zstd_decompress(mine[16:], len(members)) == members
+    # relinearisation keys, the big object of a query
+    ksk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q]) for _ in range(2)]) for _ in range(len(Q) - 1)])
+    blob = ctx.relin_keys_save(ksk, compr=2)
+    back, used = ctx.relin_keys_load(blob)
+    assert used == len(blob) and (back.reshape(ksk.shape) == ksk).all() and blob[5] == 2
+    # damage: a flipped byte in the frame, a truncated frame
+    stored = zstd_compress(ct_members(pid, False, data, (4, 0)))
+    for bad in (stored[:40] + bytes([stored[40] ^ 0x55]) + stored[41:], stored[:len(stored) // 2]):
+        with pytest.raises(apsu_amd.ApsuHeError, match="zstd|truncated|SEAL object"):
+            ctx.ct_load(MAGIC + bytes([4, 0, 2, 0, 0]) + struct.pack("<Q", 16 + len(bad)) + bad)
 
 
 def test_ciphertext_rejects_malformed(ctx):
