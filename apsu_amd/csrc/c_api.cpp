@@ -767,6 +767,82 @@ int apsu_he_seal_ct_save(const apsu_he_seal_ctx *c, int chain_idx, int is_ntt_fo
         wire_out(sealio::save_ciphertext(ct, (uint8_t)compr_mode), out, out_size);
     });
 }
+int apsu_he_seal_pt_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, int *chain_idx, uint64_t *coeff_count, uint64_t *data,
+                         size_t data_capacity_words, size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(c && buf, "null argument");
+        size_t used = 0;
+        const sealio::Plaintext pt = sealio::load_plaintext(buf, size, &used);
+        int ci = -1;                                                      // coefficient form
+        if (pt.is_ntt_form()) {
+            ci = seal_chain_idx(c, pt.parms_id);
+            if (ci < 0) throw std::invalid_argument("parms_id of the plaintext is not in this context's modulus chain");
+        }
+        if (chain_idx) *chain_idx = ci;
+        if (coeff_count) *coeff_count = pt.coeff_count;
+        if (consumed) *consumed = used;
+        if (data) {
+            if (data_capacity_words < pt.data.size()) throw std::invalid_argument("output buffer too small");
+            std::memcpy(data, pt.data.data(), pt.data.size() * sizeof(uint64_t));
+        }
+    });
+}
+int apsu_he_seal_pt_save(const apsu_he_seal_ctx *c, int chain_idx, const uint64_t *data, uint64_t coeff_count, int compr_mode, int version_major,
+                         int version_minor, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(c && data && out && out_size, "null argument");
+        sealio::Plaintext pt;
+        if (chain_idx >= 0) {
+            const sealio::Level &l = seal_level(c, chain_idx);
+            std::memcpy(pt.parms_id, l.parms_id, 32);
+            REQUIRE(coeff_count == l.q.size() * c->n, "an NTT-form plaintext has one polynomial per coefficient prime of its level");
+        }
+        pt.coeff_count = coeff_count;
+        pt.version_major = (uint8_t)version_major; pt.version_minor = (uint8_t)version_minor;
+        pt.data.assign(data, data + coeff_count);
+        wire_out(sealio::save_plaintext(pt, (uint8_t)compr_mode), out, out_size);
+    });
+}
+// BinBundleCache::batched_matching_polyn as the reference holds it -- batched_coeffs[d] = a SEAL-serialised Plaintext
+// (bin_bundle.cpp:421-428, compr_mode none or zstd) -- straight into apsu_he_db_upload_bundle, without SEAL on the host
+int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                        const uint8_t *const *blobs, const size_t *blob_sizes, apsu_he_bundle **out)
+{
+    return guarded([&] {
+        REQUIRE(c && sc && blobs && blob_sizes && out && n_coeffs > 0, "null argument");
+        const HeParams &hp = c->eng->he();
+        REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
+        std::vector<std::vector<uint64_t>> keep(n_coeffs);
+        std::vector<const uint64_t *> ptrs(n_coeffs);
+        std::vector<unsigned char> is_ntt(n_coeffs);
+        int ntt_level = -1;
+        for (uint32_t d = 0; d < n_coeffs; d++) {
+            REQUIRE(blobs[d], "null plaintext");
+            sealio::Plaintext pt = sealio::load_plaintext(blobs[d], blob_sizes[d]);
+            is_ntt[d] = pt.is_ntt_form() ? 1 : 0;
+            if (pt.is_ntt_form()) {
+                const int ci = seal_chain_idx(sc, pt.parms_id);
+                if (ci < 0 || ci > hp.first_chain_idx) throw std::invalid_argument("plaintext parms_id is not a data level of these parameters");
+                if (ntt_level >= 0 && ci != ntt_level) throw std::invalid_argument("the NTT-form plaintexts of a BinBundle share one level (bin_bundle.cpp:385-389)");
+                ntt_level = ci;
+                if (pt.coeff_count != (uint64_t)(ci + 1) * hp.n) throw std::invalid_argument("NTT-form plaintext has the wrong coefficient count");
+            } else {
+                if (pt.coeff_count > hp.n) throw std::invalid_argument("coefficient-form plaintext is longer than the ring");
+                pt.data.resize(hp.n, 0);                                 // BatchEncoder::encode writes n coefficients; shorter ones are zero-extended
+            }
+            keep[d] = std::move(pt.data);
+            ptrs[d] = keep[d].data();
+        }
+        auto b = new apsu_he_bundle;
+        try {
+            b->b = c->eng->upload_bundle(bundle_idx, cache_idx, n_coeffs, ptrs.data(), is_ntt.data());
+            if (ntt_level >= 0 && b->b->pt_level != ntt_level) throw std::invalid_argument("the NTT-form plaintexts are not at the level the BinBundle rule prescribes (bin_bundle.cpp:385-389)");
+        } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
 int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,
                                  size_t *consumed)
 {

@@ -343,6 +343,43 @@ std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr)
     return close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, compr);
 }
 
+Plaintext load_plaintext(const uint8_t *buf, size_t size, size_t *consumed)
+{
+    if (!buf) bad("null buffer");
+    Body b = open_object(buf, size);
+    Cursor c{ b.p, b.n };
+    Plaintext pt;
+    for (int i = 0; i < 4; i++) pt.parms_id[i] = c.u64();
+    pt.coeff_count = c.u64();
+    { const uint64_t s = c.u64(); std::memcpy(&pt.scale, &s, 8); }
+    pt.version_major = b.h.vmaj; pt.version_minor = b.h.vmin;
+    if (pt.coeff_count > ((uint64_t)64 << 20)) bad("implausible plaintext size");
+    Body arr = open_object(c.here(), c.left());
+    Cursor a{ arr.p, arr.n };
+    const uint64_t count = a.u64();
+    if (count != pt.coeff_count) bad("plaintext coefficient array does not match coeff_count");
+    a.need((size_t)count * 8);
+    pt.data.resize((size_t)count);
+    for (uint64_t i = 0; i < count; i++) pt.data[(size_t)i] = rd64(a.here() + 8 * i);
+    if (consumed) *consumed = (size_t)b.h.total;
+    return pt;
+}
+
+std::vector<uint8_t> save_plaintext(const Plaintext &pt, uint8_t compr)
+{
+    if (pt.data.size() != pt.coeff_count) throw std::invalid_argument("plaintext data size does not match coeff_count");
+    std::vector<uint8_t> m;
+    for (int i = 0; i < 4; i++) wr64(m, pt.parms_id[i]);
+    wr64(m, pt.coeff_count);
+    { uint64_t s; std::memcpy(&s, &pt.scale, 8); wr64(m, s); }
+    std::vector<uint8_t> arr;
+    wr64(arr, pt.coeff_count);
+    for (uint64_t w : pt.data) wr64(arr, w);
+    const std::vector<uint8_t> ao = close_object(arr, pt.version_major, pt.version_minor, COMPR_NONE);
+    m.insert(m.end(), ao.begin(), ao.end());
+    return close_object(m, pt.version_major, pt.version_minor, compr);
+}
+
 KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed)
 {
     if (!buf) bad("null buffer");

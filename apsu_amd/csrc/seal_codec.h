@@ -68,6 +68,21 @@ Ciphertext load_ciphertext(const uint8_t *buf, size_t size, const std::vector<Le
 // compr: COMPR_NONE, COMPR_ZLIB or COMPR_ZSTD.  ct.seeded: c1 is NOT written, the seed is (the caller guarantees c1 = sample(seed)).
 std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr);
 
+// seal::Plaintext (plaintext.cpp save_members [SEAL-recall]): parms_id 4 x u64 (all zero = coefficient form, else the level the
+// plaintext was transformed to NTT form at) | coeff_count u64 | scale f64 | DynArray.  What the reference keeps per coefficient of
+// a BinBundle's batched polynomial (bin_bundle.cpp:421-428: Plaintext::save, compr_mode none or zstd) and re-reads with
+// unsafe_load on every use (bin_bundle.cpp:143-146).
+struct Plaintext {
+    uint64_t parms_id[4] = { 0, 0, 0, 0 };
+    uint64_t coeff_count = 0;
+    double scale = 1.0;
+    uint8_t version_major = 4, version_minor = 0;
+    std::vector<uint64_t> data;          // coeff_count words ([L][n] in NTT form)
+    bool is_ntt_form() const { return (parms_id[0] | parms_id[1] | parms_id[2] | parms_id[3]) != 0; }
+};
+Plaintext load_plaintext(const uint8_t *buf, size_t size, size_t *consumed = nullptr);
+std::vector<uint8_t> save_plaintext(const Plaintext &pt, uint8_t compr);
+
 struct KSwitchKeys {
     uint64_t parms_id[4] = { 0, 0, 0, 0 };
     std::vector<std::vector<Ciphertext>> keys;          // [dim1][dim2]

@@ -97,6 +97,25 @@ class SealContext:
                                                C.byref(words), C.byref(used)))
         return out, used.value
 
+    def pt_load(self, buf):
+        """-> dict(chain_idx (-1: coefficient form), data [coeff_count], consumed)"""
+        Lb = load_library()
+        keep = _buf(buf)
+        ci, cnt, used = C.c_int(), C.c_uint64(), C.c_size_t()
+        _check(Lb.apsu_he_seal_pt_load(self.h, keep, C.c_size_t(len(buf)), C.byref(ci), C.byref(cnt), None, C.c_size_t(0), C.byref(used)))
+        data = np.empty(cnt.value, dtype=np.uint64)
+        _check(Lb.apsu_he_seal_pt_load(self.h, keep, C.c_size_t(len(buf)), C.byref(ci), C.byref(cnt), data.ctypes.data_as(u64p), C.c_size_t(data.size),
+                                       C.byref(used)))
+        return dict(chain_idx=ci.value, data=data, consumed=used.value)
+
+    def pt_save(self, chain_idx, data, compr=COMPR_NONE, version=(4, 0)):
+        """Plaintext::save: chain_idx -1 = coefficient form (parms_id zero), else NTT form at that level"""
+        data = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1)
+        out, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+        _check(load_library().apsu_he_seal_pt_save(self.h, int(chain_idx), data.ctypes.data_as(u64p), C.c_uint64(data.size), int(compr), version[0],
+                                                   version[1], C.byref(out), C.byref(size)))
+        return _take(out, size)
+
     def relin_keys_save(self, ksk, seeds=None, compr=COMPR_NONE, version=(4, 0)):
         ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
         sd = None
@@ -126,3 +145,14 @@ def run_query_request(ctx, seal_ctx, request, bundles, masks, compr=COMPR_NONE):
         L.apsu_he_wire_buffer_free(pk[i])
     return out
 
+
+
+def upload_bundle_serialized(ctx, seal_ctx, bundle_idx, cache_idx, blobs):
+    """apsu_he_db_upload_bundle_serialized: blobs[d] = the SEAL-serialised Plaintext the reference's BinBundle cache holds for coefficient d"""
+    from .engine import Bundle
+    keeps = [_buf(b) for b in blobs]
+    arr = (C.c_void_p * len(blobs))(*[C.cast(k, C.c_void_p) for k in keeps])
+    sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
+    h = C.c_void_p()
+    _check(load_library().apsu_he_db_upload_bundle_serialized(ctx.h, seal_ctx.h, bundle_idx, cache_idx, len(blobs), arr, sizes, C.byref(h)))
+    return Bundle(ctx, h, bundle_idx, cache_idx, len(blobs) - 1)

@@ -73,7 +73,8 @@ const char *apsu_he_last_error(void);
  * 4 (additive): ciphertexts of more than two polynomials for parameter sets without key switching -- apsu_he_multiply_sized,
  * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before.
  * apsu_he_algebraize_items (N1: item -> field elements); apsu_he_db_file_* / apsu_he_multi_db_load_file / _save_file (N2: the whole DB
- * in one mmap-able file). */
+ * in one mmap-able file); apsu_he_seal_pt_load / _save, apsu_he_db_upload_bundle_serialized (BinBundle caches as the reference stores
+ * them); zstd bodies in the SEAL codec. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -395,6 +396,17 @@ int apsu_he_seal_ct_load_unexpanded(const apsu_he_seal_ctx *c, const uint8_t *bu
  * apsu_he_seal_sample_poly_uniform(seed)) */
 int apsu_he_seal_ct_save(const apsu_he_seal_ctx *c, int chain_idx, int is_ntt_form, uint64_t ct_size, const uint64_t *data, const uint64_t *seed,
                          int compr_mode, int version_major, int version_minor, uint8_t **out, size_t *out_size);
+/* Plaintext::load / ::save (parms_id zero = coefficient form: *chain_idx = -1; else the level it was transformed at).  data NULL: only
+ * the dimensions.  These are the objects a BinBundle's cache holds per coefficient (bin_bundle.cpp:421-428, compr none or zstd). */
+int apsu_he_seal_pt_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, int *chain_idx, uint64_t *coeff_count, uint64_t *data,
+                         size_t data_capacity_words, size_t *consumed);
+int apsu_he_seal_pt_save(const apsu_he_seal_ctx *c, int chain_idx, const uint64_t *data, uint64_t coeff_count, int compr_mode, int version_major,
+                         int version_minor, uint8_t **out, size_t *out_size);
+/* apsu_he_db_upload_bundle from the reference's own representation: blobs[d] / blob_sizes[d] = batched_coeffs[d].data() / .size() of
+ * BatchedPlaintextPolyn (receiver/apsu/bin_bundle.h:52-134), i.e. SEAL-serialised Plaintexts; form and level are read from each
+ * object's parms_id and checked against the rule of bin_bundle.cpp:385-389,418-420.  No SEAL on the host.  (ABI 4) */
+int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
+                                        const uint8_t *const *blobs, const size_t *blob_sizes, apsu_he_bundle **out);
 /* RelinKeys::load -> ksk[K-1][2][K][n] (ksk NULL: only *words); ::save (seeds[K-1][8] or NULL) */
 int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,
                                  size_t *consumed);

@@ -271,3 +271,34 @@ def test_database_file_round_trip_and_rejections(tmp_path):
         G2.load_db_file(str(tmp_path / "missing"))
     for c in (G, G2, other):
         c.close()
+
+
+@pytest.mark.parametrize("compr", [0, 2])
+def test_bundle_upload_from_serialized_plaintexts(compr):
+    """apsu_he_db_upload_bundle_serialized: the BinBundle cache as the reference holds it -- one SEAL-serialised Plaintext per
+    coefficient (bin_bundle.cpp:421-428, compr_mode none, or zstd for the "-com" parameter sets) -- gives the same device
+    BinBundle as the raw-pointer upload; form and level come from each object's parms_id"""
+    from apsu_amd import seal
+    for js, degrees in ((common.toy_json(), [11, 3]), (common.toy_json(ps_low=0, max_items=6, query_powers=(1, 2, 3, 5)), [6])):
+        S = common.make_scenario(js, {0: degrees})
+        G = apsu_amd.HeContext(js)
+        sc = seal.SealContext(js)
+        rk = G.upload_relin_keys(S.rk)
+        pw = G.compute_powers([0], [[S.src[0][e] for e in S.sources]], rk)
+        pci = S.C.plain_chain_idx(S.ps_low)
+        for b in S.bundles:
+            blobs = [sc.pt_save(pci if f else -1, c, compr=compr) for c, f in zip(b["coeffs"], b["flags"])]
+            ser = seal.upload_bundle_serialized(G, sc, b["bundle_idx"], b["cache_idx"], blobs)
+            raw = G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"])
+            assert G.save_bundle(ser).tobytes() == G.save_bundle(raw).tobytes()
+            out = G.eval_bundles([ser], pw, rk, [b["mask"]])
+            assert (out[0] == common.oracle_eval(S, common.oracle_powers(S), b)).all()
+            # an NTT-form plaintext at another level than the BinBundle rule prescribes is refused
+            if any(b["flags"]) and pci > 0:
+                d = b["flags"].index(True)
+                wrong = list(blobs)
+                wrong[d] = sc.pt_save(pci - 1, b["coeffs"][d][:pci], compr=compr)
+                with pytest.raises(ValueError):
+                    seal.upload_bundle_serialized(G, sc, b["bundle_idx"], b["cache_idx"], wrong)
+        G.close()
+        sc.close()

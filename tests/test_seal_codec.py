@@ -235,6 +235,39 @@ def test_zstd_objects_both_directions(ctx):
             ctx.ct_load(MAGIC + bytes([4, 0, 2, 0, 0]) + struct.pack("<Q", 16 + len(bad)) + bad)
 
 
+def pt_members(parms_id, data, version):
+    return struct.pack("<4Q", *parms_id) + struct.pack("<Q", len(data)) + struct.pack("<d", 1.0) + dyn_array(data, version)
+
+
+@pytest.mark.parametrize("compr", [0, 1, 2])
+def test_plaintext_both_directions(ctx, compr):
+    """seal::Plaintext as a BinBundle cache stores it per coefficient (bin_bundle.cpp:421-428): coefficient form (parms_id zero)
+    and NTT form (the level's parms_id, one polynomial per prime)"""
+    if compr == 2 and _zstd() is None:
+        pytest.skip("libzstd.so.1 is not on this system")
+    rng = np.random.default_rng(31)
+    for version in ((4, 0), (3, 6)):
+        coeff = rng.integers(0, T, N, dtype=np.uint64)
+        blob = obj(pt_members([0, 0, 0, 0], coeff, version), compr, version)
+        got = ctx.pt_load(blob + b"x")
+        assert got["chain_idx"] == -1 and got["consumed"] == len(blob) and (got["data"] == coeff).all()
+        assert ctx.pt_save(-1, coeff, compr=compr, version=version) == blob
+        L = 2
+        ntt = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q[:L]])
+        blob = obj(pt_members(parms_id(N, Q[:L], T), ntt.reshape(-1), version), compr, version)
+        got = ctx.pt_load(blob)
+        assert got["chain_idx"] == L - 1 and (got["data"].reshape(L, N) == ntt).all()
+        assert ctx.pt_save(L - 1, ntt, compr=compr, version=version) == blob
+    with pytest.raises(apsu_amd.ApsuHeError):
+        ctx.pt_load(blob[:-9])
+    with pytest.raises(ValueError, match="parms_id"):
+        ctx.pt_load(obj(pt_members([5, 5, 5, 5], coeff, (4, 0)), 0))
+    with pytest.raises(apsu_amd.ApsuHeError, match="coeff_count"):
+        ctx.pt_load(obj(struct.pack("<4Q", 0, 0, 0, 0) + struct.pack("<Q", N + 1) + struct.pack("<d", 1.0) + dyn_array(coeff, (4, 0)), 0))
+    with pytest.raises(ValueError):
+        ctx.pt_save(1, coeff)                                         # an NTT-form plaintext at level 1 has 2 n words
+
+
 def test_ciphertext_rejects_malformed(ctx):
     rng = np.random.default_rng(3)
     pid = parms_id(N, Q[:2], T)
