@@ -881,6 +881,92 @@ int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk,
     });
 }
 // ---- Receiver::RunQuery from the wire (receiver_osn.cpp:160-364 + query.cpp:44-80 + result_package.cpp:29-76), without SEAL
+namespace {
+// The query of one request, decoded onto engine E's device: relinearisation keys in apsu_he_relin_upload's layout (empty without
+// key switching) and the source ciphertexts of the bundle indices `idx`, in (index, ascending exponent) order.
+struct DecodedQuery {
+    std::vector<uint64_t> relin_flat;
+    DevBuf dev;                              // [idx][source][2][first_L][n]
+    std::vector<const u64 *> src;            // device pointers into dev
+};
+void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size, const std::vector<uint32_t> &idx, DecodedQuery &out)
+{
+    const PSUParams *psu = E.psu();
+    REQUIRE(psu, "context was created without PSUParams");
+    const HeParams &hp = E.he();
+    REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
+    const size_t n = hp.n;
+    const int first = hp.first_chain_idx;
+    const size_t Lf = (size_t)first + 1, ct_words = 2 * Lf * n;
+    // Query::Query (receiver/apsu/query.cpp:44-80): relin keys, then one ciphertext per (exponent, bundle index)
+    const wire::QueryRequest q = wire::parse_query_request(request, request_size);
+    const auto &want = psu->query_params.query_powers;
+    if (q.parts.size() != want.size()) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
+    std::vector<const wire::QueryPart *> parts;                    // ascending exponent = the PowersDag's source order
+    for (uint32_t e : want) {
+        const wire::QueryPart *hit = nullptr;
+        for (const auto &p : q.parts) if (p.exponent == e) hit = &p;
+        if (!hit) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
+        if (hit->cts.size() != psu->bundle_idx_count) throw std::invalid_argument("one ciphertext per bundle index expected (query.cpp:69-74)");
+        parts.push_back(hit);
+    }
+    if (hp.using_keyswitching) {
+        if (!q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
+        const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
+        if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
+        out.relin_flat = sealio::relin_keys_layout(kk, sc->K, n);
+    }
+    if (idx.empty()) return;
+    // ciphertexts: c0 (and c1 when the object is not seeded) through page-locked memory, seeded c1 expanded on the device
+    struct OnDevice {                                              // allocations below belong to E's device, whatever the caller's thread had selected
+        int prev = -1;
+        explicit OnDevice(int dev) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != dev) { prev = cur; (void)hipSetDevice(dev); } }
+        ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } on_device(E.device());
+    const size_t n_cts = idx.size() * parts.size();
+    out.dev.alloc(n_cts * ct_words * sizeof(u64));
+    void *pinned = nullptr;
+    if (hipHostMalloc(&pinned, n_cts * ct_words * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+    struct Unpin { void *p; ~Unpin() { (void)hipHostFree(p); } } unpin{ pinned };
+    u64 *host = static_cast<u64 *>(pinned);
+    std::vector<uint64_t> seeds;
+    std::vector<u64 *> c1;
+    out.src.resize(n_cts);
+    hipStream_t st = E.stream();
+    for (size_t b = 0; b < idx.size(); b++)
+        for (size_t s2 = 0; s2 < parts.size(); s2++) {
+            const size_t k = b * parts.size() + s2;
+            const wire::Span blob = parts[s2]->cts[idx[b]];
+            const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
+            if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
+                throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
+            u64 *d = out.dev.u() + k * ct_words;
+            const size_t words = ct.seeded ? ct_words / 2 : ct_words;
+            std::memcpy(host + k * ct_words, ct.data.data(), words * sizeof(u64));
+            if (hipMemcpyAsync(d, host + k * ct_words, words * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) throw HipError("upload of a query ciphertext failed");
+            if (ct.seeded) { seeds.insert(seeds.end(), ct.seed, ct.seed + 8); c1.push_back(d + ct_words / 2); }
+            out.src[k] = d;
+        }
+    if (!c1.empty()) E.seed_expand(first, (int)c1.size(), seeds.data(), c1.data());
+    E.wait();                                                       // the page-locked staging dies with this call
+}
+
+// ResultPackage of one BinBundle (receiver_osn.cpp:507-539): its result ciphertext saved at the last level
+void result_package(const apsu_he_seal_ctx *sc, size_t n, uint32_t bundle_idx, uint32_t cache_idx, const u64 *row, uint32_t polys, int compr_mode,
+                    uint8_t **package, size_t *package_size)
+{
+    sealio::Ciphertext rc;
+    std::memcpy(rc.parms_id, seal_level(sc, 0).parms_id, 32);
+    rc.size = polys; rc.poly_modulus_degree = n; rc.coeff_modulus_size = 1;
+    rc.data.assign(row, row + (size_t)polys * n);
+    const std::vector<uint8_t> body = sealio::save_ciphertext(rc, (uint8_t)compr_mode);
+    wire::ResultPackage rp;
+    rp.bundle_idx = bundle_idx; rp.cache_idx = cache_idx;
+    rp.psu_result = wire::Span{ body.data(), body.size() };
+    wire_out(wire::build_result_package(rp), package, package_size);
+}
+} // namespace
+
 int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size,
                               const apsu_he_bundle *const *bundles, int count, const uint64_t *const *masks, int masks_on_device,
                               int result_compr_mode, uint8_t **packages, size_t *package_sizes)
@@ -888,83 +974,53 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
     return guarded([&] {
         REQUIRE(c && sc && request && count >= 0 && (count == 0 || (bundles && masks && packages && package_sizes)), "null argument");
         Engine &E = *c->eng;
-        const PSUParams *psu = E.psu();
-        REQUIRE(psu, "context was created without PSUParams");
-        const HeParams &hp = E.he();
-        REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
-        const size_t n = hp.n;
-        const int first = hp.first_chain_idx;
-        const size_t Lf = (size_t)first + 1, ct_words = 2 * Lf * n;
-        // Query::Query (receiver/apsu/query.cpp:44-80): relin keys, then one ciphertext per (exponent, bundle index)
-        const wire::QueryRequest q = wire::parse_query_request(request, request_size);
-        const auto &want = psu->query_params.query_powers;
-        if (q.parts.size() != want.size()) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
-        std::vector<const wire::QueryPart *> parts;                    // ascending exponent = the PowersDag's source order
-        for (uint32_t e : want) {
-            const wire::QueryPart *hit = nullptr;
-            for (const auto &p : q.parts) if (p.exponent == e) hit = &p;
-            if (!hit) throw std::invalid_argument("query powers do not match the parameters (query.cpp:63-68)");
-            if (hit->cts.size() != psu->bundle_idx_count) throw std::invalid_argument("one ciphertext per bundle index expected (query.cpp:69-74)");
-            parts.push_back(hit);
-        }
-        std::unique_ptr<RelinKeys> rk;
-        if (hp.using_keyswitching) {
-            if (!q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
-            const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
-            if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
-            const std::vector<uint64_t> flat = sealio::relin_keys_layout(kk, sc->K, n);
-            rk = E.upload_relin_keys(flat.data());
-        }
         // the bundle indices the given BinBundles need, ascending
         std::vector<uint32_t> idx;
         for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); idx.push_back(bundles[i]->b->bundle_idx); }
         std::sort(idx.begin(), idx.end());
         idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+        DecodedQuery dq;
+        decode_query(E, sc, request, request_size, idx, dq);
         if (idx.empty()) return;
-        // ciphertexts: c0 (and c1 when the object is not seeded) through page-locked memory, seeded c1 expanded on the device
-        const size_t n_cts = idx.size() * parts.size();
-        DevBuf dev(n_cts * ct_words * sizeof(u64));
-        void *pinned = nullptr;
-        if (hipHostMalloc(&pinned, n_cts * ct_words * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
-        struct Unpin { void *p; ~Unpin() { (void)hipHostFree(p); } } unpin{ pinned };
-        u64 *host = static_cast<u64 *>(pinned);
-        std::vector<uint64_t> seeds;
-        std::vector<u64 *> c1;
-        std::vector<const u64 *> src(n_cts);
-        hipStream_t st = E.stream();
-        for (size_t b = 0; b < idx.size(); b++)
-            for (size_t s2 = 0; s2 < parts.size(); s2++) {
-                const size_t k = b * parts.size() + s2;
-                const wire::Span blob = parts[s2]->cts[idx[b]];
-                const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
-                if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
-                    throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
-                u64 *d = dev.u() + k * ct_words;
-                const size_t words = ct.seeded ? ct_words / 2 : ct_words;
-                std::memcpy(host + k * ct_words, ct.data.data(), words * sizeof(u64));
-                if (hipMemcpyAsync(d, host + k * ct_words, words * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) throw HipError("upload of a query ciphertext failed");
-                if (ct.seeded) { seeds.insert(seeds.end(), ct.seed, ct.seed + 8); c1.push_back(d + ct_words / 2); }
-                src[k] = d;
-            }
-        if (!c1.empty()) E.seed_expand(first, (int)c1.size(), seeds.data(), c1.data());
-        std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), src.data(), true, rk.get());
+        std::unique_ptr<RelinKeys> rk;
+        if (!dq.relin_flat.empty()) rk = E.upload_relin_keys(dq.relin_flat.data());
+        std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), dq.src.data(), true, rk.get());
         std::vector<const Bundle *> bs(count);
         for (int i = 0; i < count; i++) bs[i] = bundles[i]->b.get();
-        const size_t R = E.result_polys();                                // 2 with key switching; longer results without
+        const size_t n = E.he().n, R = E.result_polys();                // 2 with key switching; longer results without
         std::vector<u64> out((size_t)count * R * n);
         E.eval_bundles(bs.data(), count, *pw, rk.get(), masks, masks_on_device != 0, out.data(), false);
         E.wait();                                                       // the device buffers of this call die with it
-        // ResultPackage per BinBundle (receiver_osn.cpp:507-539): the result ciphertext saved at the last level
+        for (int i = 0; i < count; i++)
+            result_package(sc, n, bs[i]->bundle_idx, bs[i]->cache_idx, out.data() + (size_t)i * R * n, E.result_size(*bs[i]), result_compr_mode, &packages[i],
+                           &package_sizes[i]);
+    });
+}
+
+// The same for the multi-device handle: the query is decoded once onto the first device (seeded c1 expanded there), the relinearisation
+// keys go to every device, the other devices fetch the ciphertexts of their bundle indices over xGMI (IO_SRC_ON_DEVICE), and every
+// BinBundle registered in the handle gets its ResultPackage, in id order.  masks: one per bundle id, host memory.
+int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size,
+                                    const uint64_t *const *masks, int result_compr_mode, uint8_t **packages, size_t *package_sizes, int capacity)
+{
+    return guarded([&] {
+        REQUIRE(m && sc && request, "null argument");
+        MultiEngine &M = *m->m;
+        const int count = M.bundle_count();
+        REQUIRE(count == 0 || (masks && packages && package_sizes && capacity >= count), "one mask and one package slot per registered BinBundle are needed");
+        Engine &E = M.engine(0);
+        std::vector<uint32_t> idx(M.psu().bundle_idx_count);            // eval_all takes the sources of every bundle index
+        for (uint32_t b = 0; b < idx.size(); b++) idx[b] = b;
+        DecodedQuery dq;
+        decode_query(E, sc, request, request_size, idx, dq);
+        if (!count) return;
+        if (!dq.relin_flat.empty()) M.upload_relin_keys(dq.relin_flat.data());
+        const size_t n = E.he().n, R = E.result_polys();
+        std::vector<u64> out((size_t)count * R * n);
+        M.eval_all(dq.src.data(), masks, out.data(), -1, MultiEngine::IO_SRC_ON_DEVICE, 0);
         for (int i = 0; i < count; i++) {
-            sealio::Ciphertext rc;
-            std::memcpy(rc.parms_id, seal_level(sc, 0).parms_id, 32);
-            rc.size = E.result_size(*bs[i]); rc.poly_modulus_degree = n; rc.coeff_modulus_size = 1;
-            rc.data.assign(out.begin() + (size_t)i * R * n, out.begin() + ((size_t)i * R + rc.size) * n);
-            const std::vector<uint8_t> body = sealio::save_ciphertext(rc, (uint8_t)result_compr_mode);
-            wire::ResultPackage rp;
-            rp.bundle_idx = bs[i]->bundle_idx; rp.cache_idx = bs[i]->cache_idx;
-            rp.psu_result = wire::Span{ body.data(), body.size() };
-            wire_out(wire::build_result_package(rp), &packages[i], &package_sizes[i]);
+            const Bundle &b = M.bundle(i);
+            result_package(sc, n, b.bundle_idx, b.cache_idx, out.data() + (size_t)i * R * n, E.result_size(b), result_compr_mode, &packages[i], &package_sizes[i]);
         }
     });
 }

@@ -41,6 +41,7 @@ public:
     void save_file(const std::string &path);                      // every registered BinBundle, in id order
     int bundle_count() const { return (int)where_.size(); }
     int bundle_device(int id) const { return where_.at(id).first; }
+    const Bundle &bundle(int id) const { const auto &w = where_.at(id); return *devs_[w.first]->bundles[w.second]; }
     void clear_bundles();
 
     // One query.  src_cts[b * source_count + s]: ciphertexts of every bundle index (each device reads its own);

@@ -156,3 +156,20 @@ def upload_bundle_serialized(ctx, seal_ctx, bundle_idx, cache_idx, blobs):
     h = C.c_void_p()
     _check(load_library().apsu_he_db_upload_bundle_serialized(ctx.h, seal_ctx.h, bundle_idx, cache_idx, len(blobs), arr, sizes, C.byref(h)))
     return Bundle(ctx, h, bundle_idx, cache_idx, len(blobs) - 1)
+
+
+def multi_run_query_request(multi, seal_ctx, request, masks, compr=COMPR_NONE):
+    """apsu_he_multi_run_query_request: QueryRequest bytes in -> one ResultPackage (bytes) per BinBundle registered in the handle"""
+    from .engine import _ptr_array
+    L = load_library()
+    cnt = multi.n_bundles
+    keep = _buf(request)
+    mk = [np.ascontiguousarray(m, dtype=np.uint64) for m in masks]
+    pk = (u8p * max(1, cnt))()
+    sz = (C.c_size_t * max(1, cnt))()
+    _check(L.apsu_he_multi_run_query_request(multi.h, seal_ctx.h, keep, C.c_size_t(len(request)), _ptr_array(mk), int(compr), pk, sz, cnt))
+    out = []
+    for i in range(cnt):
+        out.append(C.string_at(pk[i], sz[i]))
+        L.apsu_he_wire_buffer_free(pk[i])
+    return out

@@ -74,7 +74,7 @@ const char *apsu_he_last_error(void);
  * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before.
  * apsu_he_algebraize_items (N1: item -> field elements); apsu_he_db_file_* / apsu_he_multi_db_load_file / _save_file (N2: the whole DB
  * in one mmap-able file); apsu_he_seal_pt_load / _save, apsu_he_db_upload_bundle_serialized (BinBundle caches as the reference stores
- * them); zstd bodies in the SEAL codec. */
+ * them); zstd bodies in the SEAL codec; apsu_he_multi_run_query_request. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -428,6 +428,12 @@ int apsu_he_seed_expand(apsu_he_ctx *ctx, int chain_idx, int count, const uint64
 int apsu_he_run_query_request(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, const uint8_t *request, size_t request_size,
                               const apsu_he_bundle *const *bundles, int count, const uint64_t *const *masks, int masks_on_device,
                               int result_compr_mode, uint8_t **packages, size_t *package_sizes);
+/* The same for the multi-device handle: the request is decoded once onto the handle's first device (seeded c1
+ * expanded there), its RelinKeys go to every device, the other devices fetch the ciphertexts of their bundle indices over xGMI, and
+ * EVERY BinBundle registered in the handle gets its ResultPackage: packages[id] / package_sizes[id], capacity >= the handle's
+ * BinBundle count.  masks[id]: host memory.  (ABI 4) */
+int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *seal_ctx, const uint8_t *request, size_t request_size,
+                                    const uint64_t *const *masks, int result_compr_mode, uint8_t **packages, size_t *package_sizes, int capacity);
 /* round-2 entry points, kept: one unseeded ciphertext without a context (zlib bodies are inflated on load) */
 int apsu_he_wire_seal_ct_save(const uint64_t parms_id[4], int is_ntt_form, uint64_t ct_size, uint64_t poly_modulus_degree,
                               uint64_t coeff_modulus_size, uint64_t correction_factor, double scale, const uint64_t *data,

@@ -105,6 +105,15 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
         assert back["bundle_idx"] == b["bundle_idx"] and back["cache_idx"] == b["cache_idx"] and back["labels"] == []
         got = sc.ct_load(back["psu_result"])
         assert got["chain_idx"] == 0 and not got["seeded"] and (got["data"] == out[i]).all()
+    # ... and through the multi-device handle (query decoded on the first device, the others fetch over xGMI; {0, 0} rehearses two)
+    units = [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+    for devs in ([0], [0, 0]):
+        M = apsu_amd.MultiContext(js, devs)
+        slots = apsu_amd.partition_bundles(units, S.p["bundle_idx_count"], len(devs))
+        for i, b in enumerate(S.bundles):
+            M.upload_bundle(slots[i], b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"])
+        assert seal.multi_run_query_request(M, sc, msg, [b["mask"] for b in S.bundles], compr=compr) == pkgs, devs
+        M.close()
     # unseeded ciphertexts (a querier that saved plain Ciphertext objects) and SEAL 3.6 objects take the same call
     plain_parts = [(e, [sc.ct_save(first, False, expanded[(b, e)], compr=compr, version=(3, 6)) for b in range(S.p["bundle_idx_count"])])
                    for e in S.sources]
