@@ -155,6 +155,11 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // (the way the unrolled BEHZ finish has taken it since round 2): -0.035 +- 0.020 ms (-1.0 %) on the whole query,
         // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist
         if (const char *v = std::getenv("APSU_HE_RAW_TWIST")) raw_twist_ = std::atoi(v) != 0;
+        // ... in a grid order that puts the three workgroups of one (product, limb) pair -- which read the same operand limbs -- on one
+        // XCD (workgroups b and b + 8 share an XCD, hence its L2): -0.066 +- 0.019 and -0.033 +- 0.016 ms on the whole query in two
+        // in-process A/B runs (-1.4 %), level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
+        // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
+        if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
     }
     // level constants
@@ -1170,7 +1175,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 }
                 if (fuse_tensor_) {                                                                                              // :422/:424
                     PROF(P_NTT_FUSED, tj.size() * 3 * Ef);
-                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_);
+                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_, tensor_xcd_);
                 } else {
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
@@ -2072,7 +2077,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
                             PROF(P_NTT_FUSED, dmap.size());
                             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
-                                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_);
+                                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
                         } else {
                             { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
                             d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
@@ -2104,7 +2109,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         }
                         if (fuse_tensor_ && tj.size() == (size_t)NI) {
                             PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
-                            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_);
+                            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_);
                         } else {
                             if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
                             d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);

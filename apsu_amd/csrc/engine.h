@@ -293,6 +293,7 @@ private:
     void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
+    bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
     size_t eval_ws_budget_ = (size_t)6 << 30;
     bool raw_twist_ = true;           // inverse transforms in front of drop / mod-down kernels leave their twist to those kernels
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node

@@ -170,12 +170,27 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
 template <int LOGN, int T>
 __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
                                                    u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
-                                                   const int *__restrict__ modmap, int period)
+                                                   const int *__restrict__ modmap, int period, int xcd)
 {
     constexpr int N = 1 << LOGN;
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
     const int tid = threadIdx.x;
-    const size_t g = blockIdx.x;
+    size_t g = blockIdx.x;
+    if (xcd) {
+        // XCD-aware order: the three workgroups of one (product, limb) pair -- which read the same operand limbs -- sit 8 apart in
+        // the grid (workgroups b and b + 8 share an XCD, hence an L2): pair u = 8 blk + lane, polynomial pl at 24 blk + 8 pl + lane.
+        // (One product per block with lane = limb, so that all workgroups of limb e share an XCD and products with a common parent
+        //  find it in that L2 too, measured level against this: profiles/r03_ab_xcd.txt.)
+        const size_t pairs = n_tensor / 3, padded = (pairs + 7) / 8 * 24;
+        if (g < padded) {
+            const size_t blk = g / 24, rem = g - blk * 24, pl = rem >> 3, u = blk * 8 + (rem & 7);
+            if (u >= pairs) return;                                             // wave-uniform: the padding of the last block of 8 pairs
+            const size_t jb = u / (size_t)limbs, e = u - jb * limbs;
+            g = jb * 3 * limbs + pl * limbs + e;                                // the logical index every table below is laid out by
+        } else {
+            g = n_tensor + (g - padded);
+        }
+    }
     const int mv = modmap[g % (size_t)period];
     const NttTable tab = tabs[mv & NTT_MAP_MASK];
     if (g >= n_tensor) {                                                        // wave-uniform
@@ -212,11 +227,13 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
 }
 
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st)
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd)
 {
-    const size_t n_tensor = (size_t)njobs * 3 * limbs, count = n_tensor + n_plain;
-    if (!count) return;
-#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period); break;
+    const size_t n_tensor = (size_t)njobs * 3 * limbs;
+    const size_t count = (xcd ? (n_tensor / 3 + 7) / 8 * 24 : n_tensor) + n_plain;
+    if (!(n_tensor + n_plain)) return;
+    const int xm = xcd ? 1 : 0;
+#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period, xm); break;
     switch (logn) {
     T_CASE(14, 1024) T_CASE(13, 512) T_CASE(12, 256) T_CASE(11, 128) T_CASE(10, 64) T_CASE(8, 64) T_CASE(6, 64)
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);

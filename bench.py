@@ -190,11 +190,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The warm-up runs in the TIMED configuration: event profiling off, hence ComputePowers on its default two-stream walk.  (Until
+    # round 3 it ran with the NTT event sampling of the setup still on -- the one-stream walk -- so the first timed step was the
+    # first two-stream walk ever: second-lane arena growth, job-table uploads and event creation landed inside the timed
+    # region, 0.03-0.17 ms per step of `value` depending on the box, while latency_ms_sync and the phase timers were clean.)
+    if not args.no_profile:
+        take_profile()                             # setup launches go to the process totals only
+        ctx.profile_enable(0)
     for _ in range(args.warmup):
         step()
     fence()
-    if not args.no_profile:
-        take_profile()                             # setup + warm-up launches go to the process totals only
     # The timed region carries no HIP events at all.  The NTT launches (the roofline kernel) are bracketed by events on the
     # engine's stream in separate, untimed steps right after the closing fence (same process, same clocks: the chip has just
     # run K queries back to back): a sampled step runs ComputePowers on one stream, carries an event pair per launch
