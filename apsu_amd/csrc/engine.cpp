@@ -156,8 +156,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist
         if (const char *v = std::getenv("APSU_HE_RAW_TWIST")) raw_twist_ = std::atoi(v) != 0;
         // ... in a grid order that puts the three workgroups of one (product, limb) pair -- which read the same operand limbs -- on one
-        // XCD (workgroups b and b + 8 share an XCD, hence its L2): -0.066 +- 0.019 and -0.033 +- 0.016 ms on the whole query in two
-        // in-process A/B runs (-1.4 %), level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
+        // XCD (workgroups b and b + 8 share an XCD, hence its L2): -0.031 +- 0.007 ms (-0.9 %) on the whole query over three
+        // in-process A/B runs, level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
         // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
