@@ -441,6 +441,8 @@ int apsu_he_multi_create(const char *json, const int *devices, int n_devices, ap
 int apsu_he_multi_destroy(apsu_he_multi *m) { return guarded([&] { delete m; }); }
 int apsu_he_multi_device_count(const apsu_he_multi *m, int *n_devices)
 { return guarded([&] { REQUIRE(m && n_devices, "null argument"); *n_devices = m->m->device_count(); }); }
+int apsu_he_multi_result_polys(const apsu_he_multi *m, uint32_t *polys)
+{ return guarded([&] { REQUIRE(m && polys, "null argument"); *polys = m->m->engine(0).result_polys(); }); }
 int apsu_he_multi_relin_upload(apsu_he_multi *m, const uint64_t *ksk)
 { return guarded([&] { REQUIRE(m && ksk, "null argument"); m->m->upload_relin_keys(ksk); }); }
 int apsu_he_multi_db_upload_bundle(apsu_he_multi *m, int device_slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,

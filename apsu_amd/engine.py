@@ -570,6 +570,9 @@ class MultiContext:
         self.h = h
         self.devices = list(devices)
         self.n_bundles = 0
+        rp = C.c_uint32()
+        _check(L.apsu_he_multi_result_polys(self.h, C.byref(rp)))
+        self.result_polys = rp.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -624,7 +627,7 @@ class MultiContext:
         or writes to the device pointer out_ptr on devices[out_device_slot]"""
         if out_device_slot < 0:
             if out is None:
-                out = np.zeros((self.n_bundles, 2, 1, n), dtype=np.uint64)
+                out = np.zeros((self.n_bundles, self.result_polys, 1, n), dtype=np.uint64)
             outp = _p(out)
         else:
             out = None

@@ -251,6 +251,8 @@ int apsu_he_compute_powers_cost(const apsu_he_ctx *ctx, uint64_t *cost);
 int apsu_he_multi_create(const char *psu_params_json, const int *devices, int n_devices, apsu_he_multi **out);
 int apsu_he_multi_destroy(apsu_he_multi *m);
 int apsu_he_multi_device_count(const apsu_he_multi *m, int *n_devices);
+/* polynomials per output row of apsu_he_eval_all(_ex) = apsu_he_info.result_polys of the parameter set (2 with key switching) */
+int apsu_he_multi_result_polys(const apsu_he_multi *m, uint32_t *polys);
 /* the query's RelinKeys, replicated on every device (layout as apsu_he_relin_upload) */
 int apsu_he_multi_relin_upload(apsu_he_multi *m, const uint64_t *ksk);
 /* DB placement (ReceiverDB::generate_caches, receiver_db.cpp:808-820): as apsu_he_db_upload_bundle / _random_bundle on the
