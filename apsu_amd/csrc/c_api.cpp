@@ -809,40 +809,104 @@ int apsu_he_seal_pt_save(const apsu_he_seal_ctx *c, int chain_idx, const uint64_
 }
 // BinBundleCache::batched_matching_polyn as the reference holds it -- batched_coeffs[d] = a SEAL-serialised Plaintext
 // (bin_bundle.cpp:421-428, compr_mode none or zstd) -- straight into apsu_he_db_upload_bundle, without SEAL on the host
+static std::unique_ptr<Bundle> upload_serialized(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, uint32_t bundle_idx, uint32_t cache_idx,
+                                                 const std::vector<wire::Span> &blobs)
+{
+    const HeParams &hp = c->eng->he();
+    REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
+    const size_t n_coeffs = blobs.size();
+    REQUIRE(n_coeffs > 0, "a BinBundle has at least one coefficient");
+    std::vector<std::vector<uint64_t>> keep(n_coeffs);
+    std::vector<const uint64_t *> ptrs(n_coeffs);
+    std::vector<unsigned char> is_ntt(n_coeffs);
+    int ntt_level = -1;
+    for (size_t d = 0; d < n_coeffs; d++) {
+        REQUIRE(blobs[d].p, "null plaintext");
+        sealio::Plaintext pt = sealio::load_plaintext(blobs[d].p, blobs[d].n);
+        is_ntt[d] = pt.is_ntt_form() ? 1 : 0;
+        if (pt.is_ntt_form()) {
+            const int ci = seal_chain_idx(sc, pt.parms_id);
+            if (ci < 0 || ci > hp.first_chain_idx) throw std::invalid_argument("plaintext parms_id is not a data level of these parameters");
+            if (ntt_level >= 0 && ci != ntt_level) throw std::invalid_argument("the NTT-form plaintexts of a BinBundle share one level (bin_bundle.cpp:385-389)");
+            ntt_level = ci;
+            if (pt.coeff_count != (uint64_t)(ci + 1) * hp.n) throw std::invalid_argument("NTT-form plaintext has the wrong coefficient count");
+        } else {
+            if (pt.coeff_count > hp.n) throw std::invalid_argument("coefficient-form plaintext is longer than the ring");
+            pt.data.resize(hp.n, 0);                                 // BatchEncoder::encode writes n coefficients; shorter ones are zero-extended
+        }
+        keep[d] = std::move(pt.data);
+        ptrs[d] = keep[d].data();
+    }
+    std::unique_ptr<Bundle> b = c->eng->upload_bundle(bundle_idx, cache_idx, (uint32_t)n_coeffs, ptrs.data(), is_ntt.data());
+    if (ntt_level >= 0 && b->pt_level != ntt_level)
+        throw std::invalid_argument("the NTT-form plaintexts are not at the level the BinBundle rule prescribes (bin_bundle.cpp:385-389)");
+    return b;
+}
 int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
                                         const uint8_t *const *blobs, const size_t *blob_sizes, apsu_he_bundle **out)
 {
     return guarded([&] {
         REQUIRE(c && sc && blobs && blob_sizes && out && n_coeffs > 0, "null argument");
-        const HeParams &hp = c->eng->he();
-        REQUIRE(sc->n == hp.n && sc->K == (size_t)hp.K && sc->t == hp.t, "the SEAL context belongs to other parameters");
-        std::vector<std::vector<uint64_t>> keep(n_coeffs);
-        std::vector<const uint64_t *> ptrs(n_coeffs);
-        std::vector<unsigned char> is_ntt(n_coeffs);
-        int ntt_level = -1;
-        for (uint32_t d = 0; d < n_coeffs; d++) {
-            REQUIRE(blobs[d], "null plaintext");
-            sealio::Plaintext pt = sealio::load_plaintext(blobs[d], blob_sizes[d]);
-            is_ntt[d] = pt.is_ntt_form() ? 1 : 0;
-            if (pt.is_ntt_form()) {
-                const int ci = seal_chain_idx(sc, pt.parms_id);
-                if (ci < 0 || ci > hp.first_chain_idx) throw std::invalid_argument("plaintext parms_id is not a data level of these parameters");
-                if (ntt_level >= 0 && ci != ntt_level) throw std::invalid_argument("the NTT-form plaintexts of a BinBundle share one level (bin_bundle.cpp:385-389)");
-                ntt_level = ci;
-                if (pt.coeff_count != (uint64_t)(ci + 1) * hp.n) throw std::invalid_argument("NTT-form plaintext has the wrong coefficient count");
-            } else {
-                if (pt.coeff_count > hp.n) throw std::invalid_argument("coefficient-form plaintext is longer than the ring");
-                pt.data.resize(hp.n, 0);                                 // BatchEncoder::encode writes n coefficients; shorter ones are zero-extended
-            }
-            keep[d] = std::move(pt.data);
-            ptrs[d] = keep[d].data();
+        std::vector<wire::Span> spans(n_coeffs);
+        for (uint32_t d = 0; d < n_coeffs; d++) spans[d] = wire::Span{ blobs[d], blob_sizes[d] };
+        auto b = new apsu_he_bundle;
+        try { b->b = upload_serialized(c, sc, bundle_idx, cache_idx, spans); } catch (...) { delete b; throw; }
+        *out = b;
+    });
+}
+// One BinBundle as ReceiverDB::save wrote it (bin_bundle.fbs; BinBundle::save bin_bundle.cpp:1085-1168): dimensions only
+int apsu_he_wire_bin_bundle_info(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint64_t *mod, int *stripped, uint32_t *n_bins,
+                                 uint32_t *largest_bin, uint32_t *cache_coeffs, size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        const wire::SavedBinBundle sb = wire::parse_bin_bundle(buf, size);
+        if (bundle_idx) *bundle_idx = sb.bundle_idx;
+        if (mod) *mod = sb.mod;
+        if (stripped) *stripped = sb.stripped ? 1 : 0;
+        if (n_bins) *n_bins = (uint32_t)sb.item_bins.size();
+        if (largest_bin) { size_t m = 0; for (const auto &b : sb.item_bins) m = std::max(m, b.size()); *largest_bin = (uint32_t)m; }
+        if (cache_coeffs) *cache_coeffs = sb.has_cache ? (uint32_t)sb.batched_coeffs.size() : 0;
+        if (consumed) *consumed = sb.consumed;
+    });
+}
+// ... and onto the device: from its saved cache when there is one (no SEAL, no flatbuffers on the host), else rebuilt from the item
+// bins on the GPU (N1).  The checks are BinBundle::load's (bin_bundle.cpp:1170-1230): field modulus, number of bins, bin sizes.
+int apsu_he_db_upload_saved_bundle(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const uint8_t *buf, size_t size, uint32_t cache_idx,
+                                   apsu_he_bundle **out, size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(c && buf && out, "null argument");
+        const PSUParams *psu = c->eng->psu();
+        REQUIRE(psu, "context was created without PSUParams");
+        const wire::SavedBinBundle sb = wire::parse_bin_bundle(buf, size);
+        auto fail = [](const char *why) { throw std::runtime_error(std::string("failed to load BinBundle: ") + why); };
+        if (sb.mod != c->eng->he().t) fail("the field modulus differs from the plain_modulus of these parameters");
+        if (sb.bundle_idx >= psu->bundle_idx_count) fail("bundle index out of range");
+        if (!sb.stripped) {
+            if (sb.item_bins.size() != psu->bins_per_bundle) fail("wrong number of item bins");
+            for (const auto &bin : sb.item_bins) if (bin.size() > psu->table_params.max_items_per_bin) fail("an item bin exceeds max_items_per_bin");
         }
         auto b = new apsu_he_bundle;
         try {
-            b->b = c->eng->upload_bundle(bundle_idx, cache_idx, n_coeffs, ptrs.data(), is_ntt.data());
-            if (ntt_level >= 0 && b->b->pt_level != ntt_level) throw std::invalid_argument("the NTT-form plaintexts are not at the level the BinBundle rule prescribes (bin_bundle.cpp:385-389)");
+            if (sb.has_cache) {
+                REQUIRE(sc, "the saved cache holds SEAL objects: a SEAL context is needed");
+                b->b = upload_serialized(c, sc, sb.bundle_idx, cache_idx, sb.batched_coeffs);
+            } else {
+                if (sb.stripped) fail("a stripped BinBundle without its cache cannot be evaluated");
+                size_t stride = 1;
+                for (const auto &bin : sb.item_bins) stride = std::max(stride, bin.size());
+                std::vector<uint64_t> roots(sb.item_bins.size() * stride, 0);
+                std::vector<uint32_t> counts(sb.item_bins.size());
+                for (size_t i = 0; i < sb.item_bins.size(); i++) {
+                    counts[i] = (uint32_t)sb.item_bins[i].size();
+                    std::copy(sb.item_bins[i].begin(), sb.item_bins[i].end(), roots.begin() + i * stride);
+                }
+                b->b = c->eng->build_bundle(sb.bundle_idx, cache_idx, roots.data(), counts.data(), (uint32_t)counts.size(), (uint32_t)stride);
+            }
         } catch (...) { delete b; throw; }
         *out = b;
+        if (consumed) *consumed = sb.consumed;
     });
 }
 int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,

@@ -161,6 +161,20 @@ struct Reader {
         return t.pos + off;
     }
     uint32_t get_u32(const Table &t, int id, uint32_t dflt) const { const size_t p = field(t, id, 4); return p ? u32(p) : dflt; }
+    uint64_t u64(size_t off) const { need(off, 8); if (off % 8) bad(); uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | b[off + i]; return v; }
+    uint64_t get_u64(const Table &t, int id, uint64_t dflt) const { const size_t p = field(t, id, 8); return p ? u64(p) : dflt; }
+    // [uint64]: length, then the elements at an 8-byte aligned position
+    std::vector<uint64_t> u64_vector(size_t pos) const
+    {
+        const uint32_t len = u32(pos);
+        if ((uint64_t)len * 8 > n) bad();
+        need(pos + 4, (size_t)len * 8);
+        if (len && (pos + 4) % 8) bad();
+        visit(len / 4 + 1);
+        std::vector<uint64_t> out(len);
+        for (uint32_t i = 0; i < len; i++) out[i] = u64(pos + 4 + 8 * (size_t)i);
+        return out;
+    }
     uint8_t get_u8(const Table &t, int id, uint8_t dflt) const { const size_t p = field(t, id, 1); return p ? u8(p) : dflt; }
     // offset field -> absolute position of the child, 0 when absent; required fields must be present
     size_t child(const Table &t, int id, bool required) const
@@ -355,6 +369,37 @@ ResultPackage parse_result_package(const uint8_t *buf, size_t size)
     if (const size_t lv = r.child(t, 5, false))
         for (size_t cpos : r.table_vector(lv)) p.label_result.push_back(r.ciphertext(cpos));
     return p;
+}
+
+// ================================================================================================ a saved BinBundle
+SavedBinBundle parse_bin_bundle(const uint8_t *buf, size_t size)
+{
+    // ReceiverDB::save writes the BinBundles one after the other: this one ends where its size prefix says
+    if (!buf || size < 8) throw std::runtime_error("failed to load BinBundle: invalid buffer");
+    const uint64_t body = (uint64_t)buf[0] | ((uint64_t)buf[1] << 8) | ((uint64_t)buf[2] << 16) | ((uint64_t)buf[3] << 24);
+    if (body + 4 > size) throw std::runtime_error("failed to load BinBundle: invalid buffer");
+    Reader r{ buf, (size_t)body + 4, "BinBundle" };
+    const Reader::Table t = r.table(r.root());
+    SavedBinBundle out;
+    out.consumed = (size_t)body + 4;
+    out.bundle_idx = r.get_u32(t, 0, 0);
+    out.mod = r.get_u64(t, 1, 0);
+    out.stripped = r.get_u8(t, 5, 0) != 0;
+    {
+        const Reader::Table m = r.table(r.child(t, 2, true));                       // item_bins
+        for (size_t row : r.table_vector(r.child(m, 0, true))) {
+            const Reader::Table a = r.table(row);
+            out.item_bins.push_back(r.u64_vector(r.child(a, 0, true)));
+        }
+    }
+    if (const size_t cpos = r.child(t, 4, false)) {
+        const Reader::Table c = r.table(cpos);
+        (void)r.child(c, 0, true);                                                  // felt_matching_polyns: required, not needed here
+        const Reader::Table bp = r.table(r.child(c, 1, true));                      // batched_matching_polyn
+        for (size_t ppos : r.table_vector(r.child(bp, 0, true))) out.batched_coeffs.push_back(r.ciphertext(ppos));   // Plaintext { data } has Ciphertext's shape
+        out.has_cache = true;
+    }
+    return out;
 }
 
 } // namespace wire

@@ -55,5 +55,24 @@ struct ResultPackage {
 std::vector<uint8_t> build_result_package(const ResultPackage &r);
 ResultPackage parse_result_package(const uint8_t *buf, size_t size);
 
+// receiver/apsu/bin_bundle.fbs -- what ReceiverDB::save appends per BinBundle (BinBundle::save, bin_bundle.cpp:1085-1168; size-prefixed):
+//   BinBundle { bundle_idx:uint32; mod:uint64; item_bins:FEltMatrix (required); label_bins:[FEltMatrix]; cache:BinBundleCache; stripped:bool }
+//   FEltMatrix { rows:[FEltArray] (required) }   FEltArray { felts:[uint64] (required) }
+//   BinBundleCache { felt_matching_polyns:FEltMatrix (required); batched_matching_polyn:BatchedPlaintextPolyn (required); ... }
+//   BatchedPlaintextPolyn { coeffs:[Plaintext] (required) }   Plaintext { data:[ubyte] (required) }   (SEAL-serialised seal::Plaintext)
+// The hot path needs the cache's batched matching polynomial (-> apsu_he_db_upload_bundle_serialized) or, when the cache was not
+// saved, the item bins (-> apsu_he_db_build_bundle rebuilds it on the GPU).  Labels and interpolation polynomials are not read
+// (APSU is the unlabeled protocol on this path).
+struct SavedBinBundle {
+    uint32_t bundle_idx = 0;
+    uint64_t mod = 0;
+    bool stripped = false, has_cache = false;
+    std::vector<std::vector<uint64_t>> item_bins;        // [bin] -> field elements
+    std::vector<Span> batched_coeffs;                    // cache.batched_matching_polyn.coeffs[d].data
+    size_t consumed = 0;                                 // bytes of the buffer this BinBundle occupies (prefix included)
+};
+// throws std::runtime_error("failed to load BinBundle: invalid buffer")
+SavedBinBundle parse_bin_bundle(const uint8_t *buf, size_t size);
+
 } // namespace wire
 } // namespace apsu_he

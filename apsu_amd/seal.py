@@ -173,3 +173,16 @@ def multi_run_query_request(multi, seal_ctx, request, masks, compr=COMPR_NONE):
         out.append(C.string_at(pk[i], sz[i]))
         L.apsu_he_wire_buffer_free(pk[i])
     return out
+
+
+def upload_saved_bundle(ctx, seal_ctx, buf, cache_idx=0):
+    """apsu_he_db_upload_saved_bundle: a BinBundle as the reference persists it -> (Bundle on the device, bytes consumed)"""
+    from .engine import Bundle
+    keep = _buf(buf)
+    h, used, deg = C.c_void_p(), C.c_size_t(), C.c_uint32()
+    _check(load_library().apsu_he_db_upload_saved_bundle(ctx.h, seal_ctx.h if seal_ctx is not None else None, keep, C.c_size_t(len(buf)), int(cache_idx),
+                                                        C.byref(h), C.byref(used)))
+    _check(load_library().apsu_he_bundle_degree(h, C.byref(deg)))
+    bi = C.c_uint32()
+    _check(load_library().apsu_he_wire_bin_bundle_info(keep, C.c_size_t(len(buf)), C.byref(bi), None, None, None, None, None, None))
+    return Bundle(ctx, h, bi.value, int(cache_idx), deg.value), used.value

@@ -135,3 +135,14 @@ def seal_ct_load(buf):
                                        C.byref(vmin)))
     return dict(parms_id=list(pid), is_ntt_form=bool(ntt.value), data=data, correction_factor=cf.value, scale=sc.value,
                 version=(vmaj.value, vmin.value))
+
+
+def bin_bundle_info(buf):
+    """one BinBundle as ReceiverDB::save wrote it (bin_bundle.fbs) -> dict(bundle_idx, mod, stripped, n_bins, largest_bin, cache_coeffs, consumed)"""
+    keep = _buf(buf)
+    bi, nb, lb, cc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    mod, st, used = C.c_uint64(), C.c_int(), C.c_size_t()
+    _check(load_library().apsu_he_wire_bin_bundle_info(keep, C.c_size_t(len(buf)), C.byref(bi), C.byref(mod), C.byref(st), C.byref(nb), C.byref(lb),
+                                                      C.byref(cc), C.byref(used)))
+    return dict(bundle_idx=bi.value, mod=mod.value, stripped=bool(st.value), n_bins=nb.value, largest_bin=lb.value, cache_coeffs=cc.value,
+                consumed=used.value)

@@ -74,7 +74,8 @@ const char *apsu_he_last_error(void);
  * apsu_he_power_size, apsu_he_bundle_result_size, apsu_he_info.result_polys (the former `reserved`); those sets were refused before.
  * apsu_he_algebraize_items (N1: item -> field elements); apsu_he_db_file_* / apsu_he_multi_db_load_file / _save_file (N2: the whole DB
  * in one mmap-able file); apsu_he_seal_pt_load / _save, apsu_he_db_upload_bundle_serialized (BinBundle caches as the reference stores
- * them); zstd bodies in the SEAL codec; apsu_he_multi_run_query_request. */
+ * them), apsu_he_db_upload_saved_bundle (a BinBundle as ReceiverDB::save wrote it); zstd bodies in the SEAL codec;
+ * apsu_he_multi_run_query_request, apsu_he_multi_result_polys. */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -409,6 +410,17 @@ int apsu_he_seal_pt_save(const apsu_he_seal_ctx *c, int chain_idx, const uint64_
  * object's parms_id and checked against the rule of bin_bundle.cpp:385-389,418-420.  No SEAL on the host.  (ABI 4) */
 int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
                                         const uint8_t *const *blobs, const size_t *blob_sizes, apsu_he_bundle **out);
+/* One BinBundle as the reference persists it: the size-prefixed FlatBuffers buffer BinBundle::save appends to a saved ReceiverDB
+ * (receiver/apsu/bin_bundle.fbs; bin_bundle.cpp:1085-1168; ReceiverDB::save receiver_db.cpp:1182-1260 writes them one after the
+ * other behind its own header).  apsu_he_wire_bin_bundle_info: its dimensions and *consumed = where the next one starts.
+ * apsu_he_db_upload_saved_bundle: onto the device -- from the saved cache when there is one (SEAL Plaintext objects, read by the
+ * codec above: seal_ctx required), else rebuilt from the item bins on the GPU (apsu_he_db_build_bundle); the checks of
+ * BinBundle::load (bin_bundle.cpp:1170-1230: field modulus, number of bins, bin sizes) -> APSU_HE_RUNTIME_ERROR "failed to load
+ * BinBundle".  Labels and interpolation polynomials are not read (the unlabeled protocol).  (ABI 4) */
+int apsu_he_wire_bin_bundle_info(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint64_t *mod, int *stripped, uint32_t *n_bins,
+                                 uint32_t *largest_bin, uint32_t *cache_coeffs, size_t *consumed);
+int apsu_he_db_upload_saved_bundle(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, const uint8_t *buf, size_t size, uint32_t cache_idx,
+                                   apsu_he_bundle **out, size_t *consumed);
 /* RelinKeys::load -> ksk[K-1][2][K][n] (ksk NULL: only *words); ::save (seeds[K-1][8] or NULL) */
 int apsu_he_seal_relin_keys_load(const apsu_he_seal_ctx *c, const uint8_t *buf, size_t size, uint64_t *ksk, size_t capacity_words, size_t *words,
                                  size_t *consumed);

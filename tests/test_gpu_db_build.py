@@ -302,3 +302,51 @@ def test_bundle_upload_from_serialized_plaintexts(compr):
                     seal.upload_bundle_serialized(G, sc, b["bundle_idx"], b["cache_idx"], wrong)
         G.close()
         sc.close()
+
+
+def test_upload_of_a_bin_bundle_as_the_reference_persists_it():
+    """apsu_he_db_upload_saved_bundle: the FlatBuffers buffer BinBundle::save appends to a saved ReceiverDB (bin_bundle.fbs) -- with its
+    cache (SEAL Plaintext objects -> the serialized upload) and without (item bins -> rebuilt on the GPU) -- against the direct
+    uploads; BinBundle::load's checks"""
+    from apsu_amd import seal, wire
+    from test_wire_framing import build_bin_bundle
+    js = common.toy_json()
+    p = ref.load_params(js)
+    C = ref.RefContext.from_params(p)
+    n, t = C.n, C.t
+    G = apsu_amd.HeContext(js)
+    sc = seal.SealContext(js)
+    rng = np.random.default_rng(17)
+    bins_per_bundle = (n // p["felts_per_item"]) * p["felts_per_item"]
+    bins = [sorted(set(int(v) for v in rng.integers(1, t, int(rng.integers(0, p["max_items_per_bin"] + 1))))) for _ in range(bins_per_bundle)]
+    bins[0] = sorted(set(int(v) for v in rng.integers(1, t, p["max_items_per_bin"])))          # one bin as full as the draw allows
+    A, coeffs, flags = oracle_build(C, p["ps_low_degree"], bins)
+    pci = C.plain_chain_idx(p["ps_low_degree"])
+    direct = G.build_bundle(1, 0, bins)
+    # (a) without the cache: rebuilt from the item bins
+    buf = build_bin_bundle(1, t, bins)
+    got, used = seal.upload_saved_bundle(G, None, buf + b"next")
+    assert used == len(buf) and (got.bundle_idx, got.degree) == (1, direct.degree)
+    assert G.save_bundle(got).tobytes() == G.save_bundle(direct).tobytes()
+    # (b) with the cache: the serialized plaintexts, zstd like the "-com" sets when the library is there
+    for compr in (0, 2):
+        blobs = [sc.pt_save(pci if f else -1, c, compr=compr) for c, f in zip(coeffs, flags)]
+        buf = build_bin_bundle(1, t, bins, blobs)
+        info = wire.bin_bundle_info(buf)
+        assert info["cache_coeffs"] == len(coeffs) and info["n_bins"] == bins_per_bundle and info["largest_bin"] == max(len(b) for b in bins)
+        got, used = seal.upload_saved_bundle(G, sc, buf)
+        assert used == len(buf) and G.save_bundle(got).tobytes() == G.save_bundle(G.upload_bundle(1, 0, coeffs, flags)).tobytes()
+        with pytest.raises(ValueError, match="SEAL context"):
+            seal.upload_saved_bundle(G, None, buf)
+    # (c) stripped with cache: loads; stripped without: nothing to evaluate
+    got, _ = seal.upload_saved_bundle(G, sc, build_bin_bundle(1, t, [], blobs, stripped=True))
+    assert got.degree == direct.degree
+    for bad, why in ((build_bin_bundle(1, t, [], None, stripped=True), "stripped"),
+                     (build_bin_bundle(1, t + 2, bins), "field modulus"),
+                     (build_bin_bundle(1, t, bins[:-1]), "number of item bins"),
+                     (build_bin_bundle(1, t, [list(range(1, p["max_items_per_bin"] + 2))] + bins[1:]), "max_items_per_bin"),
+                     (build_bin_bundle(p["bundle_idx_count"], t, bins), "bundle index")):
+        with pytest.raises(apsu_amd.ApsuHeError, match=why):
+            seal.upload_saved_bundle(G, sc, bad)
+    G.close()
+    sc.close()

@@ -39,6 +39,13 @@ class FbBuilder:
         self._push(struct.pack("<I", len(data)))
         return self.off()
 
+    def u64_vector(self, vals):
+        self._prep(8, 8 * len(vals))
+        for v in reversed(vals):
+            self._push(struct.pack("<Q", int(v)))
+        self._push(struct.pack("<I", len(vals)))
+        return self.off()
+
     def offset_vector(self, offs):
         self._prep(4, 4 * len(offs))
         for o in reversed(offs):
@@ -52,12 +59,16 @@ class FbBuilder:
         # inline data, written back to front: large fields first so they end up aligned
         slots = {}
         end0 = None
-        order = sorted([i for i, f in enumerate(fields) if f is not None], key=lambda i: (fields[i][0] == "u8", i))
+        size_of = {"u64": 8, "u32": 4, "off": 4, "u8": 1}
+        order = sorted([i for i, f in enumerate(fields) if f is not None], key=lambda i: (-size_of[fields[i][0]], i))
         for i in reversed(order):
             kind, v = fields[i]
             if kind == "u8":
                 self._prep(1, 0)
                 self._push(struct.pack("<B", v))
+            elif kind == "u64":
+                self._prep(8, 0)
+                self._push(struct.pack("<Q", v))
             elif kind == "u32":
                 self._prep(4, 0)
                 self._push(struct.pack("<I", v))
@@ -66,7 +77,7 @@ class FbBuilder:
                 self._push(struct.pack("<I", self.off() + 4 - v))
             slots[i] = self.off()
             if end0 is None:
-                end0 = self.off() - (1 if kind == "u8" else 4)
+                end0 = self.off() - size_of[kind]
         if end0 is None:
             end0 = self.off()
         self._prep(4, 0)
@@ -312,3 +323,54 @@ def test_shared_children_cannot_amplify_parse_work():
     # a legitimate message of the same size class still parses
     big = model_query_request(0, None, [(e + 1, [b"c" * 16] * 4) for e in range(1000)])
     assert len(wire.parse_query_request(big)[2]) == 1000
+
+
+# --------------------------------------------------------------------------------------------- a saved BinBundle (bin_bundle.fbs)
+def build_bin_bundle(bundle_idx, mod, bins, coeff_blobs=None, stripped=False):
+    """the model's BinBundle::save (bin_bundle.cpp:1085-1168): item bins, optionally the cache's batched matching polynomial"""
+    B = FbBuilder()
+    cache = None
+    if coeff_blobs is not None:
+        pts = [B.table([("off", B.byte_vector(blob))]) for blob in coeff_blobs]
+        bp = B.table([("off", B.offset_vector(pts))])
+        fm = B.table([("off", B.offset_vector([]))])                 # felt_matching_polyns: required, unused on the hot path
+        cache = B.table([("off", fm), ("off", bp)])
+    rows = [B.table([("off", B.u64_vector(b))]) for b in bins]
+    items = B.table([("off", B.offset_vector(rows))])
+    root = B.table([("u32", bundle_idx) if bundle_idx else None, ("u64", mod), ("off", items), None, ("off", cache) if cache is not None else None,
+                    ("u8", 1) if stripped else None])
+    return B.finish_size_prefixed(root)
+
+
+def test_saved_bin_bundle_reader():
+    """bin_bundle.fbs as ReceiverDB::save persists it: dimensions, concatenation (*consumed), malformed buffers"""
+    bins = [[5, 7, 11], [], [2**40 + 3], list(range(1, 9))]
+    blobs = [bytes([i]) * (10 + i) for i in range(4)]
+    a = build_bin_bundle(3, 65537, bins, blobs)
+    b = build_bin_bundle(0, 65537, bins[:2])
+    c = build_bin_bundle(1, 65537, [], blobs[:1], stripped=True)
+    ia = wire.bin_bundle_info(a + b + c)
+    assert ia == dict(bundle_idx=3, mod=65537, stripped=False, n_bins=4, largest_bin=8, cache_coeffs=4, consumed=len(a))
+    ib = wire.bin_bundle_info((a + b + c)[ia["consumed"]:])
+    assert ib == dict(bundle_idx=0, mod=65537, stripped=False, n_bins=2, largest_bin=3, cache_coeffs=0, consumed=len(b))
+    ic = wire.bin_bundle_info(c)
+    assert ic["stripped"] and ic["n_bins"] == 0 and ic["cache_coeffs"] == 1 and ic["bundle_idx"] == 1
+    # the model reads back what it wrote (independent of the library)
+    R = FbReader(a)
+    root = R.root()
+    assert R.get_u32(root, 0, 0) == 3 and struct.unpack_from("<Q", a, R.field(root, 1))[0] == 65537
+    for bad in (a[:-1], a[:len(a) // 2], a[:4] + b"\xff\xff\xff\x7f" + a[8:], b"", a[:7]):
+        with pytest.raises(RuntimeError):
+            wire.bin_bundle_info(bad)
+    rng = np.random.default_rng(4)
+    ok = 0
+    for _ in range(1500):                                             # corruption never crashes: parses or raises
+        m = bytearray(a)
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(4, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            wire.bin_bundle_info(bytes(m))
+            ok += 1
+        except RuntimeError:
+            pass
+    assert ok < 1500
