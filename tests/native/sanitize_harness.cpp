@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -113,10 +114,21 @@ int main(int argc, char **argv)
         if (sealio::relin_keys_layout(sealio::load_kswitch_keys(kb.data(), kb.size(), chain), 3, 64).size() != 2 * 2 * 3 * 64) return 14;
         rej += fuzz(kb, [&](const uint8_t *p, size_t n) { (void)sealio::load_kswitch_keys(p, n, chain); }, 8000);
     }
+    // ---- saved BinBundles (bin_bundle.fbs; the library has no writer for them): seeds written by the test's FlatBuffers model
+    for (int i = 1; i < argc; i++) {
+        const std::string name = argv[i];
+        if (name.size() < 10 || name.substr(name.size() - 10) != ".binbundle") continue;
+        std::ifstream f(name, std::ios::binary);
+        std::vector<uint8_t> seed((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const wire::SavedBinBundle sb = wire::parse_bin_bundle(seed.data(), seed.size());
+        if (sb.consumed != seed.size() || sb.item_bins.empty()) return 15;
+        rej += fuzz(seed, [](const uint8_t *p, size_t n) { (void)wire::parse_bin_bundle(p, n); }, 30000);
+    }
     std::printf("wire: %d malformed buffers rejected, none crashed\n", rej);
 
     // ---- PSUParams JSON + derived constants + PowersDag for the parameter files given on the command line
     for (int i = 1; i < argc; i++) {
+        if (std::string(argv[i]).size() >= 10 && std::string(argv[i]).substr(std::string(argv[i]).size() - 10) == ".binbundle") continue;
         std::ifstream f(argv[i]);
         std::stringstream ss; ss << f.rdbuf();
         PSUParams p = PSUParams::Load(ss.str());

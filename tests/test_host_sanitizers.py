@@ -18,7 +18,14 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
           [os.path.join(SRC, f) for f in ("wire.cpp", "seal_codec.cpp", "params.cpp", "powers_dag.cpp", "sharding.cpp")] + ["-lz", "-ldl", "-o", exe]
     subprocess.check_call(cmd)
     params = [os.path.join(ROOT, "tests", "params", f + ".json") for f in ("100K-1", "1M-1024-com", "1M-4096-32", "256M-4096")]
+    # seeds for the saved-BinBundle reader come from the FlatBuffers model of tests/test_wire_framing.py (with and without a cache)
+    from test_wire_framing import build_bin_bundle
+    seeds = []
+    for i, blobs in enumerate((None, [bytes([7]) * 40, bytes([9]) * 13])):
+        path = tmp_path / ("seed%d.binbundle" % i)
+        path.write_bytes(build_bin_bundle(2, 65537, [[5, 7, 11], [], [2**40 + 3], list(range(1, 9))], blobs))
+        seeds.append(str(path))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([exe] + params, capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([exe] + params + seeds, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     assert r.stdout.strip().endswith("ok") and "malformed buffers rejected" in r.stdout
