@@ -854,6 +854,129 @@ int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *c, const apsu_he_seal_ctx *
         *out = b;
     });
 }
+// ---- PSUParams in their binary form (psu_params.fbs + SEAL's EncryptionParameters object): the parameter exchange and a saved ReceiverDB
+namespace {
+// -> the JSON form PSUParams::Load(json) / apsu_he_create take (psu_params.cpp:290-374).  The JSON names the coefficient primes by
+// their bit sizes (CoeffModulus::Create picks the primes), so the binary form's explicit primes must be exactly those.
+std::string psu_params_to_json(const wire::PsuParamsWire &w)
+{
+    const sealio::EncryptionParameters e = sealio::load_encryption_parameters(w.seal_params.p, w.seal_params.n);
+    if (e.scheme != 1) throw std::runtime_error("failed to load parameters: invalid scheme type");      // psu_params.cpp:283-285
+    std::vector<int> bits;
+    for (uint64_t q : e.coeff_modulus) { int b = 0; while (b < 64 && (q >> b)) b++; bits.push_back(b); }
+    if (e.coeff_modulus.empty() || e.poly_modulus_degree < 2 || (e.poly_modulus_degree & (e.poly_modulus_degree - 1)))
+        throw std::runtime_error("failed to load parameters: invalid encryption parameters");
+    for (int b : bits) if (b < 2 || b > 60) throw std::runtime_error("failed to load parameters: invalid coefficient modulus");
+    if (coeff_modulus_create((size_t)e.poly_modulus_degree, bits) != e.coeff_modulus)
+        throw std::runtime_error("failed to load parameters: the coefficient primes are not CoeffModulus::Create's for their bit sizes "
+                                 "(the JSON form cannot name them)");
+    std::string j = "{\"table_params\":{\"hash_func_count\":" + std::to_string(w.hash_func_count) + ",\"table_size\":" + std::to_string(w.table_size) +
+                    ",\"max_items_per_bin\":" + std::to_string(w.max_items_per_bin) + "},\"item_params\":{\"felts_per_item\":" +
+                    std::to_string(w.felts_per_item) + "},\"query_params\":{\"ps_low_degree\":" + std::to_string(w.ps_low_degree) + ",\"query_powers\":[";
+    for (size_t i = 0; i < w.query_powers.size(); i++) j += (i ? "," : "") + std::to_string(w.query_powers[i]);
+    j += "]},\"seal_params\":{\"plain_modulus\":" + std::to_string(e.plain_modulus) + ",\"poly_modulus_degree\":" + std::to_string(e.poly_modulus_degree) +
+         ",\"coeff_modulus_bits\":[";
+    for (size_t i = 0; i < bits.size(); i++) j += (i ? "," : "") + std::to_string(bits[i]);
+    j += "]}}";
+    (void)PSUParams::Load(j);                                            // the reference's own validation of what was just read
+    return j;
+}
+} // namespace
+int apsu_he_wire_psu_params_save(const char *psu_params_json, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(psu_params_json && out && out_size, "null argument");
+        const PSUParams p = PSUParams::Load(psu_params_json);
+        const HeParams hp = HeParams::FromPSUParams(p);
+        sealio::EncryptionParameters e;
+        e.poly_modulus_degree = hp.n; e.coeff_modulus.assign(hp.key_q.begin(), hp.key_q.begin() + hp.K); e.plain_modulus = hp.t;
+        const std::vector<uint8_t> sp = sealio::save_encryption_parameters(e, sealio::COMPR_NONE);
+        wire::PsuParamsWire w;
+        w.felts_per_item = p.item_params.felts_per_item;
+        w.table_size = p.table_params.table_size; w.max_items_per_bin = p.table_params.max_items_per_bin; w.hash_func_count = p.table_params.hash_func_count;
+        w.ps_low_degree = p.query_params.ps_low_degree;
+        w.query_powers.assign(p.query_params.query_powers.begin(), p.query_params.query_powers.end());
+        w.seal_params = wire::Span{ sp.data(), sp.size() };
+        wire_out(wire::build_psu_params(w), out, out_size);
+    });
+}
+int apsu_he_wire_psu_params_load(const uint8_t *buf, size_t size, uint8_t **json_out_buf, size_t *json_size)
+{
+    return guarded([&] {
+        REQUIRE(buf && json_out_buf && json_size, "null argument");
+        const std::string j = psu_params_to_json(wire::parse_psu_params(buf, size));
+        wire_out(std::vector<uint8_t>(j.begin(), j.end()), json_out_buf, json_size);
+    });
+}
+int apsu_he_wire_peek_type(const uint8_t *buf, size_t size, int is_response, int *type)
+{
+    return guarded([&] {
+        REQUIRE(buf && type, "null argument");
+        *type = is_response ? wire::peek_response_type(buf, size) : wire::peek_request_type(buf, size);
+    });
+}
+int apsu_he_wire_build_parms_request(uint8_t **out, size_t *out_size)
+{ return guarded([&] { REQUIRE(out && out_size, "null argument"); wire_out(wire::build_parms_request(), out, out_size); }); }
+int apsu_he_wire_build_parms_response(const uint8_t *psu_params, size_t psu_params_size, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(out && out_size && (psu_params || !psu_params_size), "null argument");
+        wire_out(wire::build_parms_response(wire::Span{ psu_params, psu_params_size }), out, out_size);
+    });
+}
+int apsu_he_wire_parse_parms_response(const uint8_t *buf, size_t size, const uint8_t **psu_params, size_t *psu_params_size)
+{
+    return guarded([&] {
+        REQUIRE(buf && psu_params && psu_params_size, "null argument");
+        const wire::Span s = wire::parse_parms_response(buf, size);
+        *psu_params = s.p; *psu_params_size = s.n;
+    });
+}
+int apsu_he_wire_build_plain_response(uint32_t bundle_idx, uint32_t cache_idx, const uint64_t *psu_result, size_t count, uint8_t **out, size_t *out_size)
+{
+    return guarded([&] {
+        REQUIRE(out && out_size && (psu_result || !count), "null argument");
+        wire::PlainResponse p;
+        p.bundle_idx = bundle_idx; p.cache_idx = cache_idx;
+        p.psu_result.assign(psu_result, psu_result + count);
+        wire_out(wire::build_plain_response(p), out, out_size);
+    });
+}
+int apsu_he_wire_parse_plain_response(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint32_t *cache_idx, uint64_t *psu_result, size_t capacity,
+                                      size_t *count)
+{
+    return guarded([&] {
+        REQUIRE(buf && count, "null argument");
+        const wire::PlainResponse p = wire::parse_plain_response(buf, size);
+        if (bundle_idx) *bundle_idx = p.bundle_idx;
+        if (cache_idx) *cache_idx = p.cache_idx;
+        *count = p.psu_result.size();
+        if (psu_result) {
+            REQUIRE(capacity >= p.psu_result.size(), "output buffer too small");
+            std::memcpy(psu_result, p.psu_result.data(), p.psu_result.size() * sizeof(uint64_t));
+        }
+    });
+}
+// The header of a database the reference saved (receiver_db.fbs): its PSUParams as JSON, counts and flags; *consumed = first BinBundle
+int apsu_he_wire_receiver_db_header(const uint8_t *buf, size_t size, uint8_t **psu_params_json, size_t *json_size, uint64_t *item_count,
+                                    uint32_t *bin_bundle_count, int *compressed, int *stripped, uint32_t *label_byte_count, size_t *consumed)
+{
+    return guarded([&] {
+        REQUIRE(buf, "null argument");
+        const wire::ReceiverDbHeader h = wire::parse_receiver_db_header(buf, size);
+        if (psu_params_json) {
+            REQUIRE(json_size, "null argument");
+            const std::string j = psu_params_to_json(wire::parse_psu_params(h.params.p, h.params.n));
+            wire_out(std::vector<uint8_t>(j.begin(), j.end()), psu_params_json, json_size);
+        }
+        if (item_count) *item_count = h.item_count;
+        if (bin_bundle_count) *bin_bundle_count = h.bin_bundle_count;
+        if (compressed) *compressed = h.compressed ? 1 : 0;
+        if (stripped) *stripped = h.stripped ? 1 : 0;
+        if (label_byte_count) *label_byte_count = h.label_byte_count;
+        if (consumed) *consumed = h.consumed;
+    });
+}
 // One BinBundle as ReceiverDB::save wrote it (bin_bundle.fbs; BinBundle::save bin_bundle.cpp:1085-1168): dimensions only
 int apsu_he_wire_bin_bundle_info(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint64_t *mod, int *stripped, uint32_t *n_bins,
                                  uint32_t *largest_bin, uint32_t *cache_coeffs, size_t *consumed)

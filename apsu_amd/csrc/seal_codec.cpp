@@ -343,6 +343,46 @@ std::vector<uint8_t> save_ciphertext(const Ciphertext &ct, uint8_t compr)
     return close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, compr);
 }
 
+EncryptionParameters load_encryption_parameters(const uint8_t *buf, size_t size, size_t *consumed)
+{
+    if (!buf) bad("null buffer");
+    Body b = open_object(buf, size);
+    Cursor c{ b.p, b.n };
+    EncryptionParameters p;
+    p.version_major = b.h.vmaj; p.version_minor = b.h.vmin;
+    p.scheme = c.u8();
+    p.poly_modulus_degree = c.u64();
+    const uint64_t count = c.u64();
+    if (count > 64 || p.poly_modulus_degree > (1u << 20)) bad("implausible encryption parameters");
+    auto modulus = [&]() {
+        Body m = open_object(c.here(), c.left());
+        c.skip((size_t)m.h.total);
+        Cursor mc{ m.p, m.n };
+        return mc.u64();
+    };
+    for (uint64_t i = 0; i < count; i++) p.coeff_modulus.push_back(modulus());
+    p.plain_modulus = modulus();
+    if (consumed) *consumed = (size_t)b.h.total;
+    return p;
+}
+
+std::vector<uint8_t> save_encryption_parameters(const EncryptionParameters &p, uint8_t compr)
+{
+    std::vector<uint8_t> m;
+    m.push_back(p.scheme);
+    wr64(m, p.poly_modulus_degree);
+    wr64(m, p.coeff_modulus.size());
+    auto modulus = [&](uint64_t v) {
+        std::vector<uint8_t> val;
+        wr64(val, v);
+        const std::vector<uint8_t> o = close_object(val, p.version_major, p.version_minor, COMPR_NONE);
+        m.insert(m.end(), o.begin(), o.end());
+    };
+    for (uint64_t q : p.coeff_modulus) modulus(q);
+    modulus(p.plain_modulus);
+    return close_object(m, p.version_major, p.version_minor, compr);
+}
+
 Plaintext load_plaintext(const uint8_t *buf, size_t size, size_t *consumed)
 {
     if (!buf) bad("null buffer");

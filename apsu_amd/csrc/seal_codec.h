@@ -83,6 +83,19 @@ struct Plaintext {
 Plaintext load_plaintext(const uint8_t *buf, size_t size, size_t *consumed = nullptr);
 std::vector<uint8_t> save_plaintext(const Plaintext &pt, uint8_t compr);
 
+// seal::EncryptionParameters (encryptionparams.cpp save_members [SEAL-recall]): scheme u8 (bfv = 1) | poly_modulus_degree u64 |
+// coeff_modulus_size u64 | that many Modulus objects | plain_modulus Modulus object; a Modulus object = its own SEALHeader + value u64.
+// What PSUParams::save embeds (psu_params.cpp:203-209, compr_mode none) in the parameter exchange and in a saved ReceiverDB.
+struct EncryptionParameters {
+    uint8_t scheme = 1;
+    uint64_t poly_modulus_degree = 0;
+    std::vector<uint64_t> coeff_modulus;
+    uint64_t plain_modulus = 0;
+    uint8_t version_major = 4, version_minor = 0;
+};
+EncryptionParameters load_encryption_parameters(const uint8_t *buf, size_t size, size_t *consumed = nullptr);
+std::vector<uint8_t> save_encryption_parameters(const EncryptionParameters &p, uint8_t compr);
+
 struct KSwitchKeys {
     uint64_t parms_id[4] = { 0, 0, 0, 0 };
     std::vector<std::vector<Ciphertext>> keys;          // [dim1][dim2]

@@ -37,7 +37,7 @@ struct TableWriter {
     std::vector<size_t> where;            // absolute position of each present field
     size_t table_pos = 0;
     explicit TableWriter(Writer &w_) : w(w_) {}
-    // sizes_in: inline byte size of every field id (1 u8, 4 u32 / offset), 0 = not stored
+    // sizes_in: inline byte size of every field id (1 u8, 4 u32 / offset, 4 k: a struct of k u32), 0 = not stored
     void begin(const std::vector<uint16_t> &sizes_in)
     {
         sizes = sizes_in;
@@ -47,7 +47,7 @@ struct TableWriter {
         // inline layout: soffset, then 4-byte fields, then 1-byte fields (largest first keeps everything aligned)
         std::vector<uint16_t> off(sizes.size(), 0);
         uint16_t cur = 4;
-        for (size_t i = 0; i < sizes.size(); i++) if (sizes[i] == 4) { off[i] = cur; cur += 4; }
+        for (size_t i = 0; i < sizes.size(); i++) if (sizes[i] >= 4) { off[i] = cur; cur = (uint16_t)(cur + sizes[i]); }   // u32, offsets, structs of u32
         for (size_t i = 0; i < sizes.size(); i++) if (sizes[i] == 1) { off[i] = cur; cur += 1; }
         const uint16_t tbl_size = cur;
         const uint16_t vt_size = (uint16_t)(4 + 2 * nf);
@@ -161,6 +161,28 @@ struct Reader {
         return t.pos + off;
     }
     uint32_t get_u32(const Table &t, int id, uint32_t dflt) const { const size_t p = field(t, id, 4); return p ? u32(p) : dflt; }
+    // inline struct: `size` bytes at an `align`-aligned position
+    size_t field_struct(const Table &t, int id, size_t size, size_t align) const
+    {
+        const size_t slot = 4 + 2 * (size_t)id;
+        if (slot + 2 > t.vt_size) return 0;
+        const uint16_t off = u16(t.vt + slot);
+        if (!off) return 0;
+        if ((size_t)off + size > t.tbl_size) bad();
+        if ((t.pos + off) % align) bad();
+        need(t.pos + off, size);
+        return t.pos + off;
+    }
+    std::vector<uint32_t> u32_vector(size_t pos) const
+    {
+        const uint32_t len = u32(pos);
+        if ((uint64_t)len * 4 > n) bad();
+        need(pos + 4, (size_t)len * 4);
+        visit(len / 8 + 1);
+        std::vector<uint32_t> out(len);
+        for (uint32_t i = 0; i < len; i++) out[i] = u32(pos + 4 + 4 * (size_t)i);
+        return out;
+    }
     uint64_t u64(size_t off) const { need(off, 8); if (off % 8) bad(); uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | b[off + i]; return v; }
     uint64_t get_u64(const Table &t, int id, uint64_t dflt) const { const size_t p = field(t, id, 8); return p ? u64(p) : dflt; }
     // [uint64]: length, then the elements at an 8-byte aligned position
@@ -369,6 +391,182 @@ ResultPackage parse_result_package(const uint8_t *buf, size_t size)
     if (const size_t lv = r.child(t, 5, false))
         for (size_t cpos : r.table_vector(lv)) p.label_result.push_back(r.ciphertext(cpos));
     return p;
+}
+
+// ================================================================================================ the unions' other members
+uint8_t peek_request_type(const uint8_t *buf, size_t size)
+{
+    Reader r{ buf, size, "ReceiverOperation" };
+    const Reader::Table rop = r.table(r.root());
+    (void)r.child(rop, 1, true);
+    return r.get_u8(rop, 0, 0);
+}
+uint8_t peek_response_type(const uint8_t *buf, size_t size)
+{
+    Reader r{ buf, size, "ReceiverOperationResponse" };
+    const Reader::Table rr = r.table(r.root());
+    (void)r.child(rr, 1, true);
+    return r.get_u8(rr, 0, 0);
+}
+
+// root { type:u8, value:offset } + the union member's table; returns the member's TableWriter ready for its fields
+static void begin_union(Writer &w, uint8_t tag, TableWriter &member, const std::vector<uint16_t> &member_sizes)
+{
+    w.u32(0); w.u32(0);
+    TableWriter root(w);
+    root.begin({ 1, 4 });
+    w.patch32(4, (uint32_t)(root.table_pos - 4));
+    root.set_u8(0, tag);
+    w.align(4);
+    member.begin(member_sizes);
+    w.patch32(root.where[1], (uint32_t)(member.table_pos - root.where[1]));
+}
+
+std::vector<uint8_t> build_parms_request()
+{
+    Writer w;
+    TableWriter m(w);
+    begin_union(w, 1, m, {});
+    return finish_size_prefixed(w);
+}
+
+std::vector<uint8_t> build_parms_response(Span psu_params)
+{
+    Writer w;
+    TableWriter m(w);
+    begin_union(w, 1, m, { 4 });
+    m.link(0);
+    write_byte_vector(w, psu_params);
+    return finish_size_prefixed(w);
+}
+
+Span parse_parms_response(const uint8_t *buf, size_t size)
+{
+    Reader r{ buf, size, "ReceiverOperationResponse" };
+    const Reader::Table rr = r.table(r.root());
+    const uint8_t type = r.get_u8(rr, 0, 0);
+    const size_t pos = r.child(rr, 1, true);
+    if (type != 1) throw std::runtime_error("unexpected operation type");
+    const Reader::Table t = r.table(pos);
+    if (const size_t d = r.child(t, 0, false)) return r.byte_vector(d);
+    return Span{};
+}
+
+std::vector<uint8_t> build_plain_response(const PlainResponse &p)
+{
+    Writer w;
+    TableWriter m(w);
+    begin_union(w, 4, m, { (uint16_t)(p.bundle_idx ? 4 : 0), 4, (uint16_t)(p.cache_idx ? 4 : 0) });
+    if (p.bundle_idx) m.set_u32(0, p.bundle_idx);
+    if (p.cache_idx) m.set_u32(2, p.cache_idx);
+    // [uint64]: the length word directly in front of the 8-aligned elements
+    w.align(4);
+    if ((w.pos() + 4) % 8) w.u32(0);
+    m.w.link(m.where[1]);
+    w.u32((uint32_t)p.psu_result.size());
+    for (uint64_t v : p.psu_result) w.u64(v);
+    return finish_size_prefixed(w);
+}
+
+PlainResponse parse_plain_response(const uint8_t *buf, size_t size)
+{
+    Reader r{ buf, size, "ReceiverOperation" };
+    const Reader::Table rop = r.table(r.root());
+    const uint8_t type = r.get_u8(rop, 0, 0);
+    const size_t pos = r.child(rop, 1, true);
+    if (type != 4) throw std::runtime_error("unexpected operation type");
+    const Reader::Table t = r.table(pos);
+    PlainResponse p;
+    p.bundle_idx = r.get_u32(t, 0, 0);
+    p.psu_result = r.u64_vector(r.child(t, 1, true));
+    p.cache_idx = r.get_u32(t, 2, 0);
+    return p;
+}
+
+// ================================================================================================ PSUParams (psu_params.fbs)
+std::vector<uint8_t> build_psu_params(const PsuParamsWire &p)
+{
+    Writer w;
+    w.u32(0); w.u32(0);
+    TableWriter t(w);
+    t.begin({ (uint16_t)(p.version ? 4 : 0), 4, 12, 4, 4 });
+    w.patch32(4, (uint32_t)(t.table_pos - 4));
+    if (p.version) t.set_u32(0, p.version);
+    w.patch32(t.where[1], p.felts_per_item);
+    w.patch32(t.where[2], p.table_size);
+    w.patch32(t.where[2] + 4, p.max_items_per_bin);
+    w.patch32(t.where[2] + 8, p.hash_func_count);
+    {   // QueryParams
+        TableWriter q(w);
+        w.align(4);
+        q.begin({ (uint16_t)(p.ps_low_degree ? 4 : 0), 4 });
+        w.patch32(t.where[3], (uint32_t)(q.table_pos - t.where[3]));
+        if (p.ps_low_degree) q.set_u32(0, p.ps_low_degree);
+        q.link(1);
+        w.u32((uint32_t)p.query_powers.size());
+        for (uint32_t v : p.query_powers) w.u32(v);
+    }
+    {   // SEALParams
+        TableWriter sp(w);
+        w.align(4);
+        sp.begin({ 4 });
+        w.patch32(t.where[4], (uint32_t)(sp.table_pos - t.where[4]));
+        sp.link(0);
+        write_byte_vector(w, p.seal_params);
+    }
+    return finish_size_prefixed(w);
+}
+
+PsuParamsWire parse_psu_params(const uint8_t *buf, size_t size)
+{
+    Reader r{ buf, size, "parameters" };
+    const Reader::Table t = r.table(r.root());
+    PsuParamsWire p;
+    p.version = r.get_u32(t, 0, 0);
+    if (p.version != 1) throw std::runtime_error("failed to load parameters: incompatible serialization version");   // psu_params.cpp:240-248
+    const size_t ip = r.field_struct(t, 1, 4, 4), tp = r.field_struct(t, 2, 12, 4);
+    if (!ip || !tp) r.bad();                                          // the reference dereferences both unconditionally
+    p.felts_per_item = r.u32(ip);
+    p.table_size = r.u32(tp); p.max_items_per_bin = r.u32(tp + 4); p.hash_func_count = r.u32(tp + 8);
+    const size_t qp = r.child(t, 3, false);
+    if (!qp) r.bad();
+    const Reader::Table q = r.table(qp);
+    p.ps_low_degree = r.get_u32(q, 0, 0);
+    if (const size_t v = r.child(q, 1, false)) p.query_powers = r.u32_vector(v);
+    const Reader::Table sp = r.table(r.child(t, 4, true));
+    p.seal_params = r.byte_vector(r.child(sp, 0, true));
+    return p;
+}
+
+// ================================================================================================ a saved ReceiverDB's header
+ReceiverDbHeader parse_receiver_db_header(const uint8_t *buf, size_t size)
+{
+    if (!buf || size < 8) throw std::runtime_error("failed to load ReceiverDB");
+    const uint64_t body = (uint64_t)buf[0] | ((uint64_t)buf[1] << 8) | ((uint64_t)buf[2] << 16) | ((uint64_t)buf[3] << 24);
+    if (body + 4 > size) throw std::runtime_error("failed to load ReceiverDB");
+    Reader r{ buf, (size_t)body + 4, "ReceiverDB" };
+    const Reader::Table t = r.table(r.root());
+    ReceiverDbHeader h;
+    h.consumed = (size_t)body + 4;
+    h.params = r.byte_vector(r.child(t, 0, true));
+    if (const size_t ip = r.field_struct(t, 1, 24, 8)) {
+        h.label_byte_count = r.u32(ip); h.nonce_byte_count = r.u32(ip + 4);
+        h.item_count = r.u64(ip + 8);
+        h.compressed = r.u8(ip + 16) != 0; h.stripped = r.u8(ip + 17) != 0;
+    } else {
+        r.bad();                                                      // ReceiverDB::Load dereferences info unconditionally
+    }
+    h.oprf_key = r.byte_vector(r.child(t, 2, true));
+    {
+        const size_t hv = r.child(t, 3, true);
+        const uint32_t len = r.u32(hv);
+        if ((uint64_t)len * 16 > r.n) r.bad();
+        r.need(hv + 4, (size_t)len * 16);
+        if (len && (hv + 4) % 8) r.bad();
+        h.hashed_item_count = len;
+    }
+    h.bin_bundle_count = r.get_u32(t, 4, 0);
+    return h;
 }
 
 // ================================================================================================ a saved BinBundle

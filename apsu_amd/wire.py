@@ -146,3 +146,75 @@ def bin_bundle_info(buf):
                                                       C.byref(cc), C.byref(used)))
     return dict(bundle_idx=bi.value, mod=mod.value, stripped=bool(st.value), n_bins=nb.value, largest_bin=lb.value, cache_coeffs=cc.value,
                 consumed=used.value)
+
+
+def peek_type(buf, is_response=False):
+    t = C.c_int()
+    _check(load_library().apsu_he_wire_peek_type(_buf(buf), C.c_size_t(len(buf)), 1 if is_response else 0, C.byref(t)))
+    return t.value
+
+
+def psu_params_save(psu_params_json):
+    """PSUParams::save: the JSON form -> the binary form (psu_params.fbs + SEAL EncryptionParameters)"""
+    out, size = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_psu_params_save(psu_params_json.encode(), C.byref(out), C.byref(size)))
+    return _take(out, size)
+
+
+def psu_params_load(buf):
+    """PSUParams::Load(binary) -> the JSON text apsu_he_create takes"""
+    out, size = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_psu_params_load(_buf(buf), C.c_size_t(len(buf)), C.byref(out), C.byref(size)))
+    return _take(out, size).decode()
+
+
+def build_parms_request():
+    out, size = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_build_parms_request(C.byref(out), C.byref(size)))
+    return _take(out, size)
+
+
+def build_parms_response(psu_params):
+    out, size = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_build_parms_response(_buf(psu_params), C.c_size_t(len(psu_params)), C.byref(out), C.byref(size)))
+    return _take(out, size)
+
+
+def parse_parms_response(buf):
+    keep = _buf(buf)
+    p, n = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_parse_parms_response(keep, C.c_size_t(len(buf)), C.byref(p), C.byref(n)))
+    return C.string_at(p, n.value) if n.value else b""
+
+
+def build_plain_response(bundle_idx, cache_idx, psu_result):
+    import numpy as np
+    v = np.ascontiguousarray(psu_result, dtype=np.uint64)
+    out, size = u8p(), C.c_size_t()
+    _check(load_library().apsu_he_wire_build_plain_response(bundle_idx, cache_idx, v.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(v.size),
+                                                           C.byref(out), C.byref(size)))
+    return _take(out, size)
+
+
+def parse_plain_response(buf):
+    import numpy as np
+    keep = _buf(buf)
+    bi, ci, cnt = C.c_uint32(), C.c_uint32(), C.c_size_t()
+    _check(load_library().apsu_he_wire_parse_plain_response(keep, C.c_size_t(len(buf)), C.byref(bi), C.byref(ci), None, C.c_size_t(0), C.byref(cnt)))
+    v = np.empty(cnt.value, dtype=np.uint64)
+    _check(load_library().apsu_he_wire_parse_plain_response(keep, C.c_size_t(len(buf)), C.byref(bi), C.byref(ci), v.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                           C.c_size_t(v.size), C.byref(cnt)))
+    return dict(bundle_idx=bi.value, cache_idx=ci.value, psu_result=v)
+
+
+def receiver_db_header(buf):
+    """the header of a database the reference saved (receiver_db.fbs) -> dict(params_json, item_count, bin_bundle_count, compressed, stripped,
+    label_byte_count, consumed)"""
+    keep = _buf(buf)
+    js, jn = u8p(), C.c_size_t()
+    items, bbs, lab, used = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_size_t()
+    comp, strip = C.c_int(), C.c_int()
+    _check(load_library().apsu_he_wire_receiver_db_header(keep, C.c_size_t(len(buf)), C.byref(js), C.byref(jn), C.byref(items), C.byref(bbs),
+                                                         C.byref(comp), C.byref(strip), C.byref(lab), C.byref(used)))
+    return dict(params_json=_take(js, jn).decode(), item_count=items.value, bin_bundle_count=bbs.value, compressed=bool(comp.value),
+                stripped=bool(strip.value), label_byte_count=lab.value, consumed=used.value)

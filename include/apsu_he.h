@@ -75,7 +75,8 @@ const char *apsu_he_last_error(void);
  * apsu_he_algebraize_items (N1: item -> field elements); apsu_he_db_file_* / apsu_he_multi_db_load_file / _save_file (N2: the whole DB
  * in one mmap-able file); apsu_he_seal_pt_load / _save, apsu_he_db_upload_bundle_serialized (BinBundle caches as the reference stores
  * them), apsu_he_db_upload_saved_bundle (a BinBundle as ReceiverDB::save wrote it); zstd bodies in the SEAL codec;
- * apsu_he_multi_run_query_request, apsu_he_multi_result_polys. */
+ * apsu_he_multi_run_query_request, apsu_he_multi_result_polys; the parameter exchange, plainResponse, PSUParams in binary form and
+ * the header of a saved ReceiverDB (apsu_he_wire_peek_type ... apsu_he_wire_receiver_db_header). */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -410,6 +411,28 @@ int apsu_he_seal_pt_save(const apsu_he_seal_ctx *c, int chain_idx, const uint64_
  * object's parms_id and checked against the rule of bin_bundle.cpp:385-389,418-420.  No SEAL on the host.  (ABI 4) */
 int apsu_he_db_upload_bundle_serialized(apsu_he_ctx *ctx, const apsu_he_seal_ctx *seal_ctx, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
                                         const uint8_t *const *blobs, const size_t *blob_sizes, apsu_he_bundle **out);
+/* The rest of the framing around the path (ABI 4).  apsu_he_wire_peek_type: the union tag of a ReceiverOperation (1 ParmsRequest,
+ * 2 OPRFRequest, 3 QueryRequest, 4 plainResponse; rop.fbs) or of a ReceiverOperationResponse (1 ParmsResponse, 2 OPRFResponse,
+ * 3 QueryResponse; rop_response.fbs).  The parameter exchange: ParmsRequest {} / ParmsResponse { data } with data = PSUParams::save's
+ * bytes (psu_params.fbs + SEAL's EncryptionParameters object, psu_params.cpp:182-290): apsu_he_wire_psu_params_save turns the JSON
+ * apsu_he_create takes into those bytes, _load turns them back into that JSON (explicit coefficient primes must be
+ * CoeffModulus::Create's for their bit sizes, which is what every JSON-created parameter set has).  plainResponse { bundle_idx,
+ * psu_result:[uint64], cache_idx }: the querier's decrypted results on their way back to the DB side (receiver_operation.cpp).
+ * The EncryptionParameters object is restated from memory of upstream SEAL like the rest of apsu_he_seal_*: UNPINNED. */
+int apsu_he_wire_peek_type(const uint8_t *buf, size_t size, int is_response, int *type);
+int apsu_he_wire_psu_params_save(const char *psu_params_json, uint8_t **out, size_t *out_size);
+int apsu_he_wire_psu_params_load(const uint8_t *buf, size_t size, uint8_t **psu_params_json, size_t *json_size);   /* not NUL-terminated */
+int apsu_he_wire_build_parms_request(uint8_t **out, size_t *out_size);
+int apsu_he_wire_build_parms_response(const uint8_t *psu_params, size_t psu_params_size, uint8_t **out, size_t *out_size);
+int apsu_he_wire_parse_parms_response(const uint8_t *buf, size_t size, const uint8_t **psu_params, size_t *psu_params_size);   /* into buf */
+int apsu_he_wire_build_plain_response(uint32_t bundle_idx, uint32_t cache_idx, const uint64_t *psu_result, size_t count, uint8_t **out, size_t *out_size);
+int apsu_he_wire_parse_plain_response(const uint8_t *buf, size_t size, uint32_t *bundle_idx, uint32_t *cache_idx, uint64_t *psu_result, size_t capacity,
+                                      size_t *count);
+/* The header ReceiverDB::save writes in front of the BinBundles (receiver/apsu/receiver_db.fbs, receiver_db.cpp:1182-1232): the
+ * parameters as JSON (release with apsu_he_wire_buffer_free; NULL: skip), item count, BinBundle count, flags; *consumed = offset of
+ * the first BinBundle, to be walked with apsu_he_wire_bin_bundle_info / apsu_he_db_upload_saved_bundle below. */
+int apsu_he_wire_receiver_db_header(const uint8_t *buf, size_t size, uint8_t **psu_params_json, size_t *json_size, uint64_t *item_count,
+                                    uint32_t *bin_bundle_count, int *compressed, int *stripped, uint32_t *label_byte_count, size_t *consumed);
 /* One BinBundle as the reference persists it: the size-prefixed FlatBuffers buffer BinBundle::save appends to a saved ReceiverDB
  * (receiver/apsu/bin_bundle.fbs; bin_bundle.cpp:1085-1168; ReceiverDB::save receiver_db.cpp:1182-1260 writes them one after the
  * other behind its own header).  apsu_he_wire_bin_bundle_info: its dimensions and *consumed = where the next one starts.

@@ -114,6 +114,37 @@ int main(int argc, char **argv)
         if (sealio::relin_keys_layout(sealio::load_kswitch_keys(kb.data(), kb.size(), chain), 3, 64).size() != 2 * 2 * 3 * 64) return 14;
         rej += fuzz(kb, [&](const uint8_t *p, size_t n) { (void)sealio::load_kswitch_keys(p, n, chain); }, 8000);
     }
+    // ---- parameter exchange, plainResponse, PSUParams in binary form (with SEAL's EncryptionParameters object inside)
+    {
+        sealio::EncryptionParameters ep;
+        ep.poly_modulus_degree = 64; ep.coeff_modulus = { 1099511590913ull, 1099511592577ull, 68719403009ull }; ep.plain_modulus = 65537;
+        const std::vector<uint8_t> eb = sealio::save_encryption_parameters(ep, sealio::COMPR_NONE);
+        if (sealio::load_encryption_parameters(eb.data(), eb.size()).coeff_modulus != ep.coeff_modulus) return 16;
+        wire::PsuParamsWire pw;
+        pw.felts_per_item = 5; pw.table_size = 24; pw.max_items_per_bin = 11; pw.hash_func_count = 3; pw.ps_low_degree = 3; pw.query_powers = { 1, 4 };
+        pw.seal_params = wire::Span{ eb.data(), eb.size() };
+        const std::vector<uint8_t> pb = wire::build_psu_params(pw);
+        const wire::PsuParamsWire pr = wire::parse_psu_params(pb.data(), pb.size());
+        if (pr.query_powers != pw.query_powers || pr.table_size != 24 || pr.seal_params.n != eb.size()) return 17;
+        wire::PlainResponse pl; pl.bundle_idx = 3; pl.cache_idx = 0; pl.psu_result = { 1, 2, 3, ~0ull };
+        const std::vector<uint8_t> plb = wire::build_plain_response(pl), rq = wire::build_parms_request(),
+                                   rs = wire::build_parms_response(wire::Span{ pb.data(), pb.size() });
+        if (wire::parse_plain_response(plb.data(), plb.size()).psu_result != pl.psu_result || wire::peek_request_type(rq.data(), rq.size()) != 1 ||
+            wire::parse_parms_response(rs.data(), rs.size()).n != pb.size()) return 18;
+        rej += fuzz(eb, [](const uint8_t *p, size_t n) { (void)sealio::load_encryption_parameters(p, n); }, 20000);
+        rej += fuzz(pb, [](const uint8_t *p, size_t n) { (void)wire::parse_psu_params(p, n); }, 20000);
+        rej += fuzz(plb, [](const uint8_t *p, size_t n) { (void)wire::parse_plain_response(p, n); }, 10000);
+        rej += fuzz(rs, [](const uint8_t *p, size_t n) { (void)wire::parse_parms_response(p, n); (void)wire::peek_response_type(p, n); }, 10000);
+    }
+    // ---- a saved ReceiverDB's header (receiver_db.fbs; seeds from the test's FlatBuffers model, like the BinBundles below)
+    for (int i = 1; i < argc; i++) {
+        const std::string name = argv[i];
+        if (name.size() < 9 || name.substr(name.size() - 9) != ".dbheader") continue;
+        std::ifstream f(name, std::ios::binary);
+        std::vector<uint8_t> seed((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        if (wire::parse_receiver_db_header(seed.data(), seed.size()).bin_bundle_count != 2) return 19;
+        rej += fuzz(seed, [](const uint8_t *p, size_t n) { (void)wire::parse_receiver_db_header(p, n); }, 20000);
+    }
     // ---- saved BinBundles (bin_bundle.fbs; the library has no writer for them): seeds written by the test's FlatBuffers model
     for (int i = 1; i < argc; i++) {
         const std::string name = argv[i];
@@ -128,7 +159,7 @@ int main(int argc, char **argv)
 
     // ---- PSUParams JSON + derived constants + PowersDag for the parameter files given on the command line
     for (int i = 1; i < argc; i++) {
-        if (std::string(argv[i]).size() >= 10 && std::string(argv[i]).substr(std::string(argv[i]).size() - 10) == ".binbundle") continue;
+        if (std::string(argv[i]).find(".json") == std::string::npos) continue;
         std::ifstream f(argv[i]);
         std::stringstream ss; ss << f.rdbuf();
         PSUParams p = PSUParams::Load(ss.str());

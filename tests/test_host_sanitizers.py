@@ -25,6 +25,16 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
         path = tmp_path / ("seed%d.binbundle" % i)
         path.write_bytes(build_bin_bundle(2, 65537, [[5, 7, 11], [], [2**40 + 3], list(range(1, 9))], blobs))
         seeds.append(str(path))
+    import struct
+    from test_wire_framing import FbBuilder
+    B = FbBuilder()
+    hashed = B.struct_vector([struct.pack("<QQ", i, i + 1) for i in range(3)], 8)
+    key = B.byte_vector(bytes(32))
+    pv = B.byte_vector(b"params")
+    hdr = tmp_path / "seed.dbheader"
+    hdr.write_bytes(B.finish_size_prefixed(B.table([("off", pv), ("struct", struct.pack("<IIQ??", 0, 16, 3, False, False) + bytes(6), 8),
+                                                    ("off", key), ("off", hashed), ("u32", 2)])))
+    seeds.append(str(hdr))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe] + params + seeds, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]

@@ -46,6 +46,20 @@ class FbBuilder:
         self._push(struct.pack("<I", len(vals)))
         return self.off()
 
+    def u32_vector(self, vals):
+        self._prep(4, 4 * len(vals))
+        for v in reversed(vals):
+            self._push(struct.pack("<I", int(v)))
+        self._push(struct.pack("<I", len(vals)))
+        return self.off()
+
+    def struct_vector(self, elems, align):
+        raw = b"".join(elems)
+        self._prep(align, len(raw))
+        self._push(raw)
+        self._push(struct.pack("<I", len(elems)))
+        return self.off()
+
     def offset_vector(self, offs):
         self._prep(4, 4 * len(offs))
         for o in reversed(offs):
@@ -59,13 +73,18 @@ class FbBuilder:
         # inline data, written back to front: large fields first so they end up aligned
         slots = {}
         end0 = None
-        size_of = {"u64": 8, "u32": 4, "off": 4, "u8": 1}
-        order = sorted([i for i, f in enumerate(fields) if f is not None], key=lambda i: (-size_of[fields[i][0]], i))
+        # ('struct', raw bytes, alignment): stored inline like a scalar of its alignment
+        size_of = {"u64": 8, "u32": 4, "off": 4, "u8": 1, "struct": 0}
+        align_of = lambda f: f[2] if f[0] == "struct" else size_of[f[0]]
+        order = sorted([i for i, f in enumerate(fields) if f is not None], key=lambda i: (-align_of(fields[i]), i))
         for i in reversed(order):
-            kind, v = fields[i]
+            kind, v = fields[i][0], fields[i][1]
             if kind == "u8":
                 self._prep(1, 0)
                 self._push(struct.pack("<B", v))
+            elif kind == "struct":
+                self._prep(fields[i][2], len(v))
+                self._push(bytes(v))
             elif kind == "u64":
                 self._prep(8, 0)
                 self._push(struct.pack("<Q", v))
@@ -77,7 +96,7 @@ class FbBuilder:
                 self._push(struct.pack("<I", self.off() + 4 - v))
             slots[i] = self.off()
             if end0 is None:
-                end0 = self.off() - size_of[kind]
+                end0 = self.off() - (len(v) if kind == "struct" else size_of[kind])
         if end0 is None:
             end0 = self.off()
         self._prep(4, 0)
@@ -374,3 +393,134 @@ def test_saved_bin_bundle_reader():
         except RuntimeError:
             pass
     assert ok < 1500
+
+
+# --------------------------------------------------------------------------------------------- parameter exchange, plainResponse, PSUParams, ReceiverDB header
+SEAL_MAGIC = b"\x5e\xa1\x10"
+
+
+def seal_obj(members, version=(4, 0)):
+    return SEAL_MAGIC + bytes([version[0], version[1], 0, 0, 0]) + struct.pack("<Q", 16 + len(members)) + members
+
+
+def model_encryption_parameters(n, coeff_modulus, plain_modulus):
+    """seal::EncryptionParameters::save [SEAL-recall]: scheme, degree, count, Modulus objects, plain modulus object"""
+    m = bytes([1]) + struct.pack("<QQ", n, len(coeff_modulus))
+    for q in list(coeff_modulus) + [plain_modulus]:
+        m += seal_obj(struct.pack("<Q", int(q)))
+    return seal_obj(m)
+
+
+def model_psu_params(felts, table_size, max_items, hash_funcs, ps_low, query_powers, seal_params, version=1):
+    B = FbBuilder()
+    sp = B.table([("off", B.byte_vector(seal_params))])
+    qp = B.table([("u32", ps_low) if ps_low else None, ("off", B.u32_vector(query_powers))])
+    root = B.table([("u32", version) if version else None, ("struct", struct.pack("<I", felts), 4),
+                    ("struct", struct.pack("<III", table_size, max_items, hash_funcs), 4), ("off", qp), ("off", sp)])
+    return B.finish_size_prefixed(root)
+
+
+def _union(tag, member_builder):
+    B = FbBuilder()
+    m = member_builder(B)
+    root = B.table([("u8", tag), ("off", m)])
+    return B.finish_size_prefixed(root)
+
+
+def test_parameter_exchange_and_plain_response_framing():
+    import json
+    import common
+    js = common.toy_json()
+    p = json.loads(js)
+    # the library's PSUParams::save against the model's reader, field by field
+    mine = wire.psu_params_save(js)
+    R = FbReader(mine)
+    root = R.root()
+    assert R.get_u32(root, 0) == 1
+    assert struct.unpack_from("<I", mine, R.field(root, 1))[0] == p["item_params"]["felts_per_item"]
+    assert struct.unpack_from("<III", mine, R.field(root, 2)) == (p["table_params"]["table_size"], p["table_params"]["max_items_per_bin"],
+                                                                   p["table_params"]["hash_func_count"])
+    back = json.loads(wire.psu_params_load(mine))
+    from oracle import ref
+    C = ref.RefContext.from_params(ref.load_params(js))
+    assert back["seal_params"] == {"plain_modulus": C.t, "poly_modulus_degree": C.n, "coeff_modulus_bits": p["seal_params"]["coeff_modulus_bits"]}
+    assert back["query_params"] == {"ps_low_degree": p["query_params"]["ps_low_degree"], "query_powers": sorted(p["query_params"]["query_powers"])}
+    assert back["table_params"] == p["table_params"] and back["item_params"] == p["item_params"]
+    # the model's PSUParams (its own EncryptionParameters bytes) through the library's reader
+    ep = model_encryption_parameters(C.n, C.q, C.t)
+    theirs = model_psu_params(p["item_params"]["felts_per_item"], p["table_params"]["table_size"], p["table_params"]["max_items_per_bin"],
+                              p["table_params"]["hash_func_count"], p["query_params"]["ps_low_degree"], sorted(p["query_params"]["query_powers"]), ep)
+    assert json.loads(wire.psu_params_load(theirs)) == back
+    assert wire.psu_params_load(wire.psu_params_save(wire.psu_params_load(theirs))) == wire.psu_params_load(theirs)
+    with pytest.raises(RuntimeError, match="serialization version"):
+        wire.psu_params_load(model_psu_params(5, 24, 11, 3, 3, [1, 4], ep, version=2))
+    with pytest.raises(RuntimeError, match="CoeffModulus::Create"):        # primes the JSON form cannot name
+        wire.psu_params_load(model_psu_params(5, 24, 11, 3, 3, [1, 4], model_encryption_parameters(C.n, C.q[::-1], C.t)))
+    with pytest.raises(RuntimeError, match="scheme"):
+        wire.psu_params_load(model_psu_params(5, 24, 11, 3, 3, [1, 4], ep[:16] + bytes([2]) + ep[17:]))
+    # ParmsRequest / ParmsResponse
+    req = wire.build_parms_request()
+    assert wire.peek_type(req) == 1 and wire.peek_type(_union(1, lambda B: B.table([]))) == 1
+    resp = wire.build_parms_response(mine)
+    assert wire.peek_type(resp, is_response=True) == 1 and wire.parse_parms_response(resp) == mine
+    assert wire.parse_parms_response(_union(1, lambda B: B.table([("off", B.byte_vector(theirs))]))) == theirs
+    assert wire.parse_parms_response(_union(1, lambda B: B.table([]))) == b""            # data is optional in the schema
+    R = FbReader(resp)
+    assert R.get_u8(R.root(), 0) == 1
+    with pytest.raises(RuntimeError, match="unexpected operation type"):
+        wire.parse_parms_response(wire.build_query_response(3, 1))
+    # plainResponse: the querier's decrypted results
+    vals = np.array([0, 1, 2**63 + 5, 77], dtype=np.uint64)
+    pr = wire.build_plain_response(2, 5, vals)
+    assert wire.peek_type(pr) == 4
+    got = wire.parse_plain_response(pr)
+    assert (got["bundle_idx"], got["cache_idx"]) == (2, 5) and (got["psu_result"] == vals).all()
+    theirs_pr = _union(4, lambda B: B.table([None, ("off", B.u64_vector([int(v) for v in vals])), ("u32", 9)]))
+    got = wire.parse_plain_response(theirs_pr)
+    assert (got["bundle_idx"], got["cache_idx"]) == (0, 9) and (got["psu_result"] == vals).all()
+    R = FbReader(pr)
+    t = R.field(R.root(), 1)
+    member = t + R.u32(t)
+    assert R.get_u32(member, 0) == 2 and R.get_u32(member, 2) == 5
+    with pytest.raises(RuntimeError):
+        wire.parse_plain_response(req)
+    rng = np.random.default_rng(8)
+    for seed_buf, fn in ((mine, wire.psu_params_load), (pr, wire.parse_plain_response), (resp, wire.parse_parms_response)):
+        for _ in range(800):                                          # corruption never crashes
+            m = bytearray(seed_buf)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                fn(bytes(m))
+            except (RuntimeError, ValueError):
+                pass
+
+
+def test_saved_receiver_db_header_and_walk():
+    """receiver_db.fbs: the header ReceiverDB::save writes, then the BinBundles one after the other"""
+    import json
+    import common
+    js = common.toy_json()
+    params = wire.psu_params_save(js)
+    B = FbBuilder()
+    hashed = B.struct_vector([struct.pack("<QQ", 11 * i + 1, 13 * i + 2) for i in range(5)], 8)
+    key = B.byte_vector(bytes(range(32)))
+    pv = B.byte_vector(params)
+    info = struct.pack("<IIQ??", 0, 16, 5, True, False) + bytes(6)
+    hdr = B.finish_size_prefixed(B.table([("off", pv), ("struct", info, 8), ("off", key), ("off", hashed), ("u32", 2)]))
+    bb0 = build_bin_bundle(0, 65537, [[1, 2], [3]])
+    bb1 = build_bin_bundle(1, 65537, [[], [9, 8, 7]], [b"x" * 30])
+    blob = hdr + bb0 + bb1
+    h = wire.receiver_db_header(blob)
+    assert json.loads(h["params_json"]) == json.loads(wire.psu_params_load(params))
+    assert (h["item_count"], h["bin_bundle_count"], h["compressed"], h["stripped"], h["label_byte_count"], h["consumed"]) == (5, 2, True, False, 0, len(hdr))
+    at = h["consumed"]
+    seen = []
+    for _ in range(h["bin_bundle_count"]):
+        info_bb = wire.bin_bundle_info(blob[at:])
+        seen.append((info_bb["bundle_idx"], info_bb["n_bins"], info_bb["cache_coeffs"]))
+        at += info_bb["consumed"]
+    assert seen == [(0, 2, 0), (1, 2, 1)] and at == len(blob)
+    for bad in (hdr[:-3], hdr[:40], b"\x10\x00\x00\x00" + bytes(16)):
+        with pytest.raises(RuntimeError):
+            wire.receiver_db_header(bad)
