@@ -1,6 +1,7 @@
 """ctypes binding of the SEAL object codec (include/apsu_he.h: apsu_he_seal_*; apsu_amd/csrc/seal_codec.h): seeded / zlib
 ciphertexts, RelinKeys, parms_id.  Host only.  UNPINNED restatement of upstream SEAL (see the header)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -186,3 +187,29 @@ def upload_saved_bundle(ctx, seal_ctx, buf, cache_idx=0):
     bi = C.c_uint32()
     _check(load_library().apsu_he_wire_bin_bundle_info(keep, C.c_size_t(len(buf)), C.byref(bi), None, None, None, None, None, None))
     return Bundle(ctx, h, bi.value, int(cache_idx), deg.value), used.value
+
+
+def load_reference_db(blob, device=0):
+    """A database the reference saved with ReceiverDB::save (receiver_db.fbs header, then one bin_bundle.fbs buffer per BinBundle,
+    receiver_db.cpp:1182-1260) -> (HeContext, SealContext, [Bundle]) with every BinBundle on the device: from its saved cache, or
+    rebuilt on the GPU from the item bins.  cache_idx = a BinBundle's position among those of its bundle index, the order
+    ReceiverDB::Load restores them in (receiver_db.cpp:1380-1420)."""
+    from . import wire
+    from .engine import HeContext
+    if isinstance(blob, (str, os.PathLike)):
+        with open(blob, "rb") as f:
+            blob = f.read()
+    hdr = wire.receiver_db_header(blob)
+    ctx = HeContext(hdr["params_json"], device=device)
+    sc = SealContext(hdr["params_json"])
+    at, seen, bundles = hdr["consumed"], {}, []
+    for _ in range(hdr["bin_bundle_count"]):
+        info = wire.bin_bundle_info(blob[at:])
+        ci = seen.get(info["bundle_idx"], 0)
+        seen[info["bundle_idx"]] = ci + 1
+        b, used = upload_saved_bundle(ctx, sc, blob[at:at + info["consumed"]], ci)
+        bundles.append(b)
+        at += used
+    if at != len(blob):
+        raise ValueError("trailing bytes behind the last BinBundle")
+    return ctx, sc, bundles

@@ -350,3 +350,42 @@ def test_upload_of_a_bin_bundle_as_the_reference_persists_it():
             seal.upload_saved_bundle(G, sc, bad)
     G.close()
     sc.close()
+
+
+def test_a_database_saved_by_the_reference_loads_and_answers_a_query():
+    """ReceiverDB::save's file (receiver_db.fbs header + bin_bundle.fbs buffers; here written by the tests' FlatBuffers model, one
+    BinBundle with its cache, one without) -> apsu_amd.seal.load_reference_db -> the query results of the directly uploaded DB"""
+    import struct
+    from apsu_amd import seal, wire
+    from test_wire_framing import FbBuilder, build_bin_bundle
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11], 1: [7]})
+    C = S.C
+    sc0 = seal.SealContext(js)
+    pci = C.plain_chain_idx(S.ps_low)
+    bins_per_bundle = (C.n // S.p["felts_per_item"]) * S.p["felts_per_item"]
+    rng = np.random.default_rng(3)
+    # bundle index 0: the scenario's BinBundle, saved WITH its cache; bundle index 1: item bins only (rebuilt on the GPU)
+    b0 = S.bundles[0]
+    blobs = [sc0.pt_save(pci if f else -1, c) for c, f in zip(b0["coeffs"], b0["flags"])]
+    bins1 = [sorted(set(int(v) for v in rng.integers(1, C.t, int(rng.integers(0, 8))))) for _ in range(bins_per_bundle)]
+    B = FbBuilder()
+    hashed = B.struct_vector([struct.pack("<QQ", i, i) for i in range(4)], 8)
+    key = B.byte_vector(bytes(32))
+    pv = B.byte_vector(wire.psu_params_save(js))
+    hdr = B.finish_size_prefixed(B.table([("off", pv), ("struct", struct.pack("<IIQ??", 0, 16, 4, False, False) + bytes(6), 8), ("off", key),
+                                          ("off", hashed), ("u32", 2)]))
+    blob = hdr + build_bin_bundle(0, C.t, [[] for _ in range(bins_per_bundle)], blobs) + build_bin_bundle(1, C.t, bins1)
+    G, sc, loaded = seal.load_reference_db(blob)
+    assert [(b.bundle_idx, b.cache_idx) for b in loaded] == [(0, 0), (1, 0)] and loaded[0].degree == 11
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers([0, 1], [[S.src[b][e] for e in S.sources] for b in (0, 1)], rk)
+    direct = [G.upload_bundle(0, 0, b0["coeffs"], b0["flags"]), G.build_bundle(1, 0, bins1)]
+    masks = [b0["mask"], S.bundles[1]["mask"]]
+    got = G.eval_bundles(loaded, pw, rk, masks)
+    assert (got == G.eval_bundles(direct, pw, rk, masks)).all()
+    assert (got[0] == common.oracle_eval(S, common.oracle_powers(S), b0)).all()
+    with pytest.raises(ValueError, match="trailing"):
+        seal.load_reference_db(blob + b"\0\0\0\0")
+    for c in (G, sc, sc0):
+        c.close()
