@@ -3,6 +3,8 @@
 #include "../../include/apsu_he.h"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -33,6 +35,29 @@ static std::mutex g_registry_mu;      // guards every ctx::live_powers / ctx::re
 static std::condition_variable g_registry_cv;
 
 static thread_local std::string g_last_error;
+
+// The SEAL objects of a query are independent: decoded (inflate) and encoded (deflate, the expensive direction) on a few host threads,
+// the way the reference builds its ResultPackages inside its thread-pool tasks (receiver_osn.cpp:334-364,507-539).
+template <class F> static void parallel_for(size_t count, F &&fn)
+{
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t T = std::min(count, std::min<size_t>(16, hw));
+    if (T <= 1) { for (size_t i = 0; i < count; i++) fn(i); return; }
+    std::atomic<size_t> next{ 0 };
+    std::exception_ptr err;
+    std::mutex mu;
+    auto body = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < count;) {
+            try { fn(i); }
+            catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < T; k++) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
 
 template <class F> static int guarded(F &&fn)
 {
@@ -1075,8 +1100,7 @@ namespace {
 // key switching) and the source ciphertexts of the bundle indices `idx`, in (index, ascending exponent) order.
 struct DecodedQuery {
     std::vector<uint64_t> relin_flat;
-    DevBuf dev;                              // [idx][source][2][first_L][n]
-    std::vector<const u64 *> src;            // device pointers into dev
+    std::vector<const u64 *> src;            // device pointers into the engine's staging buffer: [idx][source][2][first_L][n]
 };
 void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size, const std::vector<uint32_t> &idx, DecodedQuery &out)
 {
@@ -1099,45 +1123,45 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
         if (hit->cts.size() != psu->bundle_idx_count) throw std::invalid_argument("one ciphertext per bundle index expected (query.cpp:69-74)");
         parts.push_back(hit);
     }
-    if (hp.using_keyswitching) {
-        if (!q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
-        const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
-        if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
-        out.relin_flat = sealio::relin_keys_layout(kk, sc->K, n);
-    }
+    if (hp.using_keyswitching && !q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
+    // every object of the request is decoded on its own (host threads): the relinearisation keys (task 0) and one task per ciphertext
+    const size_t n_cts = idx.size() * parts.size();
+    u64 *dev = nullptr, *host = nullptr;                           // the engine's staging, kept across queries (caller holds E.wire_mutex())
+    if (n_cts) E.wire_stage(n_cts * ct_words * sizeof(u64), &dev, &host);
+    std::vector<unsigned char> seeded(n_cts, 0);
+    std::vector<uint64_t> seed_of(n_cts * 8, 0);
+    parallel_for(n_cts + 1, [&](size_t task) {
+        if (task == 0) {
+            if (!hp.using_keyswitching) return;
+            const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
+            if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
+            out.relin_flat = sealio::relin_keys_layout(kk, sc->K, n);
+            return;
+        }
+        const size_t k = task - 1, b = k / parts.size(), s2 = k % parts.size();
+        const wire::Span blob = parts[s2]->cts[idx[b]];
+        const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
+        if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
+            throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
+        std::memcpy(host + k * ct_words, ct.data.data(), (ct.seeded ? ct_words / 2 : ct_words) * sizeof(u64));
+        seeded[k] = ct.seeded ? 1 : 0;
+        if (ct.seeded) std::memcpy(&seed_of[k * 8], ct.seed, 64);
+    });
     if (idx.empty()) return;
     // ciphertexts: c0 (and c1 when the object is not seeded) through page-locked memory, seeded c1 expanded on the device
-    struct OnDevice {                                              // allocations below belong to E's device, whatever the caller's thread had selected
-        int prev = -1;
-        explicit OnDevice(int dev) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != dev) { prev = cur; (void)hipSetDevice(dev); } }
-        ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
-    } on_device(E.device());
-    const size_t n_cts = idx.size() * parts.size();
-    out.dev.alloc(n_cts * ct_words * sizeof(u64));
-    void *pinned = nullptr;
-    if (hipHostMalloc(&pinned, n_cts * ct_words * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
-    struct Unpin { void *p; ~Unpin() { (void)hipHostFree(p); } } unpin{ pinned };
-    u64 *host = static_cast<u64 *>(pinned);
     std::vector<uint64_t> seeds;
     std::vector<u64 *> c1;
     out.src.resize(n_cts);
     hipStream_t st = E.stream();
-    for (size_t b = 0; b < idx.size(); b++)
-        for (size_t s2 = 0; s2 < parts.size(); s2++) {
-            const size_t k = b * parts.size() + s2;
-            const wire::Span blob = parts[s2]->cts[idx[b]];
-            const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
-            if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
-                throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
-            u64 *d = out.dev.u() + k * ct_words;
-            const size_t words = ct.seeded ? ct_words / 2 : ct_words;
-            std::memcpy(host + k * ct_words, ct.data.data(), words * sizeof(u64));
-            if (hipMemcpyAsync(d, host + k * ct_words, words * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) throw HipError("upload of a query ciphertext failed");
-            if (ct.seeded) { seeds.insert(seeds.end(), ct.seed, ct.seed + 8); c1.push_back(d + ct_words / 2); }
-            out.src[k] = d;
-        }
+    for (size_t k = 0; k < n_cts; k++) {
+        u64 *d = dev + k * ct_words;
+        const size_t words = seeded[k] ? ct_words / 2 : ct_words;
+        if (hipMemcpyAsync(d, host + k * ct_words, words * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) throw HipError("upload of a query ciphertext failed");
+        if (seeded[k]) { seeds.insert(seeds.end(), seed_of.begin() + k * 8, seed_of.begin() + k * 8 + 8); c1.push_back(d + ct_words / 2); }
+        out.src[k] = d;
+    }
     if (!c1.empty()) E.seed_expand(first, (int)c1.size(), seeds.data(), c1.data());
-    E.wait();                                                       // the page-locked staging dies with this call
+    E.wait();                                                       // the page-locked staging may be refilled by the next query
 }
 
 // ResultPackage of one BinBundle (receiver_osn.cpp:507-539): its result ciphertext saved at the last level
@@ -1163,6 +1187,7 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
     return guarded([&] {
         REQUIRE(c && sc && request && count >= 0 && (count == 0 || (bundles && masks && packages && package_sizes)), "null argument");
         Engine &E = *c->eng;
+        std::lock_guard<std::mutex> one_query(E.wire_mutex());             // the staging buffers serve one query at a time
         // the bundle indices the given BinBundles need, ascending
         std::vector<uint32_t> idx;
         for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); idx.push_back(bundles[i]->b->bundle_idx); }
@@ -1179,10 +1204,15 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
         const size_t n = E.he().n, R = E.result_polys();                // 2 with key switching; longer results without
         std::vector<u64> out((size_t)count * R * n);
         E.eval_bundles(bs.data(), count, *pw, rk.get(), masks, masks_on_device != 0, out.data(), false);
-        E.wait();                                                       // the device buffers of this call die with it
-        for (int i = 0; i < count; i++)
-            result_package(sc, n, bs[i]->bundle_idx, bs[i]->cache_idx, out.data() + (size_t)i * R * n, E.result_size(*bs[i]), result_compr_mode, &packages[i],
-                           &package_sizes[i]);
+        E.wait();
+        E.recycle_powers(std::move(pw));                                // the next query takes the buffers from the pool (no hipMalloc / hipFree per query)
+        for (int i = 0; i < count; i++) { packages[i] = nullptr; package_sizes[i] = 0; }
+        try {
+            parallel_for((size_t)count, [&](size_t i) {
+                result_package(sc, n, bs[i]->bundle_idx, bs[i]->cache_idx, out.data() + i * R * n, E.result_size(*bs[i]), result_compr_mode, &packages[i],
+                               &package_sizes[i]);
+            });
+        } catch (...) { for (int i = 0; i < count; i++) { std::free(packages[i]); packages[i] = nullptr; } throw; }
     });
 }
 
@@ -1198,6 +1228,7 @@ int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc
         const int count = M.bundle_count();
         REQUIRE(count == 0 || (masks && packages && package_sizes && capacity >= count), "one mask and one package slot per registered BinBundle are needed");
         Engine &E = M.engine(0);
+        std::lock_guard<std::mutex> one_query(E.wire_mutex());
         std::vector<uint32_t> idx(M.psu().bundle_idx_count);            // eval_all takes the sources of every bundle index
         for (uint32_t b = 0; b < idx.size(); b++) idx[b] = b;
         DecodedQuery dq;
@@ -1207,10 +1238,13 @@ int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc
         const size_t n = E.he().n, R = E.result_polys();
         std::vector<u64> out((size_t)count * R * n);
         M.eval_all(dq.src.data(), masks, out.data(), -1, MultiEngine::IO_SRC_ON_DEVICE, 0);
-        for (int i = 0; i < count; i++) {
-            const Bundle &b = M.bundle(i);
-            result_package(sc, n, b.bundle_idx, b.cache_idx, out.data() + (size_t)i * R * n, E.result_size(b), result_compr_mode, &packages[i], &package_sizes[i]);
-        }
+        for (int i = 0; i < count; i++) { packages[i] = nullptr; package_sizes[i] = 0; }
+        try {
+            parallel_for((size_t)count, [&](size_t i) {
+                const Bundle &b = M.bundle((int)i);
+                result_package(sc, n, b.bundle_idx, b.cache_idx, out.data() + i * R * n, E.result_size(b), result_compr_mode, &packages[i], &package_sizes[i]);
+            });
+        } catch (...) { for (int i = 0; i < count; i++) { std::free(packages[i]); packages[i] = nullptr; } throw; }
     });
 }
 

@@ -389,6 +389,22 @@ Engine::~Engine()
     for (hipEvent_t e : { query_start_, query_end_ }) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (stage_) (void)hipHostFree(stage_);
+    if (wire_pinned_) (void)hipHostFree(wire_pinned_);
+}
+
+void Engine::wire_stage(size_t bytes, u64 **device, u64 **pinned)
+{
+    Enter g(this);                                               // (device guard; the buffers belong to this engine's device)
+    if (wire_dev_.bytes() < bytes) { sync(); wire_dev_.alloc(bytes + bytes / 4); }
+    if (wire_pinned_bytes_ < bytes) {
+        sync();
+        if (wire_pinned_) (void)hipHostFree(wire_pinned_);
+        wire_pinned_ = nullptr; wire_pinned_bytes_ = 0;
+        HIP_CHECK(hipHostMalloc(&wire_pinned_, bytes + bytes / 4));
+        wire_pinned_bytes_ = bytes + bytes / 4;
+    }
+    *device = wire_dev_.u();
+    *pinned = static_cast<u64 *>(wire_pinned_);
 }
 
 void Engine::sync()

@@ -192,6 +192,10 @@ public:
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
                         int *is_ntt);
     int device() const { return device_; }
+    // Staging of apsu_he_run_query_request (c_api.cpp) kept across calls: a device buffer and a page-locked host buffer of at least
+    // `bytes` (grown on demand; hipHostMalloc / hipMalloc per query cost milliseconds).  The caller holds wire_mutex() for the whole query.
+    std::mutex &wire_mutex() { return wire_mu_; }
+    void wire_stage(size_t bytes, u64 **device, u64 **pinned);
 
 private:
     // arena (bump allocator reset per top-level operation)
@@ -280,6 +284,10 @@ public:
 private:
     std::vector<DevBuf> retired_;     // arenas replaced while kernels may still reference them
     uint64_t counters_[C_COUNT] = {};
+    std::mutex wire_mu_;
+    DevBuf wire_dev_;
+    void *wire_pinned_ = nullptr;
+    size_t wire_pinned_bytes_ = 0;
 
     // PowersDag schedule (slot order = depth, parents first, power)
     struct Sched {

@@ -20,6 +20,15 @@ namespace {
 
 uint64_t rd64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
 void wr64(std::vector<uint8_t> &b, uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+// coefficient arrays: little-endian words on the wire = this host's memory layout (x86-64): one copy instead of a loop per byte
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the coefficient arrays are copied as little-endian words");
+void rd64n(uint64_t *dst, const uint8_t *p, size_t count) { if (count) std::memcpy(dst, p, count * 8); }
+void wr64n(std::vector<uint8_t> &b, const uint64_t *src, size_t count)
+{
+    const size_t at = b.size();
+    b.resize(at + count * 8);
+    if (count) std::memcpy(b.data() + at, src, count * 8);
+}
 
 constexpr size_t MAX_BODY = (size_t)1 << 30;                    // inflated size cap (zip bombs)
 
@@ -227,7 +236,7 @@ void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::
     if (count > total) bad("coefficient array larger than the ciphertext");
     a.need((size_t)count * 8);
     ct.data.assign((size_t)total, 0);
-    for (uint64_t i = 0; i < count; i++) ct.data[(size_t)i] = rd64(a.here() + 8 * i);
+    rd64n(ct.data.data(), a.here(), (size_t)count);
     if (count == total) { ct.seeded = false; return; }
     if (!(ct.size == 2 && count == poly_words)) bad("inconsistent coefficient array size");
     // seeded: the generator's description follows; c1 is what it samples
@@ -263,7 +272,7 @@ std::vector<uint8_t> ciphertext_members(const Ciphertext &ct)
     const uint64_t count = ct.seeded ? poly_words : total;
     std::vector<uint8_t> arr;
     wr64(arr, count);
-    for (uint64_t i = 0; i < count; i++) wr64(arr, ct.data[(size_t)i]);
+    wr64n(arr, ct.data.data(), (size_t)count);
     const std::vector<uint8_t> ao = close_object(arr, ct.version_major, ct.version_minor, COMPR_NONE);
     m.insert(m.end(), ao.begin(), ao.end());
     if (ct.seeded) {
@@ -400,7 +409,7 @@ Plaintext load_plaintext(const uint8_t *buf, size_t size, size_t *consumed)
     if (count != pt.coeff_count) bad("plaintext coefficient array does not match coeff_count");
     a.need((size_t)count * 8);
     pt.data.resize((size_t)count);
-    for (uint64_t i = 0; i < count; i++) pt.data[(size_t)i] = rd64(a.here() + 8 * i);
+    rd64n(pt.data.data(), a.here(), (size_t)count);
     if (consumed) *consumed = (size_t)b.h.total;
     return pt;
 }
@@ -414,7 +423,7 @@ std::vector<uint8_t> save_plaintext(const Plaintext &pt, uint8_t compr)
     { uint64_t s; std::memcpy(&s, &pt.scale, 8); wr64(m, s); }
     std::vector<uint8_t> arr;
     wr64(arr, pt.coeff_count);
-    for (uint64_t w : pt.data) wr64(arr, w);
+    wr64n(arr, pt.data.data(), pt.data.size());
     const std::vector<uint8_t> ao = close_object(arr, pt.version_major, pt.version_minor, COMPR_NONE);
     m.insert(m.end(), ao.begin(), ao.end());
     return close_object(m, pt.version_major, pt.version_minor, compr);
