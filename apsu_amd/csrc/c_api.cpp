@@ -1126,6 +1126,11 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
     if (hp.using_keyswitching && !q.has_relin_keys) throw std::invalid_argument("the query carries no relinearization keys");
     // every object of the request is decoded on its own (host threads): the relinearisation keys (task 0) and one task per ciphertext
     const size_t n_cts = idx.size() * parts.size();
+    struct OnDevice {                                              // the copies below are queued on E's stream: its device must be the current one
+        int prev = -1;
+        explicit OnDevice(int d) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != d) { prev = cur; (void)hipSetDevice(d); } }
+        ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } on_device(E.device());
     u64 *dev = nullptr, *host = nullptr;                           // the engine's staging, kept across queries (caller holds E.wire_mutex())
     if (n_cts) E.wire_stage(n_cts * ct_words * sizeof(u64), &dev, &host);
     std::vector<unsigned char> seeded(n_cts, 0);
