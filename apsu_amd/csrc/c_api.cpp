@@ -1100,9 +1100,13 @@ namespace {
 // key switching) and the source ciphertexts of the bundle indices `idx`, in (index, ascending exponent) order.
 struct DecodedQuery {
     std::vector<uint64_t> relin_flat;
+    // seeded RelinKeys left for the device to expand (keys_on_device): c1 of key d sits at word key_c1_at[i] of relin_flat / of the uploaded keys
+    std::vector<uint64_t> key_seeds;
+    std::vector<size_t> key_c1_at;
     std::vector<const u64 *> src;            // device pointers into the engine's staging buffer: [idx][source][2][first_L][n]
 };
-void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size, const std::vector<uint32_t> &idx, DecodedQuery &out)
+void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size, const std::vector<uint32_t> &idx, DecodedQuery &out,
+                  bool keys_on_device)
 {
     const PSUParams *psu = E.psu();
     REQUIRE(psu, "context was created without PSUParams");
@@ -1138,9 +1142,18 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
     parallel_for(n_cts + 1, [&](size_t task) {
         if (task == 0) {
             if (!hp.using_keyswitching) return;
-            const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain);
+            // (expanding the seeded halves of the keys on the host is ~0.5 ms per key on this call's critical path; the single-device caller
+            //  leaves it to apsu_he_seed_expand's kernels on the uploaded keys)
+            const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain, nullptr, !keys_on_device);
             if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
             out.relin_flat = sealio::relin_keys_layout(kk, sc->K, n);
+            if (keys_on_device && !kk.keys.empty())
+                for (size_t d = 0; d < kk.keys[0].size(); d++)
+                    if (kk.keys[0][d].seeded) {
+                        if (std::memcmp(kk.keys[0][d].parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("a seeded RelinKeys entry is not at the key level");
+                        out.key_seeds.insert(out.key_seeds.end(), kk.keys[0][d].seed, kk.keys[0][d].seed + 8);
+                        out.key_c1_at.push_back((d * 2 + 1) * sc->K * n);
+                    }
             return;
         }
         const size_t k = task - 1, b = k / parts.size(), s2 = k % parts.size();
@@ -1199,10 +1212,17 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
         std::sort(idx.begin(), idx.end());
         idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
         DecodedQuery dq;
-        decode_query(E, sc, request, request_size, idx, dq);
+        decode_query(E, sc, request, request_size, idx, dq, true);
         if (idx.empty()) return;
         std::unique_ptr<RelinKeys> rk;
-        if (!dq.relin_flat.empty()) rk = E.upload_relin_keys(dq.relin_flat.data());
+        if (!dq.relin_flat.empty()) {
+            rk = E.upload_relin_keys(dq.relin_flat.data());
+            if (!dq.key_c1_at.empty()) {                                 // c1 of the seeded keys: sampled by the device, in place
+                std::vector<u64 *> dst;
+                for (size_t at : dq.key_c1_at) dst.push_back(rk->data.u() + at);
+                E.seed_expand(-1, (int)dst.size(), dq.key_seeds.data(), dst.data());
+            }
+        }
         std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), dq.src.data(), true, rk.get());
         std::vector<const Bundle *> bs(count);
         for (int i = 0; i < count; i++) bs[i] = bundles[i]->b.get();
@@ -1237,7 +1257,7 @@ int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc
         std::vector<uint32_t> idx(M.psu().bundle_idx_count);            // eval_all takes the sources of every bundle index
         for (uint32_t b = 0; b < idx.size(); b++) idx[b] = b;
         DecodedQuery dq;
-        decode_query(E, sc, request, request_size, idx, dq);
+        decode_query(E, sc, request, request_size, idx, dq, false);       // (keys expanded on the host: every device gets a copy)
         if (!count) return;
         if (!dq.relin_flat.empty()) M.upload_relin_keys(dq.relin_flat.data());
         const size_t n = E.he().n, R = E.result_polys();

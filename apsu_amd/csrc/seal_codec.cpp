@@ -429,7 +429,7 @@ std::vector<uint8_t> save_plaintext(const Plaintext &pt, uint8_t compr)
     return close_object(m, pt.version_major, pt.version_minor, compr);
 }
 
-KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed)
+KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed, bool expand)
 {
     if (!buf) bad("null buffer");
     Body b = open_object(buf, size);
@@ -449,7 +449,7 @@ KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector
             Body cb = open_object(pk.p, pk.n);
             Cursor cc{ cb.p, cb.n };
             Ciphertext ct;
-            parse_ciphertext_members(cc, cb.h.vmaj, cb.h.vmin, chain, ct);
+            parse_ciphertext_members(cc, cb.h.vmaj, cb.h.vmin, chain, ct, expand);
             k.keys[(size_t)i].push_back(std::move(ct));
         }
     }

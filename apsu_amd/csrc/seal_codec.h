@@ -101,7 +101,8 @@ struct KSwitchKeys {
     std::vector<std::vector<Ciphertext>> keys;          // [dim1][dim2]
     uint8_t version_major = 4, version_minor = 0;
 };
-KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr);
+// expand = false: seeded keys keep c1 zero and their seed (Ciphertext::seeded / seed), for a caller that expands them on the device
+KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector<Level> &chain, size_t *consumed = nullptr, bool expand = true);
 std::vector<uint8_t> save_kswitch_keys(const KSwitchKeys &k, uint8_t compr);
 // RelinKeys -> the [decomp][2][K][n] array apsu_he_relin_upload takes (keys[0][*], every one size 2 at the key level, NTT form)
 std::vector<uint64_t> relin_keys_layout(const KSwitchKeys &k, size_t K, size_t n);

@@ -161,3 +161,42 @@ def test_seed_expansion_on_the_device_equals_the_host_codec(bits):
         assert (out.cpu().numpy().view(np.uint64)[:2] == got[:2]).all()
     G.close()
     sc.close()
+
+
+def test_seeded_relin_keys_are_expanded_on_the_device():
+    """apsu_he_run_query_request with Serializable<RelinKeys> as KeyGenerator::create_relin_keys saves them (sender_osn.cpp:223-227):
+    the second polynomial of every key comes as a seed; the single-device path samples it on the GPU, in place in the uploaded
+    keys.  Parity is about the arithmetic: the keys' c1 are replaced by the seeds' expansions (the keys then no longer decrypt),
+    and every result must equal the oracle's under the very same keys; the multi-device handle (host expansion) must agree."""
+    js = common.toy_json()
+    S = common.make_scenario(js, {0: [11, 4], 1: [7]})
+    C = S.C
+    sc = seal.SealContext(js)
+    rng = np.random.default_rng(5)
+    seeds = rng.integers(0, 2**63, (C.K - 1, 8), dtype=np.uint64)
+    ksk = S.rk.copy()
+    for d in range(C.K - 1):
+        ksk[d, 1] = sc.sample_poly_uniform(-1, [int(x) for x in seeds[d]], C.K, C.n)
+    rk_blob = sc.relin_keys_save(ksk, seeds=seeds, compr=seal.COMPR_ZLIB)
+    back, _ = sc.relin_keys_load(rk_blob)
+    assert (back.reshape(ksk.shape) == ksk).all() and len(rk_blob) < ksk.nbytes * 0.7
+    parts = [(e, [sc.ct_save(C.first, False, S.src[b][e] if b in S.src else S.src[0][e]) for b in range(S.p["bundle_idx_count"])]) for e in S.sources]
+    msg = wire.build_query_request(seal.COMPR_ZLIB, rk_blob, parts)
+    G = apsu_amd.HeContext(js)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    pkgs = seal.run_query_request(G, sc, msg, gb, masks)
+    S.rk = ksk                                                   # the oracle under the same keys
+    opw = common.oracle_powers(S)
+    for i, b in enumerate(S.bundles):
+        got = sc.ct_load(wire.parse_result_package(pkgs[i])["psu_result"])["data"]
+        assert (got == common.oracle_eval(S, opw, b)).all(), "bundle %d" % i
+    units = [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+    M = apsu_amd.MultiContext(js, [0, 0])
+    slots = apsu_amd.partition_bundles(units, S.p["bundle_idx_count"], 2)
+    for i, b in enumerate(S.bundles):
+        M.upload_bundle(slots[i], b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"])
+    assert seal.multi_run_query_request(M, sc, msg, masks) == pkgs
+    M.close()
+    G.close()
+    sc.close()
