@@ -1257,9 +1257,10 @@ int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc
         std::vector<uint32_t> idx(M.psu().bundle_idx_count);            // eval_all takes the sources of every bundle index
         for (uint32_t b = 0; b < idx.size(); b++) idx[b] = b;
         DecodedQuery dq;
-        decode_query(E, sc, request, request_size, idx, dq, false);       // (keys expanded on the host: every device gets a copy)
+        decode_query(E, sc, request, request_size, idx, dq, true);
         if (!count) return;
-        if (!dq.relin_flat.empty()) M.upload_relin_keys(dq.relin_flat.data());
+        if (!dq.relin_flat.empty())                                       // every device samples the seeded halves of its copy itself
+            M.upload_relin_keys_seeded(dq.relin_flat.data(), dq.key_seeds.data(), dq.key_c1_at.data(), (int)dq.key_c1_at.size());
         const size_t n = E.he().n, R = E.result_polys();
         std::vector<u64> out((size_t)count * R * n);
         M.eval_all(dq.src.data(), masks, out.data(), -1, MultiEngine::IO_SRC_ON_DEVICE, 0);

@@ -116,6 +116,18 @@ void MultiEngine::upload_relin_keys(const u64 *ksk)
     run_all([&](Dev &d) { d.rk = d.eng->upload_relin_keys(ksk); });
 }
 
+void MultiEngine::upload_relin_keys_seeded(const u64 *ksk, const u64 *seeds, const size_t *c1_at, int n_seeded)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    run_all([&](Dev &d) {
+        d.rk = d.eng->upload_relin_keys(ksk);
+        if (n_seeded <= 0) return;
+        std::vector<u64 *> dst(n_seeded);
+        for (int i = 0; i < n_seeded; i++) dst[i] = d.rk->data.u() + c1_at[i];
+        d.eng->seed_expand(-1, n_seeded, seeds, dst.data());
+    });
+}
+
 int MultiEngine::upload_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs, const u64 *const *coeff_ptrs,
                                const unsigned char *is_ntt)
 {

@@ -30,6 +30,8 @@ public:
     const HeParams &he() const { return hp_; }
 
     void upload_relin_keys(const u64 *ksk);                      // replicated on every device
+    // the same with seeded keys: c1 of entry i (at word c1_at[i] of ksk) is sampled from seeds[i * 8 ..] on every device, in place
+    void upload_relin_keys_seeded(const u64 *ksk, const u64 *seeds, const size_t *c1_at, int n_seeded);
     // DB placement: the bundle's id is its registration order (= its row in eval_all's output)
     int upload_bundle(int slot, uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs, const u64 *const *coeff_ptrs,
                       const unsigned char *is_ntt);

@@ -167,7 +167,7 @@ def test_seeded_relin_keys_are_expanded_on_the_device():
     """apsu_he_run_query_request with Serializable<RelinKeys> as KeyGenerator::create_relin_keys saves them (sender_osn.cpp:223-227):
     the second polynomial of every key comes as a seed; the single-device path samples it on the GPU, in place in the uploaded
     keys.  Parity is about the arithmetic: the keys' c1 are replaced by the seeds' expansions (the keys then no longer decrypt),
-    and every result must equal the oracle's under the very same keys; the multi-device handle (host expansion) must agree."""
+    and every result must equal the oracle's under the very same keys; the multi-device handle (every device samples its own copy) must agree."""
     js = common.toy_json()
     S = common.make_scenario(js, {0: [11, 4], 1: [7]})
     C = S.C
