@@ -1105,8 +1105,9 @@ struct DecodedQuery {
     std::vector<size_t> key_c1_at;
     std::vector<const u64 *> src;            // device pointers into the engine's staging buffer: [idx][source][2][first_L][n]
 };
+// dev / host: the engine's staging (Engine::wire_stage, at least idx.size() * query_powers.size() ciphertexts), caller holds E.wire_mutex()
 void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request, size_t request_size, const std::vector<uint32_t> &idx, DecodedQuery &out,
-                  bool keys_on_device)
+                  bool keys_on_device, u64 *dev, u64 *host)
 {
     const PSUParams *psu = E.psu();
     REQUIRE(psu, "context was created without PSUParams");
@@ -1135,8 +1136,6 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
         explicit OnDevice(int d) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != d) { prev = cur; (void)hipSetDevice(d); } }
         ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
     } on_device(E.device());
-    u64 *dev = nullptr, *host = nullptr;                           // the engine's staging, kept across queries (caller holds E.wire_mutex())
-    if (n_cts) E.wire_stage(n_cts * ct_words * sizeof(u64), &dev, &host);
     std::vector<unsigned char> seeded(n_cts, 0);
     std::vector<uint64_t> seed_of(n_cts * 8, 0);
     parallel_for(n_cts + 1, [&](size_t task) {
@@ -1211,9 +1210,23 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
         for (int i = 0; i < count; i++) { REQUIRE(bundles[i], "null bundle"); idx.push_back(bundles[i]->b->bundle_idx); }
         std::sort(idx.begin(), idx.end());
         idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+        const PSUParams *psu = E.psu();
+        REQUIRE(psu, "context was created without PSUParams");
+        // one staging area for the whole query, kept across calls: [source ciphertexts | masks | results], device and page-locked host
+        const size_t n = E.he().n, R = E.result_polys();                // 2 with key switching; longer results without
+        const size_t ct_words = (size_t)2 * (E.he().first_chain_idx + 1) * n;
+        const size_t src_words = idx.size() * psu->query_params.query_powers.size() * ct_words;
+        const size_t mask_words = masks_on_device ? 0 : (size_t)count * n, res_words = (size_t)count * R * n;
+        u64 *dev = nullptr, *host = nullptr;
+        E.wire_stage((src_words + mask_words + res_words) * sizeof(u64) + 64, &dev, &host);
         DecodedQuery dq;
-        decode_query(E, sc, request, request_size, idx, dq, true);
+        decode_query(E, sc, request, request_size, idx, dq, true, dev, host);
         if (idx.empty()) return;
+        struct OnDevice {
+            int prev = -1;
+            explicit OnDevice(int d) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != d) { prev = cur; (void)hipSetDevice(d); } }
+            ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+        } on_device(E.device());
         std::unique_ptr<RelinKeys> rk;
         if (!dq.relin_flat.empty()) {
             rk = E.upload_relin_keys(dq.relin_flat.data());
@@ -1226,15 +1239,24 @@ int apsu_he_run_query_request(apsu_he_ctx *c, const apsu_he_seal_ctx *sc, const 
         std::unique_ptr<Powers> pw = E.compute_powers(idx.data(), (int)idx.size(), dq.src.data(), true, rk.get());
         std::vector<const Bundle *> bs(count);
         for (int i = 0; i < count; i++) bs[i] = bundles[i]->b.get();
-        const size_t n = E.he().n, R = E.result_polys();                // 2 with key switching; longer results without
-        std::vector<u64> out((size_t)count * R * n);
-        E.eval_bundles(bs.data(), count, *pw, rk.get(), masks, masks_on_device != 0, out.data(), false);
+        // masks through the page-locked staging in one copy (28 pageable 64 KiB copies cost more than the evaluation's launch overhead)
+        std::vector<const u64 *> mptr(count);
+        if (masks_on_device) {
+            for (int i = 0; i < count; i++) mptr[i] = masks[i];
+        } else {
+            for (int i = 0; i < count; i++) { REQUIRE(masks[i], "null mask"); std::memcpy(host + src_words + (size_t)i * n, masks[i], n * sizeof(u64)); mptr[i] = dev + src_words + (size_t)i * n; }
+            if (hipMemcpyAsync(dev + src_words, host + src_words, mask_words * sizeof(u64), hipMemcpyHostToDevice, E.stream()) != hipSuccess)
+                throw HipError("upload of the masks failed");
+        }
+        u64 *res_dev = dev + src_words + mask_words, *res_host = host + src_words + mask_words;
+        E.eval_bundles(bs.data(), count, *pw, rk.get(), mptr.data(), true, res_dev, true);
+        if (hipMemcpyAsync(res_host, res_dev, res_words * sizeof(u64), hipMemcpyDeviceToHost, E.stream()) != hipSuccess) throw HipError("download of the results failed");
         E.wait();
         E.recycle_powers(std::move(pw));                                // the next query takes the buffers from the pool (no hipMalloc / hipFree per query)
         for (int i = 0; i < count; i++) { packages[i] = nullptr; package_sizes[i] = 0; }
         try {
             parallel_for((size_t)count, [&](size_t i) {
-                result_package(sc, n, bs[i]->bundle_idx, bs[i]->cache_idx, out.data() + i * R * n, E.result_size(*bs[i]), result_compr_mode, &packages[i],
+                result_package(sc, n, bs[i]->bundle_idx, bs[i]->cache_idx, res_host + i * R * n, E.result_size(*bs[i]), result_compr_mode, &packages[i],
                                &package_sizes[i]);
             });
         } catch (...) { for (int i = 0; i < count; i++) { std::free(packages[i]); packages[i] = nullptr; } throw; }
@@ -1256,8 +1278,11 @@ int apsu_he_multi_run_query_request(apsu_he_multi *m, const apsu_he_seal_ctx *sc
         std::lock_guard<std::mutex> one_query(E.wire_mutex());
         std::vector<uint32_t> idx(M.psu().bundle_idx_count);            // eval_all takes the sources of every bundle index
         for (uint32_t b = 0; b < idx.size(); b++) idx[b] = b;
+        const size_t ct_words = (size_t)2 * (E.he().first_chain_idx + 1) * E.he().n;
+        u64 *dev = nullptr, *host = nullptr;
+        E.wire_stage(idx.size() * M.psu().query_params.query_powers.size() * ct_words * sizeof(u64) + 64, &dev, &host);
         DecodedQuery dq;
-        decode_query(E, sc, request, request_size, idx, dq, true);
+        decode_query(E, sc, request, request_size, idx, dq, true, dev, host);
         if (!count) return;
         if (!dq.relin_flat.empty())                                       // every device samples the seeded halves of its copy itself
             M.upload_relin_keys_seeded(dq.relin_flat.data(), dq.key_seeds.data(), dq.key_c1_at.data(), (int)dq.key_c1_at.size());
