@@ -421,6 +421,49 @@ def main():
         except Exception as e:                                          # never lose the main line
             result["host_io"] = {"error": str(e)}
 
+    # ---- the same query from the WIRE (rank 0, N=1 only; never `value`) ------------------------
+    # apsu_he_run_query_request: the framed QueryRequest as the reference's querier sends it (SEAL objects: seeded ciphertexts + seeded
+    # RelinKeys; query.cpp:44-80) in, one framed ResultPackage per BinBundle out; parse, inflate, seed expansion on the device, the query,
+    # serialise -- host wall clock.  The same source ciphertexts as above (c0 from src_host; c1 = the seed's expansion), same masks.
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_host_io and rk_host is not None:
+        try:
+            from apsu_amd import seal as _seal, wire as _wire
+            sc = _seal.SealContext(params_json)
+            wrng = np.random.default_rng(SEED0 + 7)
+            powers = sorted(int(p) for p in json.loads(params_json)["query_params"]["query_powers"])
+            mlist = [np.ascontiguousarray(mask_host[unit_pos[(u[0], u[1])]]) for u in mine]
+            wio = {}
+            for compr, name in ((_seal.COMPR_NONE, "none"), (_seal.COMPR_ZSTD, "zstd"), (_seal.COMPR_ZLIB, "zlib")):
+                try:
+                    parts = []
+                    for si, e in enumerate(powers):
+                        cts = []
+                        for b in range(ctx.bundle_idx_count):
+                            seed = [int(x) for x in wrng.integers(0, 2**63, 8, dtype=np.uint64)]
+                            cts.append(sc.ct_save(first, False, np.ascontiguousarray(src_host[b, si]), seed=seed, compr=compr))
+                        parts.append((e, cts))
+                    kseeds = wrng.integers(0, 2**63, (K - 1, 8), dtype=np.uint64)
+                    msg = _wire.build_query_request(compr, sc.relin_keys_save(rk_host, seeds=kseeds, compr=compr), parts)
+                    for _ in range(2):
+                        pk = _seal.run_query_request(ctx, sc, msg, bundles, mlist, compr=compr)
+                    ts = []
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        pk = _seal.run_query_request(ctx, sc, msg, bundles, mlist, compr=compr)
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                    wio[name + "_ms"] = round(sorted(ts)[2], 3)
+                    wio[name + "_bytes"] = {"request": len(msg), "packages": sum(len(x) for x in pk)}
+                except Exception as e:                                  # e.g. no libzstd on the box
+                    wio[name + "_ms"] = None
+                    wio[name + "_error"] = str(e)
+            wio["note"] = ("apsu_he_run_query_request, one query at a time, host wall clock incl. the Python binding: framed QueryRequest (seeded "
+                           "ciphertexts + seeded RelinKeys as SEAL objects under compr none / zstd / zlib) -> %d framed ResultPackages; SEAL's object "
+                           "format is restated, unpinned (apsu_amd/csrc/seal_codec.h)" % len(bundles))
+            result["wire_io"] = wio
+            sc.close()
+        except Exception as e:                                          # never lose the main line
+            result["wire_io"] = {"error": str(e)}
+
     # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host,
