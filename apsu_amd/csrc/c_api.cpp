@@ -1158,7 +1158,9 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
         const size_t k = task - 1, b = k / parts.size(), s2 = k % parts.size();
         const wire::Span blob = parts[s2]->cts[idx[b]];
         const sealio::Ciphertext ct = sealio::load_ciphertext(blob.p, blob.n, sc->chain, nullptr, false);
-        if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n)
+        // (SEALObject::extract -> is_valid_for in the reference, seal_object.h:161-219: dimensions must be the level's, not the peer's claim)
+        if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n ||
+            ct.coeff_modulus_size != Lf || ct.data.size() != ct_words)
             throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
         std::memcpy(host + k * ct_words, ct.data.data(), (ct.seeded ? ct_words / 2 : ct_words) * sizeof(u64));
         seeded[k] = ct.seeded ? 1 : 0;

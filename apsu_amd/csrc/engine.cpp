@@ -6,6 +6,7 @@
 // (drop-limb, BEHZ floor, key-switch mod-down) is applied per term exactly where the reference
 // applies it (SURVEY.md §2.4 note N1), so results are bit-identical to the CPU path.
 #include "engine.h"
+#include "seal_codec.h"
 
 #include <algorithm>
 #include <array>
@@ -1654,7 +1655,20 @@ void Engine::seed_expand(int chain_idx, int count, const u64 *seeds, u64 *const 
     const bool key_level = chain_idx < 0 || chain_idx == hp_.K - 1;
     if (!key_level) check_level(chain_idx);
     const int L = key_level ? hp_.K : chain_idx + 1;
-    if (L > DMAXL) throw std::invalid_argument("too many RNS limbs for the device-side seed expansion");
+    // The device list holds 8192 rejected words per object.  The rejection rate is ~q / 2^64 per word, so ~60-bit primes with a large
+    // L * n may legitimately exceed it (and L may exceed the device tables): those objects are expanded by the host's
+    // sample_poly_uniform (seal_codec.cpp) and uploaded -- slower, same words.  APSU_HE_SEED_EXPAND_HOST=1 forces that path (tests).
+    auto host_expand = [&] {
+        std::vector<u64> q(hp_.key_q.begin(), hp_.key_q.begin() + L), buf((size_t)L * hp_.n);
+        for (int i = 0; i < count; i++) {
+            if (!dst[i]) throw std::invalid_argument("null destination");
+            sealio::sample_poly_uniform(seeds + (size_t)i * 8, q.data(), (size_t)L, hp_.n, buf.data());
+            HIP_CHECK(hipMemcpyAsync(dst[i], buf.data(), buf.size() * sizeof(u64), hipMemcpyHostToDevice, st_));
+            sync();                                              // buf is reused
+        }
+    };
+    static const bool force_host = [] { const char *v = std::getenv("APSU_HE_SEED_EXPAND_HOST"); return v && std::atoi(v) != 0; }();
+    if (L > DMAXL || force_host) { host_expand(); return; }
     const DevLevel *lv = nullptr;
     if (key_level && hp_.K - 1 > hp_.first_chain_idx) {
         // the key level is not a data level: a DevLevel-shaped view that carries its moduli only
@@ -1694,7 +1708,7 @@ void Engine::seed_expand(int chain_idx, int count, const u64 *seeds, u64 *const 
     if (h_overflow) {
         HIP_CHECK(hipMemsetAsync(d_seed_rej_.p(), 0, d_seed_rej_.bytes(), st_));
         sync();
-        throw std::logic_error("seed expansion: more rejected words than the device list holds (modulus too close to 2^64)");
+        host_expand();                                           // more rejected words than the device list holds: the host redoes these objects
     }
 }
 

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <stdexcept>
@@ -204,13 +205,16 @@ struct MultiEngine::Rccl {
     typedef int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
     typedef int (*Destroy)(void *);
     typedef const char *(*ErrStr)(int);
-    InitAll init_all = nullptr; AllGather all_gather = nullptr; Destroy destroy = nullptr; ErrStr err = nullptr;
+    InitAll init_all = nullptr; AllGather all_gather = nullptr; Destroy destroy = nullptr, abort = nullptr; ErrStr err = nullptr;
     std::vector<void *> comms;
+    std::atomic<bool> broken{ false };                           // a collective failed: communicators were aborted, fall back to peer copies
+    void abort_all() { broken = true; if (abort) for (void *&c : comms) if (c) { (void)abort(c); c = nullptr; } }
     ~Rccl() { if (destroy) for (void *c : comms) if (c) (void)destroy(c); if (lib) dlclose(lib); }
 };
 
 bool MultiEngine::rccl_ready()
 {
+    if (rccl_ && rccl_->broken) rccl_.reset();                     // an earlier collective failed (eval_all): peer copies from now on
     if (rccl_tried_) return (bool)rccl_;
     rccl_tried_ = true;
     std::vector<int> devlist;
@@ -226,6 +230,7 @@ bool MultiEngine::rccl_ready()
     r->all_gather = (Rccl::AllGather)dlsym(r->lib, "ncclAllGather");
     r->destroy = (Rccl::Destroy)dlsym(r->lib, "ncclCommDestroy");
     r->err = (Rccl::ErrStr)dlsym(r->lib, "ncclGetErrorString");
+    r->abort = (Rccl::Destroy)dlsym(r->lib, "ncclCommAbort");
     if (!r->init_all || !r->all_gather || !r->destroy) return false;
     r->comms.assign(devlist.size(), nullptr);
     if (r->init_all(r->comms.data(), (int)devlist.size(), devlist.data()) != 0) { r->comms.clear(); return false; }
@@ -357,10 +362,25 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
     // kernels, so the kernels that consume / produce the query's buffers anyway (the source gather of ComputePowers, the
     // evaluation's epilogue) read and write them IN PLACE over PCIe / xGMI: 80 small copies per query (24 ciphertexts, 28
     // masks, 28 result rows at ~8 us each) become none.  Pageable host buffers go through the device's own page-locked area.
+    // With the RCCL gather every worker must reach the collective or none may: a worker that fails before it (ComputePowers,
+    // the evaluation, an allocation) would leave the others waiting in the all-gather for ever, with mu_ held.  So the compute part
+    // is guarded per worker, the workers meet once, and the collective is entered only if nobody failed.
+    struct Rendezvous {
+        std::mutex m; std::condition_variable cv; size_t arrived = 0, expect; size_t failed = 0;
+        explicit Rendezvous(size_t e) : expect(e) {}
+        bool arrive(bool ok) {                                    // true iff every worker arrived without a failure
+            std::unique_lock<std::mutex> lk(m);
+            if (!ok) failed++;
+            if (++arrived == expect) cv.notify_all(); else cv.wait(lk, [&] { return arrived == expect; });
+            return failed == 0;
+        }
+    } meet(devs_.size());
     run_all([&](Dev &d) {
         const int cnt = (int)d.bundles.size();
         Engine &E = *d.eng;
         hipStream_t st = E.stream();
+        std::exception_ptr compute_error;
+        try {
         auto reachable = [&](int other_device) {                  // may kernels on d.device address memory of other_device?
             if (other_device == d.device) return true;
             int can = 0;
@@ -443,7 +463,11 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             }
             E.recycle_powers(std::move(pw));
         }
+        } catch (...) { compute_error = std::current_exception(); }
         if (use_rccl) {
+            const bool all_ok = meet.arrive(!compute_error);
+            if (compute_error) std::rethrow_exception(compute_error);
+            if (!all_ok) { (void)hipStreamSynchronize(st); throw std::runtime_error("another device failed before the RCCL gather; nothing was gathered"); }
             // ONE all-gather of max_rows fixed-size rows per device, then the output device places them by id
             int slot = 0;
             for (size_t i = 0; i < devs_.size(); i++) if (devs_[i].get() == &d) slot = (int)i;
@@ -451,7 +475,11 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             if (d.gath.bytes() < need) { E.wait(); d.gath.alloc(need); }
             if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.wait(); d.out.alloc(max_rows * row * sizeof(u64)); }
             const int rc = rccl_->all_gather(d.out.u(), d.gath.u(), max_rows * row, /* ncclUint64 */ 5, rccl_->comms[slot], st);
-            if (rc != 0) throw std::runtime_error(std::string("RCCL all-gather failed: ") + (rccl_->err ? rccl_->err(rc) : "?"));
+            if (rc != 0) {                                        // the peers may already sit in the collective: abort every communicator so they return
+                const std::string why = rccl_->err ? rccl_->err(rc) : "?";
+                rccl_->abort_all();
+                throw std::runtime_error("RCCL all-gather failed: " + why);
+            }
             if (d.device == out_device && slot == out_slot) {
                 for (size_t s2 = 0; s2 < devs_.size(); s2++)
                     for (size_t i = 0; i < devs_[s2]->ids.size(); i++)
@@ -459,7 +487,7 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
                                                  hipMemcpyDeviceToDevice, st));
             }
             HIP_CHECK(hipStreamSynchronize(st));
-        }
+        } else if (compute_error) std::rethrow_exception(compute_error);
     });
     if (phase_on_) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -233,12 +233,16 @@ void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::
     c.skip((size_t)arr.h.total);
     Cursor a{ arr.p, arr.n };
     const uint64_t count = a.u64();
-    if (count > total) bad("coefficient array larger than the ciphertext");
+    // nothing is allocated before the peer's dimensions are backed by bytes that are really there: the array is either the whole
+    // ciphertext or (seeded, size 2) its first polynomial, and the level named by parms_id must have coeff_modulus_size primes
+    if (!(count == total || (ct.size == 2 && count == poly_words))) bad("inconsistent coefficient array size");
     a.need((size_t)count * 8);
+    const Level *lv = find_level(chain, ct.parms_id);
+    if (lv && (lv->q.size() != ct.coeff_modulus_size)) bad("coeff_modulus_size does not match the parms_id's level");
+    // (total <= 2 * count and count * 8 bytes are present: the allocation below is at most twice the bytes received)
     ct.data.assign((size_t)total, 0);
     rd64n(ct.data.data(), a.here(), (size_t)count);
     if (count == total) { ct.seeded = false; return; }
-    if (!(ct.size == 2 && count == poly_words)) bad("inconsistent coefficient array size");
     // seeded: the generator's description follows; c1 is what it samples
     Body info = open_object(c.here(), c.left());
     c.skip((size_t)info.h.total);
@@ -250,9 +254,7 @@ void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::
     for (int i = 0; i < 8; i++) ct.seed[i] = rd64(ic.here() + 8 * i);
     ct.seeded = true;
     if (!expand) return;
-    const Level *lv = find_level(chain, ct.parms_id);
     if (!lv) bad("parms_id of a seeded ciphertext is not in this context's modulus chain");
-    if (lv->q.size() != ct.coeff_modulus_size) bad("coeff_modulus_size does not match the parms_id's level");
     sample_poly_uniform(ct.seed, lv->q.data(), lv->q.size(), (size_t)ct.poly_modulus_degree, ct.data.data() + poly_words);
     ct.seeded = true;
 }
@@ -444,9 +446,9 @@ KSwitchKeys load_kswitch_keys(const uint8_t *buf, size_t size, const std::vector
         const uint64_t dim2 = c.u64();
         if (dim2 > 64) bad("implausible decomposition count");
         for (uint64_t j = 0; j < dim2; j++) {
-            Body pk = open_object(c.here(), c.left());             // PublicKey: an object holding one ciphertext object
-            c.skip((size_t)pk.h.total);
-            Body cb = open_object(pk.p, pk.n);
+            // PublicKey::save forwards to its Ciphertext's save: ONE header per key, the ciphertext members right behind it
+            Body cb = open_object(c.here(), c.left());
+            c.skip((size_t)cb.h.total);
             Cursor cc{ cb.p, cb.n };
             Ciphertext ct;
             parse_ciphertext_members(cc, cb.h.vmaj, cb.h.vmin, chain, ct, expand);
@@ -465,8 +467,7 @@ std::vector<uint8_t> save_kswitch_keys(const KSwitchKeys &k, uint8_t compr)
     for (const auto &row : k.keys) {
         wr64(m, row.size());
         for (const Ciphertext &ct : row) {
-            const std::vector<uint8_t> co = close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, COMPR_NONE);
-            const std::vector<uint8_t> pk = close_object(co, ct.version_major, ct.version_minor, COMPR_NONE);
+            const std::vector<uint8_t> pk = close_object(ciphertext_members(ct), ct.version_major, ct.version_minor, COMPR_NONE);
             m.insert(m.end(), pk.begin(), pk.end());
         }
     }

@@ -21,8 +21,8 @@
 //                      seeded: the DynArray holds c0 only (size/2 of the words); c1 = sample_poly_uniform(PRNG(seed))
 //   DynArray<u64>    : own SEALHeader (compr none) | count u64 | words
 //   UniformRandomGeneratorInfo : own SEALHeader | prng_type u8 (1 blake2xb, 2 shake256) | seed 64 B
-//   PublicKey        : own SEALHeader | Ciphertext object
-//   KSwitchKeys      : parms_id 4 x u64 | dim1 u64 | for each: dim2 u64 | dim2 x PublicKey object
+//   PublicKey        : exactly its Ciphertext's object (PublicKey::save forwards to pk_.save: ONE SEALHeader, no envelope of its own)
+//   KSwitchKeys      : parms_id 4 x u64 | dim1 u64 | for each: dim2 u64 | dim2 x PublicKey (= Ciphertext) object
 //                      RelinKeys: dim1 = 1, dim2 = decomposition count = K - 1, every key ciphertext size 2 over all K primes, NTT form
 //   parms_id         : BLAKE2b-256 of the u64 words {scheme (BFV = 1), poly_modulus_degree, coeff moduli..., plain_modulus}
 //   sample_poly_uniform (util/rlwe.cpp): fill L*n words from the generator, then per limb replace every word >= the largest

@@ -100,6 +100,26 @@ int main(int argc, char **argv)
             if (sealio::load_ciphertext(sbuf2.data(), sbuf2.size(), chain).data != sc.data) return 13;
             rej += fuzz(sbuf2, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 8000);
         }
+        {   // forged dimensions: (a) a tiny object that claims 64 x 64 x 2^20 words must allocate nothing; (b) a level's parms_id with
+            // another coeff_modulus_size is refused with and without seed expansion
+            sealio::Ciphertext big = ct;
+            big.size = 64; big.coeff_modulus_size = 64; big.poly_modulus_degree = 1u << 20;
+            std::vector<uint8_t> eb = sealio::save_ciphertext(ct, sealio::COMPR_NONE);
+            auto put64 = [&](size_t at, uint64_t v) { std::memcpy(eb.data() + at, &v, 8); };
+            put64(16 + 33, 64); put64(16 + 41, (uint64_t)1 << 20); put64(16 + 49, 64);
+            bool refused = false;
+            try { (void)sealio::load_ciphertext(eb.data(), eb.size(), chain); } catch (const std::exception &) { refused = true; }
+            if (!refused) return 19;
+            sealio::Ciphertext one = ct;
+            one.coeff_modulus_size = 1; one.data.resize(2 * 64);
+            const std::vector<uint8_t> ob = sealio::save_ciphertext(one, sealio::COMPR_NONE);
+            for (bool expand : { true, false }) {
+                refused = false;
+                try { (void)sealio::load_ciphertext(ob.data(), ob.size(), chain, nullptr, expand); } catch (const std::exception &) { refused = true; }
+                if (!refused) return 20;
+            }
+            rej += 3;
+        }
         sealio::KSwitchKeys kk;
         std::memcpy(kk.parms_id, chain[0].parms_id, 32);
         kk.keys.resize(1);

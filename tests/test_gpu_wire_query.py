@@ -119,6 +119,13 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
                    for e in S.sources]
     pk2 = seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, plain_parts), gb, [b["mask"] for b in S.bundles], compr=compr)
     assert pk2 == pkgs
+    # a ciphertext that names the first data level but claims ONE coefficient prime (a forged coeff_modulus_size): refused, nothing is
+    # read behind its short coefficient array
+    short = expanded[(0, S.sources[0])][:, :1]
+    forged = obj(ct_members(model_parms_id(n, [int(v) for v in C.q[:first + 1]], C.t), False, short, (4, 0)), compr)
+    bad_parts = [(e, ([forged] + list(c[1:])) if e == S.sources[0] else c) for e, c in plain_parts]
+    with pytest.raises((ValueError, apsu_amd.ApsuHeError), match="coeff_modulus_size|first data level"):
+        seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, bad_parts), gb, [b["mask"] for b in S.bundles], compr=compr)
     with pytest.raises(ValueError, match="query powers"):            # a part with a foreign exponent (query.cpp:63-68)
         seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, [(e + 1, c) for e, c in parts]), gb, [b["mask"] for b in S.bundles])
     with pytest.raises(ValueError, match="relinearization"):

@@ -279,6 +279,21 @@ def test_ciphertext_rejects_malformed(ctx):
             ctx.ct_load(bad)
     with pytest.raises(apsu_amd.ApsuHeError, match="zstd"):
         ctx.ct_load(blob[:5] + bytes([2]) + blob[6:])
+    # dimensions are the peer's claim: a level's parms_id with another coeff_modulus_size is refused in every load mode (the
+    # reference's SEALObject::extract -> is_valid_for does the same, common/apsu/seal_object.h:161-219) ...
+    forged = obj(ct_members(pid, False, data[:, :1], (4, 0)), 0)
+    with pytest.raises(apsu_amd.ApsuHeError, match="coeff_modulus_size"):
+        ctx.ct_load(forged)
+    with pytest.raises(apsu_amd.ApsuHeError, match="coeff_modulus_size"):
+        ctx.ct_load_unexpanded(forged, 2, N)
+    # ... and a ~100-byte object that claims 2^32 words allocates nothing: the array must be the whole ciphertext or its seeded half
+    import time
+    hdr = struct.pack("<4Q", *pid) + bytes([0]) + struct.pack("<3Q", 64, 1 << 20, 64) + struct.pack("<Q", 1) + struct.pack("<d", 1.0)
+    t0 = time.time()
+    for cnt_words in ([], [1, 2, 3]):
+        with pytest.raises(apsu_amd.ApsuHeError, match="inconsistent coefficient array"):
+            ctx.ct_load(obj(hdr + dyn_array(cnt_words, (4, 0)), 0))
+    assert time.time() - t0 < 1.0
     # a seeded ciphertext whose parms_id this context does not know
     seed = [1, 2, 3, 4, 5, 6, 7, 8]
     sblob = obj(ct_members([9, 9, 9, 9], False, data, (4, 0), seed=seed), 0)
@@ -318,7 +333,8 @@ def test_relin_keys_both_directions(ctx, compr, seeded):
         seeds.append(seed)
     members = struct.pack("<4Q", *pid) + struct.pack("<Q", 1) + struct.pack("<Q", K - 1)
     for j in range(K - 1):
-        members += obj(obj(ct_members(pid, True, keys[j], (4, 0), seed=seeds[j] if seeded else None), 0), 0)     # PublicKey { Ciphertext }
+        # PublicKey::save forwards to its Ciphertext's save (SEAL publickey.h): ONE header per key, no envelope of its own
+        members += obj(ct_members(pid, True, keys[j], (4, 0), seed=seeds[j] if seeded else None), 0)
     blob = obj(members, compr)
     ksk, used = ctx.relin_keys_load(blob)
     assert used == len(blob)

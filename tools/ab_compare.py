@@ -1,7 +1,7 @@
 """A/B of two engine configurations inside ONE process on the same box and thermal state: two contexts, created under
 different environment switches (read at apsu_he_create), each with its own copy of the synthetic DB; rounds of `--steps`
 queries alternate A B A B ...; prints the per-round means, the paired difference and its standard error.
-    python tools/ab_test.py --a APSU_HE_FUSE_TENSOR=0 --b APSU_HE_FUSE_TENSOR=1 [--config 16M-4096] [--world 1]"""
+    python tools/ab_compare.py --a APSU_HE_FUSE_TENSOR=0 --b APSU_HE_FUSE_TENSOR=1 [--config 16M-4096] [--world 1]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, apsu_amd
