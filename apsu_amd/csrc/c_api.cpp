@@ -81,7 +81,7 @@ template <class F> static int guarded(F &&fn)
 extern "C" {
 
 const char *apsu_he_last_error(void) { return g_last_error.c_str(); }
-int apsu_he_abi_version(void) { return 4; }
+int apsu_he_abi_version(void) { return APSU_HE_ABI_VERSION; }
 
 int apsu_he_create(const char *json, int device, apsu_he_ctx **out)
 {

@@ -24,6 +24,7 @@ struct DevLevel {
     Mod ext[DMAXE];                             // q_0..q_{L-1}, Bsk..   (modulus of each ext limb)
     u64 t;
     u32 mac_shift[DMAXL], mac_chunk[DMAXL];     // k_mac: operand split width s = ceil(bits(q_j)/2) and terms per carry-free chunk
+    u32 mac_chunk_k[DMAXL];                     // ... of the three-product form (middle products have 2 s + 2 bits)
     // add_plain (App. B7) and plaintext lift (B5)
     u64 coeff_div_plain[DMAXL];
     u64 q_mod_t, threshold;
@@ -107,9 +108,10 @@ struct MacJob {
 constexpr int NTT_MAP_RAW = 1 << 30, NTT_MAP_MASK = NTT_MAP_RAW - 1;
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
                 int period, hipStream_t st);
-// forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n
+// forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n.
+// nored: the caller has checked ntt_gather_nored_ok for every (source, target) pair of the launch: no reduction on load
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                       hipStream_t st);
+                       hipStream_t st, bool nored = false);
 // out = a (.) b per limb; a:[batch][polys][L][n], b:[batch][L][n] (b_batch_stride may be 0)
 void launch_dyadic_plain(const DevLevel *lv, const u64 *ct, const u64 *pt, u64 *out, int polys, size_t n, int batch,
                          size_t pt_batch_stride, hipStream_t st);
@@ -185,7 +187,8 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
 // raw: acc comes from an inverse NTT that left out its twist (L <= 4; needs key->md_tw / p_tw)
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
                        hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0, bool raw = false);
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st);
+// kara: the three-product accumulation (k_mac<.., true>, lv->mac_chunk_k)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false);
 // Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
 // Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.
 struct EpiJob { const u64 *ct; const u64 *add1; const u64 *add2; const u64 *a0; const u64 *mask; u64 *out; };

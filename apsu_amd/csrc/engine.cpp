@@ -161,6 +161,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // in-process A/B runs, level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
         // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
+        if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
+        if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
         if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
     }
     // level constants
@@ -195,6 +197,10 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                     // cross sum takes two products (< 2^(2 sh)) per term, plus one slot for the carried residue
                     const u64 cap = ((u64)1 << (63 - 2 * sh));
                     d.mac_chunk[j] = (u32)std::min<u64>(cap > 2 ? cap - 1 : 2, 1u << 20);
+                    // three-product form: one middle product (a0 + a1)(c0 + c1) < 2^(2 sh + 2) per term, the carried residue enters as
+                    // (r0, r0 + r1) < 2^(sh + 1): one slot as well
+                    const u64 capk = 2 * sh + 2 < 64 ? ((u64)1 << (62 - 2 * sh)) : 0;
+                    d.mac_chunk_k[j] = (u32)std::min<u64>(capk > 2 ? capk - 1 : 0, 1u << 20);   // 0: not usable for this modulus
                 }
                 d.coeff_div_plain[j] = h.coeff_div_plain[j];
                 d.incr[j] = h.upper_half_incr[j];
@@ -556,6 +562,13 @@ struct ProfScope {
 };
 #define PROF(kind, units) ProfScope prof_scope_(this, kind, units)
 static uint64_t mac_units(const std::vector<MacJob> &mj) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * j.nl; return u; }
+// mean number of terms per (stream, limb) chain of a launch: the three-product form pays for long chains only
+static uint32_t mac_mean_cnt(const std::vector<MacJob> &mj)
+{
+    uint64_t u = 0, c = 0;
+    for (auto &j : mj) { u += (uint64_t)j.cnt * j.ng * j.nl; c += (uint64_t)j.ng * j.nl; }
+    return c ? (uint32_t)(u / c) : 0;
+}
 
 // single-stream description of a multiply-accumulate; group_mac() packs streams that share the
 // ciphertext powers and the term count into MacJobs of up to MAC_G streams
@@ -718,6 +731,19 @@ struct EngineAccess {
 #define TIER1_SLOTS() job_seq_base_ = 512
 
 // ============================================================================ device building blocks
+// Does the multiply-accumulate launch of a level use its three-product form?  It needs carry-free chunks of at least 7 terms for
+// every limb, and it pays for long chains only: macbench (profiles/r04_mac_kara.txt) has it 1.2 % slower at 44 terms per chain
+// (16M-4096) and 2 % faster at 150 (256M-4096 has 310).  APSU_HE_MAC_KARA=0/1 forces it off / on wherever it is usable.
+bool Engine::mac_kara(int lvl, uint32_t mean_cnt) const
+{
+    if (mac_kara_ == 0 || (mac_kara_ < 0 && mean_cnt < 96)) return false;
+    for (int j = 0; j <= lvl; j++) {
+        const int bits = 64 - __builtin_clzll(hp_.key_q[j]), sh = (bits + 1) / 2;
+        if (62 - 2 * sh < 3) return false;
+    }
+    return true;
+}
+
 void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
 {
     PROF(inverse ? P_NTT_INV : P_NTT_FWD, count);
@@ -734,8 +760,14 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
         for (int b = 0; b < batch; b++)
             for (int I = 0; I <= L; I++)
                 for (int J = 0; J < L; J++) src[((size_t)b * (L + 1) + I) * L + J] = ct3 + (size_t)b * ct_stride + ((size_t)2 * L + J) * n;
+        // sources are residues of q_0 .. q_{L-1}, targets q_0 .. q_{L-1} and the special prime: with SEAL's narrow coefficient primes
+        // the lazy transform takes them as they are (16M-4096: 56-bit sources into 56- and 50-bit targets)
+        u64 max_src = 0;
+        for (int J = 0; J < L; J++) max_src = std::max(max_src, hp_.key_q[J]);
+        bool nored = gather_nored_ && hp_.logn <= 14;
+        for (int I = 0; I <= L && nored; I++) nored = ntt_gather_nored_ok(hp_.key_q[I < L ? I : hp_.K - 1], max_src, hp_.logn);
         PROF(P_NTT_FWD, src.size());
-        launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_);
+        launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_, nored);
     }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
     // the inverse transform leaves its twist to the mod-down kernel, whose own constants absorb it (unrolled sizes)
@@ -1245,8 +1277,11 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 for (size_t i = 0; i < np; i++)
                     for (size_t pl = 0; pl < 2 * Lf; pl++)
                         srcp[(((size_t)b * np + i) * 2 * Lf) + pl] = slot_ptr(s.slot_of[s.low_powers[i]], b) + pl * n;
+            // (limb j of a slot is already a canonical residue of q_j: nothing to reduce)
+            bool nored = gather_nored_ && hp_.logn <= 14;
+            for (size_t j = 0; j < Lf && nored; j++) nored = ntt_gather_nored_ok(hp_.key_q[j], hp_.key_q[j], hp_.logn);
             PROF(P_NTT_FWD, srcp.size());
-            launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_);
+            launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_, nored);
         } else if (do_low) {
             convert(s.low_powers, low_target, pw->low.u());
             d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                      // :467,475
@@ -1904,7 +1939,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
                     ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
                 }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj))); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
                 // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
                 { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
@@ -1937,7 +1972,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     std::vector<int> imap;                              // modulus of every limb polynomial of the merged block
                     const MacJob *mac_jobs = nullptr;
                     int n_mac = 0;
-                    uint64_t units = 0;
+                    uint64_t units = 0; uint32_t mean_cnt = 0;
                 } g;
                 g.ids = ps_ids;
                 std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
@@ -2027,6 +2062,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     g.mac_jobs = upload_jobs(mj);
                     g.n_mac = (int)mj.size();
                     g.units = mac_units(mj);
+                    g.mean_cnt = mac_mean_cnt(mj);
                 }
 
                 // ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
@@ -2035,7 +2071,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const int Bs = (int)g.ids.size(), NI = g.NI;
                     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
                     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_); }
+                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt)); }
                     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
                     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
@@ -2079,7 +2115,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
                             std::vector<MacStream> cs;
                             cf_streams(g, cs);
-                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_);
+                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)));
                         }
                         std::vector<TensorSumJob> tj;
                         std::vector<FinishSumJob> fj;
@@ -2118,7 +2154,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             g.cf = ws(w_cf);
                             std::vector<MacStream> cs;
                             cf_streams(g, cs);
-                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_); }
+                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj))); }
                             d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
                         }
                         u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
@@ -2406,7 +2442,7 @@ void Engine::eval_bundles_nks(const Bundle *const *bundles, int count, const Pow
             if (!b.use_ps) {                                                                        // bin_bundle.cpp:106-174
                 if (b.degree) {
                     low_streams(b.ntt.u(), b.degree, rs[x], result);                                // :140-149
-                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
+                    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(0, mac_mean_cnt(mj))); }
                     d_ntt_ct(result, RS, 0, true);                                                  // :154
                 } else {
                     HIP_CHECK(hipMemsetAsync(result, 0, (size_t)RS * n * sizeof(u64), st_));
@@ -2435,7 +2471,7 @@ void Engine::eval_bundles_nks(const Bundle *const *bundles, int count, const Pow
                 for (uint32_t pp = 0; pp < even(s_high) / 2; pp++)
                     ms.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bs) + (size_t)pp * 2 * E * n, cf + (size_t)pp * 2 * n, H, (u32)n,
                                             (u32)(S * E * n), (u32)(E * n), (u32)n, 0, 1 });
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(0), 1, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(0, mac_mean_cnt(mj))); }
                 d_ntt_ct(blk, (words / n) + even(s_low) + even(s_high), 0, true);                   // :268,297,321 and the product's transform
                 HIP_CHECK(hipMemsetAsync(result, 0, (size_t)RS * n * sizeof(u64), st_));            // :238-240
                 for (uint32_t i = 1; i <= nin; i++) {                                               // :272-273,301-303

@@ -302,6 +302,9 @@ private:
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
+    int mac_kara_ = -1;               // k_mac with three products per term instead of four: -1 by chain length, 0 / 1 forced (APSU_HE_MAC_KARA)
+    bool mac_kara(int lvl, uint32_t mean_cnt) const;
+    bool gather_nored_ = true;        // gathered forward transforms skip the reduce-on-load where the lazy range allows (ntt_gather_nored_ok)
     size_t eval_ws_budget_ = (size_t)6 << 30;
     bool raw_twist_ = true;           // inverse transforms in front of drop / mod-down kernels leave their twist to those kernels
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node

@@ -5,6 +5,7 @@
 // level constants read through wave-uniform loads.  No MFMA: the work is modular-integer
 // butterflies and dyadic products (BASELINE.json north_star).
 #include "device.h"
+#include "ntt_wg.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -19,39 +20,7 @@ void throw_hip(hipError_t e, const char *file, int line);
 // transform_to_ntt_inplace / transform_from_ntt_inplace
 // (receiver_osn.cpp:467,475 ; bin_bundle.cpp:154,268,297,321) and every NTT inside
 // multiply / relinearize / multiply_plain.  One workgroup per limb polynomial, limb resident in LDS.
-template <int LOGN, bool INV, int MODE, int T, bool RED = false, bool RAW = false, class SRC = SrcPlain>
-__device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr,
-                                         const SRC &operands = SRC())
-{
-    constexpr int N = 1 << LOGN;
-    constexpr int P = plan_passes(LOGN);
-    // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
-    //  line is consumed by the wave's eight consecutive loads.  Staging the limb through LDS with coalesced loads first was
-    //  measured again in round 2 for small launches: no gain, profiles/r02_ntt_latency.txt)
-    if constexpr (RED) ntt_pass<LOGN, INV, MODE, 0, true>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
-    else if constexpr (!std::is_same<SRC, SrcPlain>::value) {
-        // computed input (tensor product on load): four operand streams read with the first pass's 128-byte lane stride
-        // thrash the vector L1 (measured: the fused launch 65 % slower than tensor + transform apart), so the products are
-        // formed with coalesced 16-byte loads into the LDS image and the first pass starts from there
-        for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
-        __syncthreads();
-        ntt_pass<LOGN, INV, MODE, 0, false, false, SrcPlain, true>(lds, p, tid, T, tab);
-    } else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
-    // (RAW only concerns the pass that leaves the inverse transform, the last one)
-    if constexpr (P > 1) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 1, false, RAW>(lds, p, tid, T, tab); }
-    if constexpr (P > 2) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 2, false, RAW>(lds, p, tid, T, tab); }
-    if constexpr (P > 3) { __syncthreads(); ntt_pass<LOGN, INV, MODE, 3, false, RAW>(lds, p, tid, T, tab); }
-    if (!INV) {                                  // forward: the last pass left 16 contiguous coefficients per lane in LDS
-        __syncthreads();
-        for (int e = 2 * tid; e < N; e += 2 * T) {
-            u64x2 v = *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));
-            v[0] = ntt_fwd_finish<MODE>(v[0], tab);
-            v[1] = ntt_fwd_finish<MODE>(v[1], tab);
-            *reinterpret_cast<u64x2 *>(p + e) = v;
-        }
-    }
-}
-
+// (the workgroup body -- passes + synchronisation -- lives in ntt_wg.h)
 // split != 0: the launch transforms the two HALVES of limbs twice this size (poly_modulus_degree 32768: one limb is 256 KiB and
 // does not fit a workgroup's LDS).  Block g is half g & 1 of limb g >> 1 and takes table 2 * modulus + half, whose forward
 // twiddles are the big transform's for that half (W_h[2^s + b] = W[2^(s+1) + h 2^s + b]); the first Cooley-Tukey stage runs in
@@ -68,9 +37,9 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     const NttTable tab = tabs[split ? (((mv & NTT_MAP_MASK) << 1) | (int)(g & 1)) : (mv & NTT_MAP_MASK)];
     u64 *p = data + g * N;
     if (INV && ((mv & NTT_MAP_RAW) || split)) {                                 // wave-uniform branches
-        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, false, INV>(lds, p, tab, tid);
-        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, false, INV>(lds, p, tab, tid);
-        else ntt_body<LOGN, INV, NTT_WIDE, T, false, INV>(lds, p, tab, tid);
+        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, INV>(lds, p, tab, tid);
+        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, INV>(lds, p, tab, tid);
+        else ntt_body<LOGN, INV, NTT_WIDE, T, 0, INV>(lds, p, tab, tid);
         return;
     }
     if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);
@@ -129,7 +98,7 @@ __global__ __launch_bounds__(EW_T) void k_ntt_last_stage(u64 *__restrict__ data,
 // to data + g*N.  Replaces the decompose kernel of the key switch (App. B10): out[I][J] = NTT_I(c2_J mod m_I).
 template <int LOGN, int T>
 __global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restrict__ src, u64 *__restrict__ data,
-                                                  const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period)
+                                                  const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period, int nored)
 {
     constexpr int N = 1 << LOGN;
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
@@ -137,14 +106,19 @@ __global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restric
     const size_t g = blockIdx.x;
     const NttTable tab = tabs[modmap[g % (size_t)period]];
     u64 *p = data + g * N;
-    if (tab.narrow) ntt_body<LOGN, false, NTT_NARROW, T, true>(lds, p, tab, tid, src[g]);
-    else if (tab.wide_d4) ntt_body<LOGN, false, NTT_WIDE_NEAR, T, true>(lds, p, tab, tid, src[g]);
-    else ntt_body<LOGN, false, NTT_WIDE, T, true>(lds, p, tab, tid, src[g]);
+    // nored: every source residue fits the lazy range of every (narrow) target as it stands (checked by the host, ntt_gather_nored_ok):
+    // the transform is linear and its closing reduction takes any 64-bit value, so the reduction on load is left out
+    if (tab.narrow) {
+        if (nored) ntt_body<LOGN, false, NTT_NARROW, T, 2>(lds, p, tab, tid, src[g]);
+        else ntt_body<LOGN, false, NTT_NARROW, T, 1>(lds, p, tab, tid, src[g]);
+    } else if (tab.wide_d4) ntt_body<LOGN, false, NTT_WIDE_NEAR, T, 1>(lds, p, tab, tid, src[g]);
+    else ntt_body<LOGN, false, NTT_WIDE, T, 1>(lds, p, tab, tid, src[g]);
 }
 
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                       hipStream_t st)
+                       hipStream_t st, bool nored)
 {
+    const int nr = nored ? 1 : 0;
     if (!count) return;
     if (logn == 15) {                                            // first stage gathers and reduces, the halves are plain transforms
         const size_t n = (size_t)1 << 15;
@@ -153,7 +127,7 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
         KERNEL_CHECK();
         return;
     }
-#define G_CASE(LN, T) case LN: hipLaunchKernelGGL((k_ntt_gather<LN, T>), dim3((unsigned)count), dim3(T), 0, st, src, data, tabs, modmap, period); break;
+#define G_CASE(LN, T) case LN: hipLaunchKernelGGL((k_ntt_gather<LN, T>), dim3((unsigned)count), dim3(T), 0, st, src, data, tabs, modmap, period, nr); break;
     switch (logn) {
     G_CASE(14, 1024) G_CASE(13, 512) G_CASE(12, 256) G_CASE(11, 128) G_CASE(10, 64) G_CASE(8, 64) G_CASE(6, 64)
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
@@ -196,9 +170,9 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     if (g >= n_tensor) {                                                        // wave-uniform
         u64 *p = plain + (g - n_tensor) * N;
         if (mv & NTT_MAP_RAW) {
-            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, true>(lds, p, tab, tid);
-            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, true>(lds, p, tab, tid);
-            else ntt_body<LOGN, true, NTT_WIDE, T, false, true>(lds, p, tab, tid);
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true>(lds, p, tab, tid);
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true>(lds, p, tab, tid);
+            else ntt_body<LOGN, true, NTT_WIDE, T, 0, true>(lds, p, tab, tid);
         } else {
             if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T>(lds, p, tab, tid);
             else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
@@ -216,13 +190,13 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     else ops = SrcTensor{ a1, b1, nullptr, nullptr };
     u64 *p = job.d + (size_t)r * N;
     if (mv & NTT_MAP_RAW) {
-        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else ntt_body<LOGN, true, NTT_WIDE, T, false, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
     } else {
-        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else ntt_body<LOGN, true, NTT_WIDE, T, false, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
     }
 }
 
@@ -1476,7 +1450,11 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // else.  `chunk` terms (2*chunk*2^(2s) < 2^64) are accumulated before the sums are recombined
 // (S00 + Sx*2^s + S11*2^(2s)) and reduced; for the 48..56-bit coefficient primes a whole inner polynomial
 // fits in one chunk.
-template <int G, int C>
+// KARA: three products per (stream, coefficient, polynomial, term) instead of four -- S00 += a0 c0, S11 += a1 c1,
+// Smid += (a0 + a1)(c0 + c1), the cross sum recovered at fold time as Smid - S00 - S11; the power-side sums c0 + c1 are formed
+// once per term and shared by the G streams.  A middle product has 2s + 2 bits, so a carry-free chunk is half as long
+// (lv->mac_chunk_k) and the carried residue r re-enters as the "term" (a0 c0, mid) = (r mod 2^s, r mod 2^s + (r >> s)).
+template <int G, int C, bool KARA = false>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
     static_assert(C == 1 || C == 2, "coefficients per lane");
@@ -1490,7 +1468,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     if (g0 >= (int)job.ng || blockIdx.y >= jp->nl) return;
     const int j = blockIdx.y + job.limb0;                      // limb
     const Mod m = lv->q[j];
-    const u32 s = lv->mac_shift[j], chunk = lv->mac_chunk[j];
+    const u32 s = lv->mac_shift[j], chunk = KARA ? lv->mac_chunk_k[j] : lv->mac_chunk[j];
     const u32 lomask = (1u << s) - 1;                          // s <= 30
     const u64 *p0 = job.pw + (size_t)j * n + k;
     const u64 *p1 = p0 + job.pw_poly_stride;
@@ -1529,6 +1507,13 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
         for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int c = 0; c < C; c++) { clo[p][c] = (u32)t.c[p][c] & lomask; chi[p][c] = (u32)(t.c[p][c] >> s); }
+        u32 csum[2][C];
+        if (KARA) {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int c = 0; c < C; c++) csum[p][c] = clo[p][c] + chi[p][c];
+        }
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
@@ -1537,14 +1522,17 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     s00[g][c][p] += (u64)alo * clo[p][c];
-                    sx[g][c][p] += (u64)alo * chi[p][c];
-                    sx[g][c][p] += (u64)ahi * clo[p][c];
+                    if (KARA) sx[g][c][p] += (u64)(alo + ahi) * csum[p][c];
+                    else {
+                        sx[g][c][p] += (u64)alo * chi[p][c];
+                        sx[g][c][p] += (u64)ahi * clo[p][c];
+                    }
                     s11[g][c][p] += (u64)ahi * chi[p][c];
                 }
             }
     };
     // recombine S00 + Sx*2^s + S11*2^(2s) (< 2^128) and reduce; the residue re-enters as the next chunk's S00
-    auto fold = [&]() {
+    auto fold = [&](bool last) {
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
@@ -1552,10 +1540,13 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     u128p acc{ s00[g][c][p], 0 };
-                    add128(acc, u128p{ sx[g][c][p] << s, sx[g][c][p] >> (64 - s) });
+                    const u64 cross = KARA ? sx[g][c][p] - s00[g][c][p] - s11[g][c][p] : sx[g][c][p];
+                    add128(acc, u128p{ cross << s, cross >> (64 - s) });
                     add128(acc, u128p{ s11[g][c][p] << (2 * s), s11[g][c][p] >> (64 - 2 * s) });
-                    s00[g][c][p] = barrett128(acc, m);
-                    sx[g][c][p] = s11[g][c][p] = 0;
+                    const u64 r = barrett128(acc, m);
+                    if (KARA && !last) { s00[g][c][p] = r & lomask; sx[g][c][p] = (r & lomask) + (r >> s); }
+                    else { s00[g][c][p] = r; sx[g][c][p] = 0; }
+                    s11[g][c][p] = 0;
                 }
     };
 
@@ -1571,10 +1562,10 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
         load_term(i + 2 < cnt ? i + 2 : cnt - 1, A);             // clamped prefetch (a re-read hits the cache)
         mac_term(B);
         in_chunk += 2;
-        if (in_chunk + 3 > chunk) { fold(); in_chunk = 1; }      // the folded residue counts as one term
+        if (in_chunk + 3 > chunk) { fold(false); in_chunk = 1; } // the folded residue counts as one term
     }
     if (cnt & 1) mac_term(A);                                    // A holds the last term
-    fold();
+    fold(true);
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {
@@ -1599,12 +1590,13 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 #ifndef APSU_MAC_C
 #define APSU_MAC_C 2
 #endif
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara)
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
-    hipLaunchKernelGGL((k_mac<G, C>), dim3((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G))),
-                       dim3(EW_T), 0, st, lv, jobs, n);
+    const dim3 grid((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G)));
+    if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+    else hipLaunchKernelGGL((k_mac<G, C, false>), grid, dim3(EW_T), 0, st, lv, jobs, n);
     KERNEL_CHECK();
 }
 

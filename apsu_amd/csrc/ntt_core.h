@@ -28,6 +28,8 @@
 // All of this is invisible in the results: outputs are canonical residues.
 // The pass functions are __host__ __device__ so tests can emulate a workgroup on the CPU.
 #pragma once
+#include <type_traits>
+
 #include "modmath.h"
 
 struct TwPair { u64 w, wq; };          // twiddle and its Shoup quotient, 16 B -> one dwordx4 load
@@ -52,6 +54,14 @@ struct NttTable {
 };
 
 HD bool ntt_is_narrow(u64 q, int logn) { return (unsigned __int128)q * (unsigned)(4 * logn + 1) < ((unsigned __int128)1 << 64); }
+
+// May a forward transform modulo q take residues below max_src (of another modulus) WITHOUT reducing them on load?  A narrow
+// modulus runs without any range control: a value grows by less than 4q per stage, so max_src + 4 logn q <= 2^64 keeps every
+// intermediate inside 64 bits; the transform is linear and its closing reduction takes any 64-bit value.
+HD bool ntt_gather_nored_ok(u64 q, u64 max_src, int logn)
+{
+    return ntt_is_narrow(q, logn) && (unsigned __int128)q * (unsigned)(4 * logn) + max_src <= ((unsigned __int128)1 << 64);
+}
 
 // fold parameters of q (k = 0 when the fold reduction does not apply)
 HD void ntt_fold_params(u64 q, u32 &k, u32 &c)
@@ -199,13 +209,78 @@ enum PassIo { IO_LDS = 0, IO_GLOBAL = 1 };
 enum NttMode { NTT_NARROW = 0, NTT_WIDE = 1, NTT_WIDE_NEAR = 2 };
 HD int ntt_mode(const NttTable &tab) { return tab.narrow ? NTT_NARROW : (tab.wide_d4 ? NTT_WIDE_NEAR : NTT_WIDE); }
 
+// ---- the twiddles of one pass for one work item, as a register array -------------------------------------------------
+// Forward (Cooley-Tukey, twiddle per block): stage u of the pass uses 2^u distinct table entries per group of columns
+// (column groups share them; groups that are adjacent BLOCKS have their own).  Inverse (decimation in time, twiddle per
+// position inside the block): stage with row gap `bit` uses `bit` row positions, times the G columns when the groups are
+// columns.  Either way (2^K - 1) * GM entries; slot numbering below.  A pass either loads them where it uses them (TwInline)
+// or takes a set that was loaded EARLIER -- by the pass in front of it, just before that pass stored its results, so that
+// the table loads (L2 latency) overlap the LDS turnaround instead of following it (round 4; ntt_wg.h).
+template <int LOGN, int S, int K, bool INV> struct PassShape {
+    static constexpr int R = 1 << K, G = 16 >> K, LOWBITS = LOGN - S - K;
+    static constexpr bool COLS = (1 << LOWBITS) >= G;
+    static constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;
+    static constexpr int GM = INV ? (COLS ? G : 1) : (COLS ? 1 : G);
+    static constexpr int NT = (R - 1) * GM;
+    // forward: (stage u, row j, group g) -> slot;  inverse: (row gap bit, row j, group gg) -> slot
+    static constexpr int fwd_slot(int u, int j, int g) { return ((1 << u) - 1) * GM + (j >> (K - u)) * GM + (COLS ? 0 : g); }
+    static constexpr int inv_slot(int bit, int j, int gg) { return (bit - 1) * GM + (j & (bit - 1)) * GM + (COLS ? gg : 0); }
+};
+struct TwInline {};                                               // marker: the pass loads its twiddles itself
+template <int NT> struct TwRegs { u64x2 t[NT > 0 ? NT : 1]; };
+struct NoHook { HD void operator()() const {} };
+
+// table entries of pass (S, K) for work item w into tw (same index algebra as ntt_pass16 below)
+template <int LOGN, int S, int K, bool INV>
+HD void ntt_load_twiddles(TwRegs<PassShape<LOGN, S, K, INV>::NT> &tw, int w, const NttTable &tab)
+{
+    using PS = PassShape<LOGN, S, K, INV>;
+    constexpr int R = PS::R, G = PS::G, LOWBITS = PS::LOWBITS, CG = PS::CG;
+    constexpr bool COLS = PS::COLS;
+    constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);
+    int block, c0;
+    if (COLS) { block = w / CG; c0 = (w % CG) * G; }
+    else { block = w * G; c0 = 0; }
+#pragma unroll
+    for (int uu = 0; uu < K; uu++) {
+        const int u = INV ? K - 1 - uu : uu;
+        const int bit = 1 << (K - 1 - u);
+        if (INV) {
+#pragma unroll
+            for (int jl = 0; jl < bit; jl++)
+#pragma unroll
+                for (int gg = 0; gg < PS::GM; gg++) {
+                    const int jj = COLS ? ((jl << LOWBITS) | (c0 + gg)) : jl;
+                    const int gap = COLS ? (bit << LOWBITS) : bit;
+                    tw.t[PS::inv_slot(bit, jl, gg)] = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
+                }
+        } else {
+#pragma unroll
+            for (int jh = 0; jh < (1 << u); jh++)
+#pragma unroll
+                for (int g = 0; g < PS::GM; g++) {
+                    int ti = (1 << (S + u)) + ((COLS ? block : block + g) << u) + jh;
+                    if (UNIFORM_TW) ti = UNIFORM_INT(ti);
+                    tw.t[PS::fwd_slot(u, jh << (K - u), g)] = ldg16(reinterpret_cast<const u64 *>(tab.fwd + ti));
+                }
+        }
+    }
+    (void)R;
+}
+
 // One pass over stages S .. S+K-1 for work item w in [0, n/16).
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
 // MODE: range discipline of the modulus (wave-uniform per limb): see NTT_NARROW / NTT_WIDE / NTT_WIDE_NEAR
-template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, bool RED = false, bool RAW = false, class SRC = SrcPlain>
-HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab, const SRC &src = SRC())
+//   TW: TwInline, or the pass's twiddles loaded earlier (TwRegs);  HOOK: called once between the butterflies and the stores
+//   (ntt_wg.h uses it to issue the NEXT pass's twiddle loads).
+template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, int RED = 0, bool RAW = false, class SRC = SrcPlain,
+          class TW = TwInline, class HOOK = NoHook>
+HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab, const SRC &src = SRC(), const TW &tw = TW(),
+                   const HOOK &hook = HOOK())
 {
+    using PS = PassShape<LOGN, S, K, INV>;
+    constexpr bool PRE = !std::is_same<TW, TwInline>::value;
     constexpr int R = 1 << K;                  // radix
     constexpr int G = 16 >> K;                 // independent groups per thread
     constexpr int LOWBITS = LOGN - S - K;      // bits of the column index
@@ -259,7 +334,8 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
             }
     }
 
-    if (RED && IN == IO_GLOBAL) {              // gathered input holds residues of ANOTHER modulus: reduce on load
+    if (RED == 1 && IN == IO_GLOBAL) {         // gathered input holds residues of ANOTHER modulus: reduce on load (RED == 2: the host
+                                               // has checked that they fit the lazy range as they are, ntt_wg.h)
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
@@ -284,7 +360,9 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         if (!COLS && gg != g) continue;
                         const int jj = COLS ? (((j & (bit - 1)) << LOWBITS) | (c0 + gg)) : (j & (bit - 1));
                         const int gap = COLS ? (bit << LOWBITS) : bit;
-                        const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
+                        u64x2 tv;
+                        if constexpr (PRE) tv = tw.t[PS::inv_slot(bit, j, gg)];
+                        else tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
@@ -294,7 +372,9 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                 }
                 int ti = (1 << (S + u)) + (((COLS ? block : block + g)) << u) + (j >> (K - u));
                 if (UNIFORM_TW) ti = UNIFORM_INT(ti);
-                const u64x2 tv = ldg16(reinterpret_cast<const u64 *>(W + ti));
+                u64x2 tv;
+                if constexpr (PRE) tv = tw.t[PS::fwd_slot(u, j, g)];
+                else tv = ldg16(reinterpret_cast<const u64 *>(W + ti));
                 const TwPair t{ tv[0], tv[1] };
 #pragma unroll
                 for (int gg = 0; gg < G; gg++) {
@@ -308,6 +388,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
         }
     }
 
+    hook();
     if (OUT == IO_GLOBAL && !(INV && RAW)) {   // leaving the transform: canonical residues (RAW: the consumer applies the twist)
 #pragma unroll
         for (int g = 0; g < G; g++)
@@ -385,14 +466,29 @@ constexpr int plan_s(int logn, int p)
     return s;
 }
 
+// shape of the pass executed PASS-th (for the twiddle sets above)
+template <int LOGN, bool INV, int PASS> struct ExecPass {
+    static constexpr int P = plan_passes(LOGN), p = INV ? P - 1 - PASS : PASS, K = plan_k(LOGN, p), S = plan_s(LOGN, p);
+    using Shape = PassShape<LOGN, S, K, INV>;
+    using Tw = TwRegs<Shape::NT>;
+};
+template <int LOGN, bool INV, int PASS>
+HD void ntt_pass_twiddles(typename ExecPass<LOGN, INV, PASS>::Tw &tw, int tid, const NttTable &tab)
+{
+    using E = ExecPass<LOGN, INV, PASS>;
+    ntt_load_twiddles<LOGN, E::S, E::K, INV>(tw, tid, tab);
+}
+
 // Executes pass number PASS (in execution order) for "thread" tid of a T-thread workgroup.
 // The caller separates passes with __syncthreads() (device) or by looping tid (host emulation).
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
 //            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
 // STAGED: the caller has already put the input into the LDS image (k_intt_tensor forms its products with coalesced loads).
-template <int LOGN, bool INV, int MODE, int PASS, bool RED = false, bool RAW = false, class SRC = SrcPlain, bool STAGED = false>
-HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab, const SRC &src = SRC())
+template <int LOGN, bool INV, int MODE, int PASS, int RED = 0, bool RAW = false, class SRC = SrcPlain, bool STAGED = false,
+          class TW = TwInline, class HOOK = NoHook>
+HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab, const SRC &src = SRC(), const TW &tw = TW(),
+                 const HOOK &hook = HOOK())
 {
     constexpr int P = plan_passes(LOGN);
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
@@ -400,5 +496,6 @@ HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab, const
     constexpr int S = plan_s(LOGN, p);
     constexpr int IN = (PASS == 0 && !STAGED) ? IO_GLOBAL : IO_LDS;   // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T) ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW, SRC>(lds, glob, w, tab, src);
+    for (int w = tid; w < (1 << (LOGN - 4)); w += T)
+        ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW, SRC, TW, HOOK>(lds, glob, w, tab, src, tw, hook);
 }

@@ -77,6 +77,7 @@ const char *apsu_he_last_error(void);
  * them), apsu_he_db_upload_saved_bundle (a BinBundle as ReceiverDB::save wrote it); zstd bodies in the SEAL codec;
  * apsu_he_multi_run_query_request, apsu_he_multi_result_polys; the parameter exchange, plainResponse, PSUParams in binary form and
  * the header of a saved ReceiverDB (apsu_he_wire_peek_type ... apsu_he_wire_receiver_db_header). */
+#define APSU_HE_ABI_VERSION 4   /* what this header describes; compare with apsu_he_abi_version() of the loaded library */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

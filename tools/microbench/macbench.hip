@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_morph(const MacJob *__restrict__ jobs, 
 }
 int main(int argc, char** argv) {
     const size_t n = 8192, L = 3, ptw = L * n;
-    const int terms = 44, streams = 784 - 784 % MAC_G, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
+    const int terms = getenv("TERMS") ? atoi(getenv("TERMS")) : 44, streams = 784 - 784 % MAC_G, nb = argc > 1 ? atoi(argv[1]) : 4; const size_t pad = argc > 2 ? atoi(argv[2]) : 0, ppad = argc > 3 ? atoi(argv[3]) : 0;   // pad: words added to the power stride; ppad: to the poly stride       // nb: bundle indices interleaved in the powers layout
     const size_t skew = getenv("SKEW") ? atoi(getenv("SKEW")) : 0;   // extra words between consecutive streams (breaks the 8.25 MB stride)
     const size_t words = (size_t)streams * terms * ptw;
     u64 *db, *pw, *out; DevLevel* lv; MacJob* dj;
@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
     k_fillrand<<<4096, 256>>>(db, words + (size_t)streams * skew, ((u64)1 << 55) - 1); k_fillrand<<<1024, 256>>>(pw, (size_t)terms * pstride, ((u64)1 << 55) - 1);
     DevLevel h; memset(&h, 0, sizeof(h)); h.L = 3;
     u64 q[3] = { 0xfffffffff70001ULL, 0xfffffffff78001ULL, 0xfffffffffb4001ULL };
-    for (int j = 0; j < 3; j++) { unsigned __int128 all = ~(unsigned __int128)0; unsigned __int128 r = all / q[j]; h.q[j] = Mod{ q[j], (u64)r, (u64)(r >> 64) }; h.mac_shift[j] = 28; h.mac_chunk[j] = 127; }
+    for (int j = 0; j < 3; j++) { unsigned __int128 all = ~(unsigned __int128)0; unsigned __int128 r = all / q[j]; h.q[j] = Mod{ q[j], (u64)r, (u64)(r >> 64) }; h.mac_shift[j] = 28; h.mac_chunk[j] = 127; h.mac_chunk_k[j] = 63; }
     CHECK(hipMalloc(&lv, sizeof(h))); CHECK(hipMemcpy(lv, &h, sizeof(h), hipMemcpyHostToDevice));
     std::vector<MacJob> jobs;
     for (int s = 0; s < streams; s += MAC_G) {
@@ -88,6 +88,45 @@ int main(int argc, char** argv) {
         std::sort(t.begin(), t.end());
         printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, 2, nb, pad,
                t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
+    }
+    if (getenv("B2B")) {
+        // is part of a launch's time a fixed cost per launch?  N launches queued back to back (no host wait in between) against N x one launch
+        for (int nl : { 1, 2, 4 }) {
+            std::vector<float> t;
+            for (int rep = 0; rep < 8; rep++) {
+                CHECK(hipEventRecord(e0));
+                for (int k = 0; k < nl; k++) launch_mac(lv, 3, dj, n, (int)jobs.size(), 0);
+                CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep >= 2) t.push_back(ms);
+            }
+            std::sort(t.begin(), t.end());
+            printf("%d launches back to back: median %.3f ms = %.3f ms per launch (%.0f GB/s)\n", nl, t[t.size() / 2], t[t.size() / 2] / nl, words * 8 / (t[t.size() / 2] / nl * 1e-3) / 1e9);
+        }
+    }
+    if (getenv("KARA")) {
+        // three-product accumulation: same jobs, separate output, bit-compared with the four-product form; A B A B timing
+        u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
+        std::vector<MacJob> jobs2 = jobs;
+        for (size_t x = 0; x < jobs2.size(); x++) for (int g = 0; g < MAC_G; g++) jobs2[x].out[g] = out2 + (jobs[x].out[g] - out);
+        MacJob *dj2; CHECK(hipMalloc(&dj2, jobs2.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj2, jobs2.data(), jobs2.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+        std::vector<float> ta, tb;
+        for (int rep = 0; rep < 24; rep++) {
+            float ms;
+            CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj, n, (int)jobs.size(), 0, false); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+            CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 4) ta.push_back(ms);
+            CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj2, n, (int)jobs2.size(), 0, true); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+            CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 4) tb.push_back(ms);
+        }
+        std::sort(ta.begin(), ta.end()); std::sort(tb.begin(), tb.end());
+        printf("four products : min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)\n", ta[0], words * 8 / (ta[0] * 1e-3) / 1e9, ta[ta.size() / 2], words * 8 / (ta[ta.size() / 2] * 1e-3) / 1e9);
+        printf("three products: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)\n", tb[0], words * 8 / (tb[0] * 1e-3) / 1e9, tb[tb.size() / 2], words * 8 / (tb[tb.size() / 2] * 1e-3) / 1e9);
+        const size_t ow = (size_t)streams * 2 * L * n;
+        std::vector<u64> h1(ow), h2(ow);
+        CHECK(hipMemcpy(h1.data(), out, ow * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h2.data(), out2, ow * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t x = 0; x < ow; x++) bad += h1[x] != h2[x];
+        printf("three vs four products: %zu of %zu output words differ\n", bad, ow);
+        if (getenv("TERMS")) return 0;
     }
     if (getenv("RING")) {
         // LDS-DMA ring variant: same jobs, separate output, bit-compared with k_mac's
