@@ -1584,6 +1584,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     }
 }
 
+
 #ifndef APSU_MAC_G
 #define APSU_MAC_G 4
 #endif
@@ -1594,6 +1595,9 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
+    // (round 4, measured and not adopted -- tools/microbench/mac_persist.hip, profiles/r04_mac_{units,persist,stagger}.txt: a launch
+    //  costs ~0.26 ms more than its chains' length explains, i.e. ~14 us per workgroup; long-lived workgroups that keep the load
+    //  pipeline running across chains were 4-9 % SLOWER, starting the first resident generation in phases changed nothing)
     const dim3 grid((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G)));
     if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
     else hipLaunchKernelGGL((k_mac<G, C, false>), grid, dim3(EW_T), 0, st, lv, jobs, n);

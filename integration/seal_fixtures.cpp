@@ -194,7 +194,7 @@ void emit_ops(const string &dir, const string &tag, size_t n, const vector<int> 
     J.hexv("plain_modulus", t);
     { vector<long long> b(bits.begin(), bits.end()); J.raw("coeff_bits", ints_json(b)); }
     J.num("plain_bits", plain_bits);
-    { vector<uint64_t> psi; for (auto &tb : C.context.key_context_data()->small_ntt_tables()) psi.push_back(tb.get_root()); J.raw("psi", hex_list(psi.data(), psi.size())); }
+    { vector<uint64_t> psi; for (size_t j = 0; j < C.K; j++) psi.push_back(C.context.key_context_data()->small_ntt_tables()[j].get_root()); J.raw("psi", hex_list(psi.data(), psi.size())); }
     J.str("seal_version", std::to_string(SEAL_VERSION_MAJOR) + "." + std::to_string(SEAL_VERSION_MINOR) + "." + std::to_string(SEAL_VERSION_PATCH));
     RelinKeys rk = random_relin_keys(C, rng);
     J.raw("rk", rk_json(rk));
@@ -269,8 +269,10 @@ parms_id_type parms_id_for_chain_idx(const SEALContext &context, size_t chain_id
 void clear_irrelevant_bits(const EncryptionParameters &parms, Ciphertext &ct)
 {
     if (parms.coeff_modulus().size() != 1) return;
-    const int irrelevant = parms.coeff_modulus()[0].bit_count() - parms.plain_modulus().bit_count() - 1
-                           - static_cast<int>(util::get_power_of_two(parms.poly_modulus_degree())) + 1 - 1;
+    // bits kept = bit_count(t) + significant bits of n (log2 n + 1) - 1
+    int n_bits = 0;
+    for (size_t v = parms.poly_modulus_degree(); v; v >>= 1) n_bits++;
+    const int irrelevant = parms.coeff_modulus()[0].bit_count() - (parms.plain_modulus().bit_count() + n_bits - 1);
     if (irrelevant <= 0) return;
     const uint64_t mask = ~((uint64_t(1) << irrelevant) - 1);
     for (size_t p = 0; p < ct.size(); p++)
@@ -385,6 +387,9 @@ void emit_path(const string &dir, const string &tag, size_t n, const vector<int>
     Json J;
     J.num("n", (long long)n);
     { vector<long long> b(bits.begin(), bits.end()); J.raw("coeff_bits", ints_json(b)); }
+    { vector<uint64_t> q; for (auto &m : C.context.key_context_data()->parms().coeff_modulus()) q.push_back(m.value()); J.raw("coeff_modulus", hex_list(q.data(), q.size())); }
+    J.hexv("plain_modulus", t);
+    J.str("seal_version", std::to_string(SEAL_VERSION_MAJOR) + "." + std::to_string(SEAL_VERSION_MINOR) + "." + std::to_string(SEAL_VERSION_PATCH));
     J.num("plain_bits", plain_bits); J.num("ps_low_degree", ps_low); J.num("max_items_per_bin", max_items);
     { vector<long long> v(query_powers.begin(), query_powers.end()); J.raw("query_powers", ints_json(v)); }
     { vector<long long> v(targets.begin(), targets.end()); J.raw("targets", ints_json(v)); }

@@ -18,43 +18,148 @@ SEAL_H = r'''
 #include <array>
 #include <cstddef>
 #include <cstdint>
+#include <iostream>
 #include <memory>
 #include <vector>
+#define SEAL_VERSION_MAJOR 4
+#define SEAL_VERSION_MINOR 1
+#define SEAL_VERSION_PATCH 1
+#define SEAL_USE_ZLIB
+#define SEAL_USE_ZSTD
 namespace seal {
 using seal_byte = std::byte;
 using parms_id_type = std::array<std::uint64_t, 4>;
 enum class compr_mode_type : std::uint8_t { none = 0, zlib = 1, zstd = 2 };
+enum class scheme_type : std::uint8_t { none = 0, bfv = 1, ckks = 2 };
+enum class sec_level_type : int { none = 0, tc128 = 128 };
 class MemoryPoolHandle {};
+class Modulus { public: std::uint64_t value() const; int bit_count() const; };
+struct CoeffModulus { static std::vector<Modulus> Create(std::size_t poly_modulus_degree, std::vector<int> bit_sizes); };
+struct PlainModulus { static Modulus Batching(std::size_t poly_modulus_degree, int bit_size); };
+class EncryptionParameters {
+public:
+    EncryptionParameters(scheme_type scheme);
+    void set_poly_modulus_degree(std::size_t n);
+    void set_coeff_modulus(const std::vector<Modulus> &q);
+    void set_plain_modulus(const Modulus &t);
+    std::size_t poly_modulus_degree() const;
+    const std::vector<Modulus> &coeff_modulus() const;
+    const Modulus &plain_modulus() const;
+};
+namespace util {
+class NTTTables { public: std::uint64_t get_root() const; };
+int get_power_of_two(std::uint64_t value);
+}
 class SEALContext {
 public:
-    class ContextData { public: std::size_t chain_index() const; };
+    class ContextData {
+    public:
+        std::size_t chain_index() const;
+        const EncryptionParameters &parms() const;
+        const parms_id_type &parms_id() const;
+        std::shared_ptr<const ContextData> next_context_data() const;
+        const util::NTTTables *small_ntt_tables() const;
+    };
+    SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true, sec_level_type sec_level = sec_level_type::tc128);
     std::shared_ptr<const ContextData> get_context_data(parms_id_type id) const;
+    std::shared_ptr<const ContextData> key_context_data() const;
+    std::shared_ptr<const ContextData> first_context_data() const;
+    std::shared_ptr<const ContextData> last_context_data() const;
+    const parms_id_type &key_parms_id() const;
     const parms_id_type &first_parms_id() const;
     const parms_id_type &last_parms_id() const;
     bool using_keyswitching() const;
 };
 class Plaintext {
 public:
+    Plaintext();
+    explicit Plaintext(std::size_t coeff_count);
     std::uint64_t *data();
     const std::uint64_t *data() const;
+    std::uint64_t &operator[](std::size_t i);
+    std::size_t coeff_count() const;
+    void set_zero();
     bool is_ntt_form() const;
+    parms_id_type &parms_id();
     void unsafe_load(const SEALContext &context, const seal_byte *in, std::size_t size);
+    std::streamoff save(std::ostream &stream, compr_mode_type compr_mode) const;
+    std::streamoff load(const SEALContext &context, std::istream &stream);
 };
 class Ciphertext {
 public:
     std::uint64_t *data();
     const std::uint64_t *data() const;
+    std::uint64_t *data(std::size_t poly_index);
+    const std::uint64_t *data(std::size_t poly_index) const;
     std::size_t size() const;
     std::size_t coeff_modulus_size() const;
     std::size_t poly_modulus_degree() const;
+    bool &is_ntt_form();
     bool is_ntt_form() const;
     const parms_id_type &parms_id() const;
     void resize(const SEALContext &context, parms_id_type parms_id, std::size_t size);
+    std::streamoff save(std::ostream &stream, compr_mode_type compr_mode) const;
+    std::streamoff load(const SEALContext &context, std::istream &stream);
 };
-class PublicKey { public: const Ciphertext &data() const; };
-class KSwitchKeys { public: const std::vector<std::vector<PublicKey>> &data() const; };
+template <class T> class Serializable { public: std::streamoff save(std::ostream &stream, compr_mode_type compr_mode) const; };
+class PublicKey { public: Ciphertext &data(); const Ciphertext &data() const; };
+class KSwitchKeys {
+public:
+    std::vector<std::vector<PublicKey>> &data();
+    const std::vector<std::vector<PublicKey>> &data() const;
+    parms_id_type &parms_id();
+    std::streamoff save(std::ostream &stream, compr_mode_type compr_mode) const;
+    std::streamoff load(const SEALContext &context, std::istream &stream);
+};
 class RelinKeys : public KSwitchKeys {};
-class Evaluator;
+class SecretKey { public: Plaintext &data(); const Plaintext &data() const; };
+class KeyGenerator {
+public:
+    KeyGenerator(const SEALContext &context);
+    const SecretKey &secret_key() const;
+    void create_relin_keys(RelinKeys &destination);
+    Serializable<RelinKeys> create_relin_keys();
+};
+class Encryptor {
+public:
+    Encryptor(const SEALContext &context, const SecretKey &secret_key);
+    void encrypt_symmetric(const Plaintext &plain, Ciphertext &destination) const;
+    Serializable<Ciphertext> encrypt_symmetric(const Plaintext &plain) const;
+};
+class Decryptor {
+public:
+    Decryptor(const SEALContext &context, const SecretKey &secret_key);
+    void decrypt(const Ciphertext &encrypted, Plaintext &destination);
+    int invariant_noise_budget(const Ciphertext &encrypted);
+};
+class BatchEncoder {
+public:
+    BatchEncoder(const SEALContext &context);
+    void encode(const std::vector<std::uint64_t> &values, Plaintext &destination) const;
+    void decode(const Plaintext &plain, std::vector<std::uint64_t> &destination) const;
+};
+class Evaluator {
+public:
+    Evaluator(const SEALContext &context);
+    void transform_to_ntt(const Ciphertext &encrypted, Ciphertext &destination) const;
+    void transform_to_ntt(const Plaintext &plain, parms_id_type parms_id, Plaintext &destination) const;
+    void transform_to_ntt_inplace(Ciphertext &encrypted) const;
+    void transform_to_ntt_inplace(Plaintext &plain, parms_id_type parms_id) const;
+    void transform_from_ntt_inplace(Ciphertext &encrypted_ntt) const;
+    void multiply_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const;
+    void add(const Ciphertext &a, const Ciphertext &b, Ciphertext &destination) const;
+    void add_inplace(Ciphertext &a, const Ciphertext &b) const;
+    void add_plain(const Ciphertext &encrypted, const Plaintext &plain, Ciphertext &destination) const;
+    void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const;
+    void mod_switch_to_next(const Ciphertext &encrypted, Ciphertext &destination) const;
+    void mod_switch_to_next_inplace(Ciphertext &encrypted) const;
+    void mod_switch_to_inplace(Ciphertext &encrypted, parms_id_type parms_id) const;
+    void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &destination) const;
+    void multiply_inplace(Ciphertext &a, const Ciphertext &b) const;
+    void square(const Ciphertext &encrypted, Ciphertext &destination) const;
+    void relinearize(const Ciphertext &encrypted, const RelinKeys &relin_keys, Ciphertext &destination) const;
+    void relinearize_inplace(Ciphertext &encrypted, const RelinKeys &relin_keys) const;
+};
 }
 '''
 
@@ -178,5 +283,15 @@ def test_adapter_is_well_formed_against_forward_declarations(tmp_path):
     shutil.copy(os.path.join(ROOT, "integration", "he_gpu.h"), inc / "apsu" / "he_gpu.h")
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", str(inc), "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "integration", "receiver_hot_path.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_seal_fixture_generator_is_well_formed_against_forward_declarations(tmp_path):
+    """integration/seal_fixtures.cpp (the SEAL cross-check kit) against the same hand-written declarations: syntax and overloads only"""
+    inc = tmp_path / "inc"
+    (inc / "seal").mkdir(parents=True)
+    (inc / "seal" / "seal.h").write_text(SEAL_H)
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", str(inc), os.path.join(ROOT, "integration", "seal_fixtures.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]

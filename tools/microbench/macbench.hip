@@ -1,6 +1,7 @@
 // Stand-alone timing of the engine's k_mac on a synthetic DB, to bisect its HBM efficiency (see readbw.hip for the ceilings).
 #include "../../apsu_amd/csrc/kernels.hip"
 #include "mac_ring.hip"
+#include "mac_persist.hip"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -88,6 +89,32 @@ int main(int argc, char** argv) {
         std::sort(t.begin(), t.end());
         printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, 2, nb, pad,
                t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
+    }
+    if (getenv("PERSIST")) {
+        // long-lived workgroups (k_mac_p) against one workgroup per unit (k_mac): separate output, bit-compared; A B A B timing
+        u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
+        std::vector<MacJob> jobs2 = jobs;
+        for (size_t x = 0; x < jobs2.size(); x++) for (int g = 0; g < MAC_G; g++) jobs2[x].out[g] = out2 + (jobs[x].out[g] - out);
+        MacJob *dj2; CHECK(hipMalloc(&dj2, jobs2.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj2, jobs2.data(), jobs2.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+        const bool kara = getenv("KARA2") != nullptr;
+        for (int r : { 0, 16, 24, 32, 48, 64, 96 }) {
+            std::vector<float> ta, tb;
+            for (int rep = 0; rep < 14; rep++) {
+                float ms;
+                CHECK(hipEventRecord(e0)); launch_mac(lv, 3, dj, n, (int)jobs.size(), 0, kara); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) ta.push_back(ms);
+                CHECK(hipEventRecord(e0)); launch_mac_persist(lv, dj2, n, (int)jobs2.size(), 0, kara, r); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) tb.push_back(ms);
+            }
+            std::sort(ta.begin(), ta.end()); std::sort(tb.begin(), tb.end());
+            const size_t ow = (size_t)streams * 2 * L * n;
+            std::vector<u64> h1(ow), h2(ow);
+            CHECK(hipMemcpy(h1.data(), out, ow * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h2.data(), out2, ow * 8, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t x = 0; x < ow; x++) bad += h1[x] != h2[x];
+            printf("persistent R=%2d: median %.3f ms (%.0f GB/s)   per unit: %.3f ms (%.0f GB/s)   %+.1f %%   %zu words differ\n", r, tb[tb.size() / 2],
+                   words * 8 / (tb[tb.size() / 2] * 1e-3) / 1e9, ta[ta.size() / 2], words * 8 / (ta[ta.size() / 2] * 1e-3) / 1e9, (tb[tb.size() / 2] / ta[ta.size() / 2] - 1) * 100, bad);
+            CHECK(hipMemset(out2, 0, ow * 8));
+        }
     }
     if (getenv("B2B")) {
         // is part of a launch's time a fixed cost per launch?  N launches queued back to back (no host wait in between) against N x one launch
