@@ -269,10 +269,14 @@ def main():
         ctx.profile_enable(2)
     ms_local = elapsed * 1e3 / max(1, args.steps)
     ms_step = ms_local
+    ms_by_rank = [round(ms_local, 4)]
     if world > 1:
-        tt = torch.tensor([ms_local], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_step = float(tt.item())
+        # MAX over ranks is the step time; the per-rank list shows the straggler (and that the collective saw `world` ranks)
+        mine_t = torch.tensor([ms_local], dtype=torch.float64, device=gdev)
+        all_t = torch.zeros(world, dtype=torch.float64, device=gdev)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        ms_by_rank = [round(float(v), 4) for v in all_t.cpu().tolist()]
+        ms_step = max(ms_by_rank)
 
     result = {
         "metric": "sender query-eval ms (ComputePowers + all BinBundles + gather), %s params" % args.config,
@@ -290,6 +294,19 @@ def main():
                    "db_bytes_rank0": db_bytes, "binbundles_rank0": len(mine), "parallelism": "binbundle-shard x%d" % world,
                    "setup_s": round(t_setup, 2)},
     }
+
+    # what ran the gather: torch.distributed's view of the job (RCCL is what "nccl" means on ROCm), so that a reader of the line can
+    # see that the collective had `world` ranks and which rank was the straggler
+    dinfo = {"world_size": world, "ms_local_by_rank": ms_by_rank, "binbundles_by_rank": [len(a) for a in assign]}
+    if world > 1:
+        dinfo["backend"] = dist.get_backend()
+        dinfo["world_size"] = dist.get_world_size()
+        dinfo["gather"] = "all_gather_into_tensor of %d fixed-size rows per rank (%d bytes per rank)" % (max_local, max_local * 2 * n * 8)
+    try:
+        dinfo["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                          # never lose the main line
+        dinfo["rccl_version"] = "unavailable: %s" % e
+    result["distributed"] = dinfo
 
     if phases is not None:
         result["phases_ms"] = {k: {"instances": v[0], "avg": round(v[1], 4), "min": round(v[2], 4), "max": round(v[3], 4)} for k, v in phases.items()}
@@ -317,16 +334,31 @@ def main():
             "algorithmic_bytes_per_launch": int(ntt_bytes / max(1, ntt_launches)),
             "avg_launch_us": round(ntt_ms * 1e3 / max(1, ntt_launches), 2),
             "launches_per_step": ntt_launches / steps, "limb_transforms_per_step": ntt_limbs / steps, "steps_sampled": sampled,
-            "note": "working sets of in-path launches are mostly Infinity-Cache resident; see ntt_stream for >=1 GiB batches",
         }
         # the inverse transforms whose LOAD also forms the BEHZ tensor product (k_intt_tensor) are a different kernel doing more
         # than a transform; with them every limb transform of the query is covered
         f_ms, f_la, f_li, f_by, f_ach = fig(prof, ("ntt_fused",))
         a_ms, a_la, a_li, a_by, a_ach = fig(prof, ("ntt_fwd", "ntt_inv", "ntt_fused"))
+        # ... and by the bytes the fused kernel really moves per output limb: polynomial 0 and 2 of a product read two operand limbs
+        # (a0 b0 | a1 b1) and write one = 24 n bytes, polynomial 1 reads four (a0 b1 + a1 b0) = 40 n; the Bsk sums that ride in the same
+        # launch are plain transforms (16 n).  The operands come from L2 / the Infinity Cache (each is read by up to three workgroups,
+        # placed on one XCD), so this is cache bandwidth, not an HBM claim -- it says why the 16 n figure undersells the kernel.
+        f_actual_bytes = f_li * (24 + 40 + 24) / 3.0 * n
+        f_actual = f_actual_bytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
         result["roofline"]["fused_transforms"] = {
             "kernel": "k_intt_tensor (inverse transform + tensor product on load)", "achieved": round(f_ach, 1),
             "frac": round(f_ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(f_ms * 1e3 / max(1, f_la), 2),
-            "launches_per_step": f_la / steps, "limb_transforms_per_step": f_li / steps}
+            "launches_per_step": f_la / steps, "limb_transforms_per_step": f_li / steps,
+            "bytes_per_limb_actual": {"poly0": 24 * n, "poly1": 40 * n, "poly2": 24 * n, "mean": round(88 * n / 3.0, 1)},
+            "achieved_actual_bytes": round(f_actual, 1), "frac_actual_bytes": round(f_actual / HBM_PEAK_GBS, 4),
+            "note": "achieved / frac count 16 n bytes per limb like a plain transform; *_actual_bytes count the operand limbs the load "
+                    "really reads (served by L2 / Infinity Cache, an upper bound when the launch also carries plain limbs)"}
+        result["roofline"]["note"] = ("the transform is instruction-issue bound, not HBM-bound: 9 integer multiplies + 6 sixty-four-bit add-class "
+                                      "instructions per butterfly at 4.6-5.4 cycles each (profiles/r01_intmul_microbench.txt), VALU busy 80-83 % "
+                                      "at 2.05 GHz (profiles/r03_ntt_pmc.txt; round 4 see profiles/r04_ntt_pmc.txt), HBM traffic 1.05x "
+                                      "algorithmic; a butterfly-only kernel would reach 4.9 TB/s = 0.61 (profiles/r02_bfly_microbench.txt). "
+                                      "In-path launches are mostly Infinity-Cache resident and 13 of 15 are below 2 000 limbs (launch-round bound); "
+                                      "see ntt_stream for >= 1 GiB batches")
         result["roofline"]["all_transforms"] = {"achieved": round(a_ach, 1), "frac": round(a_ach / HBM_PEAK_GBS, 4),
                                                 "limb_transforms_per_step": a_li / steps, "ms_per_step": round(a_ms / steps, 4)}
         # the same figure over the two untimed steps that carry events around EVERY launch (cross-check of the sample)

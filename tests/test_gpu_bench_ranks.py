@@ -34,6 +34,30 @@ def test_two_rank_bench_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["gather_check"] == {"rank0_rows_match": True, "all_binbundle_rows_filled": True, "rows": 34}
     assert d["config"]["binbundles_rank0"] == 17
+    # the line says who gathered: both ranks, their own step times, the split of the BinBundles
+    assert d["distributed"]["world_size"] == 2 and d["distributed"]["backend"] == "gloo"
+    assert len(d["distributed"]["ms_local_by_rank"]) == 2 and max(d["distributed"]["ms_local_by_rank"]) == d["ms_per_step"]
+    assert d["distributed"]["binbundles_by_rank"] == [17, 17]
+
+
+def test_two_rank_bench_over_rccl():
+    """the driver's launch for N = 2 -- one rank per GPU, the "nccl" (= RCCL) backend, results gathered over xGMI.  Needs two GPUs:
+    skipped on the one-GPU boxes this repository is developed on (the N > 1 code path is rehearsed there by the gloo test above and
+    by the one-rank RCCL group below; RCCL with more than one rank first runs in the driver's SCALE step)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("APSU_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "1M-1024-com", "--no-profile"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size"] == 2
+    assert d["gather_check"] == {"rank0_rows_match": True, "all_binbundle_rows_filled": True, "rows": 34}
+    assert len(d["distributed"]["ms_local_by_rank"]) == 2
 
 
 def test_rccl_collective_pattern_one_rank():
