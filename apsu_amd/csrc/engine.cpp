@@ -561,6 +561,9 @@ struct ProfScope {
     ~ProfScope() { e->prof_end(); }
 };
 #define PROF(kind, units) ProfScope prof_scope_(this, kind, units)
+// element-wise classes: units = ALGORITHMIC bytes of the launch (compulsory operand reads + result writes, 8 bytes per word;
+// level constants and the relinearisation keys -- shared by every coefficient, cache-resident -- not counted)
+#define PROFW(kind, words) ProfScope prof_scope_(this, kind, (uint64_t)(words) * 8)
 static uint64_t mac_units(const std::vector<MacJob> &mj) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * j.nl; return u; }
 // mean number of terms per (stream, limb) chain of a launch: the three-product form pays for long chains only
 static uint32_t mac_mean_cnt(const std::vector<MacJob> &mj)
@@ -775,10 +778,11 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
     const int *amap = raw ? map_ksacc_raw(chain_idx) : map_ksacc(chain_idx);
     // (the inner product formed by the inverse transform's load, the way the BEHZ tensor product is, was measured in round 3:
     //  2 % SLOWER on the whole query -- six operand streams per output and tdec read twice; tools/microbench/intt_ks_experiment.hip)
-    { PROF(P_KEYSWITCH, 0); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
+    { PROFW(P_KEYSWITCH, (size_t)batch * n * ((size_t)L * (L + 1) + 2 * (L + 1))); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), amap, L + 1, true);
     const bool fuse_ext = ext_out && n_ext > 0 && fuse_ext_ && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
-    { PROF(P_KEYSWITCH, 0); launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0, raw); }
+    { PROFW(P_KEYSWITCH, (size_t)batch * n * (2 * (L + 1) + 4 * L) + (fuse_ext ? (size_t)n_ext * 2 * (hlevel(chain_idx).L + hlevel(chain_idx).nB + 1) * n : 0));
+      launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0, raw); }
     return fuse_ext;
 }
 
@@ -1206,7 +1210,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 const int npar = pl.sp - pl.s0;
                 if (npar > 0) {
                     // (parents that came out of a key switch were extended by its mod-down kernel: run.ext_done)
-                    if (run.ext_done != (int)d - 1) { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(first), hlevel(first).L, hlevel(first).nB, slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
+                    if (run.ext_done != (int)d - 1) { PROFW(P_BEHZ_EXT, (size_t)npar * nb * 2 * n * (Lf + Ef)); launch_behz_ext(dlevel(first), hlevel(first).L, hlevel(first).nB, slot_ptr(pl.s0, 0), slot_w, 2, ext_ptr(pl.s0, 0), n, npar * nb, st_); }
                     d_ntt(ext_ptr(pl.s0, 0), (size_t)npar * nb * 2 * Ef, map_ext(first), (int)Ef, false);
                 }
                 const auto &cl = s.levels[d];
@@ -1229,7 +1233,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
                 }
-                { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
+                { PROFW(P_BEHZ_FINISH, fj.size() * 3 * n * (Ef + Lf)); launch_behz_finish(dlevel(first), hlevel(first).L, hlevel(first).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
                 if (hp_.using_keyswitching && nn > 0) {                                                                          // :431
                     const int npar_here = ((size_t)d + 1 < s.levels.size()) ? (cl.sp - cl.s0) : 0;
                     if (d_relinearize(slot_ptr(cl.s0, 0), slot_w, nn * nb, *rk, first, npar_here ? ext_ptr(cl.s0, 0) : nullptr, npar_here * nb))
@@ -1260,11 +1264,11 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
             for (size_t i = 0; i < powers.size(); i++)
                 for (int b = 0; b < nb; b++)
                     jobs.push_back(CtJob{ slot_ptr(s.slot_of[powers[i]], b), cur + ((size_t)b * powers.size() + i) * 2 * (Lf - 1) * n });
-            { PROF(P_MODSWITCH, 0); launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_); }                     // :463,471,478
+            { PROFW(P_MODSWITCH, (size_t)cnt * 2 * n * (2 * Lf - 1)); launch_modswitch_jobs(dlevel(first), upload_jobs(jobs), 2, n, cnt, st_); }                     // :463,471,478
             lvl = first - 1;
             while (lvl > target) {
                 u64 *nxt = dst_for(lvl - 1);
-                { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lvl), cur, (size_t)2 * (lvl + 1) * n, 2, nxt, n, cnt, st_); }
+                { PROFW(P_MODSWITCH, (size_t)cnt * 2 * n * (2 * lvl + 1)); launch_modswitch(dlevel(lvl), cur, (size_t)2 * (lvl + 1) * n, 2, nxt, n, cnt, st_); }
                 cur = nxt;
                 lvl--;
             }
@@ -1289,7 +1293,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
         if (do_high && pw->n_high) {
             convert(s.high_powers, high, pw->high.u());
             // derived form used by eval_patstock's ct x ct products and coefficient-form plaintext products
-            { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
+            { PROFW(P_BEHZ_EXT, (size_t)pw->n_high * nb * 2 * n * (Lh + Eh)); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, pw->high.u(), Lh * n, 1, pw->hext.u(), n, (int)(pw->n_high * nb * 2), st_); }
             d_ntt(pw->hext.u(), (size_t)pw->n_high * nb * 2 * Eh, map_ext(high), (int)Eh, false);
         }
     }
@@ -1942,7 +1946,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj))); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
                 // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
-                { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
+                { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
             }
 
             // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
@@ -2079,17 +2083,17 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     u64 *ext = ws((size_t)NI * 2 * Eh * n);
                     bool fused_drop = false;
                     if (low == high + 1) {
-                        PROF(P_BEHZ_EXT, 0);
+                        PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Ll + Eh));
                         fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_, raw_drop);
                     }
                     if (!fused_drop) {
                         u64 *innerh = inner;
                         for (int lv = low; lv > high; lv--) {
                             u64 *nxt = ws((size_t)NI * 2 * lv * n);
-                            { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
+                            { PROFW(P_MODSWITCH, (size_t)NI * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
                             innerh = nxt;
                         }
-                        { PROF(P_BEHZ_EXT, 0); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+                        { PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Lh + Eh)); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
                     }
                     d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
                     if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
@@ -2140,15 +2144,16 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                                     const size_t job = (size_t)in_off[x] + i;
                                     pj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(1 + i, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n });
                                 }
-                            { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
+                            // (only the Bsk limbs: four operand limbs per term in, three sums per BinBundle out)
+                            { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
                             PROF(P_NTT_FUSED, dmap.size());
                             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
                                                tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
                         } else {
-                            { PROF(P_TENSOR, 0); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
+                            { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
                             d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
                         }
-                        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
+                        { PROFW(P_BEHZ_FINISH, ((size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh) + (size_t)Bs * 3 * Lh) * n); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
                     } else {
                         if (late_high) {
                             g.cf = ws(w_cf);
@@ -2194,12 +2199,12 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         std::vector<I0Job> ij;
                         for (int x = 0; x < Bs; x++)
                             ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
-                        { PROF(P_MODSWITCH, 0); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0); }
+                        { PROFW(P_MODSWITCH, (size_t)Bs * n * (4 * Lh + 2 * l)); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0); }
                     } else {
                         u64 *termh = term;
                         for (int lv = low; lv > high; lv--) {
                             u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
-                            { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
+                            { PROFW(P_MODSWITCH, (size_t)Bs * l * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
                             termh = nxt;
                         }
                         i0 = ws((size_t)Bs * 2 * Lh * n);
@@ -2213,7 +2218,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     for (int x = 0; x < Bs; x++)
                         ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
                                              bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]) });
-                    { PROF(P_MODSWITCH, 0); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
+                    { PROFW(P_MODSWITCH, (size_t)Bs * n * (7 * Lh + 4)); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
                 }
             }
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);

@@ -297,7 +297,7 @@ def main():
 
     # what ran the gather: torch.distributed's view of the job (RCCL is what "nccl" means on ROCm), so that a reader of the line can
     # see that the collective had `world` ranks and which rank was the straggler
-    dinfo = {"world_size": world, "ms_local_by_rank": ms_by_rank, "binbundles_by_rank": [len(a) for a in assign]}
+    dinfo = {"world_size": world, "ms_local_by_rank": ms_by_rank, "binbundles_by_rank": [len(assign[r]) for r in range(world)]}
     if world > 1:
         dinfo["backend"] = dist.get_backend()
         dinfo["world_size"] = dist.get_world_size()
@@ -369,6 +369,18 @@ def main():
         mac_ms, _, mac_units = prof_all["dyadic_mac"]
         mac_bytes = mac_units * n * 8                                   # plaintext bytes streamed from HBM
         result["kernels_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof_all.items()}
+        # element-wise classes: the engine reports the ALGORITHMIC bytes of every launch (compulsory operand reads + result writes;
+        # apsu_amd/csrc/engine.cpp PROFW) next to its event time.  Their operands are produced by the kernel in front of them and sit in
+        # L2 / the Infinity Cache, so these are cache-bandwidth figures priced against the HBM peak only for comparability.
+        ew = {}
+        for cls in ("behz_ext", "behz_tensor", "behz_finish", "keyswitch", "modswitch"):
+            ms_c, la_c, by_c = prof_all[cls]
+            if ms_c > 0 and by_c > 0:
+                ew[cls] = {"ms_per_step": round(ms_c / 2, 4), "launches_per_step": la_c / 2, "algorithmic_MB_per_step": round(by_c / 2 / 1e6, 1),
+                           "GBps": round(by_c / (ms_c * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(by_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if ew:
+            ew["note"] = "per class of element-wise kernel: algorithmic bytes per step / event time; VALU-busy figures per kernel are in profiles/r04_elementwise_roofline.txt"
+            result["elementwise_roofline"] = ew
         mac_gbps = mac_bytes / (mac_ms * 1e-3) / 1e9 if mac_ms > 0 else 0.0
         result["dyadic_mac"] = {"db_GBps": round(mac_gbps, 1), "frac_of_hbm_peak": round(mac_gbps / HBM_PEAK_GBS, 4),
                                 "db_bytes_per_step": int(mac_bytes / 2), "ms_per_step": round(mac_ms / 2, 4),
