@@ -10,6 +10,7 @@
 #include <string>
 
 #include "blake2x.h"
+#include "keccak.h"
 
 namespace apsu_he {
 namespace sealio {
@@ -248,15 +249,15 @@ void parse_ciphertext_members(Cursor &c, uint8_t vmaj, uint8_t vmin, const std::
     c.skip((size_t)info.h.total);
     Cursor ic{ info.p, info.n };
     const uint8_t type = ic.u8();
-    if (type == 2) bad("seeded ciphertext under the Shake256 generator: only SEAL's default (Blake2xb) is supported");
-    if (type != 1) bad("unknown generator type in a seeded ciphertext");
+    if (type != PRNG_BLAKE2XB && type != PRNG_SHAKE256) bad("unknown generator type in a seeded ciphertext");
     ic.need(64);
     for (int i = 0; i < 8; i++) ct.seed[i] = rd64(ic.here() + 8 * i);
     ct.seeded = true;
-    if (!expand) return;
+    ct.prng_type = type;
+    if (!expand && type == PRNG_BLAKE2XB) return;                  // left to the device (apsu_he_seed_expand)
     if (!lv) bad("parms_id of a seeded ciphertext is not in this context's modulus chain");
-    sample_poly_uniform(ct.seed, lv->q.data(), lv->q.size(), (size_t)ct.poly_modulus_degree, ct.data.data() + poly_words);
-    ct.seeded = true;
+    sample_poly_uniform(ct.seed, lv->q.data(), lv->q.size(), (size_t)ct.poly_modulus_degree, ct.data.data() + poly_words, type);
+    if (!expand) ct.seeded = false;                               // a Shake256 object handed to a caller that expands on the device: complete as it is
 }
 
 std::vector<uint8_t> ciphertext_members(const Ciphertext &ct)
@@ -279,7 +280,7 @@ std::vector<uint8_t> ciphertext_members(const Ciphertext &ct)
     m.insert(m.end(), ao.begin(), ao.end());
     if (ct.seeded) {
         std::vector<uint8_t> info;
-        info.push_back(1);                                        // prng_type::blake2xb
+        info.push_back(ct.prng_type);                             // prng_type::blake2xb (1) or shake256 (2)
         for (int i = 0; i < 8; i++) wr64(info, ct.seed[i]);
         const std::vector<uint8_t> io = close_object(info, ct.version_major, ct.version_minor, COMPR_NONE);
         m.insert(m.end(), io.begin(), io.end());
@@ -313,8 +314,38 @@ std::vector<Level> modulus_chain(uint64_t n, const std::vector<uint64_t> &key_mo
     return chain;
 }
 
-void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst)
+void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst, uint8_t prng_type)
 {
+    if (prng_type == PRNG_SHAKE256) {
+        // Shake256PRNG::refill_buffer (randomgen.cpp [SEAL-recall]): 4096-byte buffer k = SHAKE256(seed || k), consumed in order
+        std::vector<uint64_t> buf(512);
+        uint64_t have = ~(uint64_t)0;
+        auto word = [&](uint64_t w) -> uint64_t {
+            if ((w >> 9) != have) {
+                have = w >> 9;
+                uint64_t in[9];
+                for (int i = 0; i < 8; i++) in[i] = seed[i];
+                in[8] = have;
+                keccak::shake256(reinterpret_cast<uint8_t *>(buf.data()), 4096, reinterpret_cast<const uint8_t *>(in), sizeof(in));
+            }
+            return buf[w & 511];
+        };
+        const uint64_t bulk = (uint64_t)L * n;
+        for (uint64_t w = 0; w < bulk; w++) dst[w] = word(w);
+        uint64_t next = bulk;
+        for (size_t j = 0; j < L; j++) {
+            const uint64_t max_random = ~(uint64_t)0;
+            const uint64_t max_multiple = max_random - (max_random % q[j]) - 1;
+            uint64_t *p = dst + j * n;
+            for (size_t k = 0; k < n; k++) {
+                uint64_t r = p[k];
+                while (r >= max_multiple) r = word(next++);
+                p[k] = r % q[j];
+            }
+        }
+        return;
+    }
+    if (prng_type != PRNG_BLAKE2XB) throw std::invalid_argument("unknown generator type");
     Blake2xbSeed s;
     for (int i = 0; i < 8; i++) s.w[i] = seed[i];
     uint64_t blk[8];

@@ -21,6 +21,8 @@
 //                      seeded: the DynArray holds c0 only (size/2 of the words); c1 = sample_poly_uniform(PRNG(seed))
 //   DynArray<u64>    : own SEALHeader (compr none) | count u64 | words
 //   UniformRandomGeneratorInfo : own SEALHeader | prng_type u8 (1 blake2xb, 2 shake256) | seed 64 B
+//                      shake256 (keccak.h): buffer k = SHAKE256(seed || k as u64) squeezed to 4096 bytes; such objects are expanded on the
+//                      host whatever the caller asked for (the device kernels know Blake2xb only) and then count as unseeded
 //   PublicKey        : exactly its Ciphertext's object (PublicKey::save forwards to pk_.save: ONE SEALHeader, no envelope of its own)
 //   KSwitchKeys      : parms_id 4 x u64 | dim1 u64 | for each: dim2 u64 | dim2 x PublicKey (= Ciphertext) object
 //                      RelinKeys: dim1 = 1, dim2 = decomposition count = K - 1, every key ciphertext size 2 over all K primes, NTT form
@@ -45,8 +47,10 @@ void compute_parms_id(uint64_t out[4], uint64_t scheme, uint64_t poly_modulus_de
 // key level first (all K primes), then every data level down to one prime (SEALContext's chain)
 std::vector<Level> modulus_chain(uint64_t poly_modulus_degree, const std::vector<uint64_t> &key_moduli, uint64_t plain_modulus);
 
-// util::sample_poly_uniform under SEAL's Blake2xb generator seeded with `seed`: dst[L][n]
-void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst);
+// util::sample_poly_uniform under one of SEAL's generators seeded with `seed`: dst[L][n].  prng_type 1 = Blake2xb (SEAL's default),
+// 2 = Shake256 (a SEAL built with SEAL_DEFAULT_PRNG=Shake256; host only -- such objects are always expanded by the codec itself)
+enum : uint8_t { PRNG_BLAKE2XB = 1, PRNG_SHAKE256 = 2 };
+void sample_poly_uniform(const uint64_t seed[8], const uint64_t *q, size_t L, size_t n, uint64_t *dst, uint8_t prng_type = PRNG_BLAKE2XB);
 
 struct Ciphertext {
     uint64_t parms_id[4] = { 0, 0, 0, 0 };
@@ -54,6 +58,7 @@ struct Ciphertext {
     uint64_t size = 0, poly_modulus_degree = 0, coeff_modulus_size = 0, correction_factor = 1;
     double scale = 1.0;
     bool seeded = false;                 // load: the object carried a seed (expanded into data); save: write the seeded form
+    uint8_t prng_type = PRNG_BLAKE2XB;   // generator of a seeded object
     uint64_t seed[8] = { 0 };
     uint8_t version_major = 4, version_minor = 0;
     std::vector<uint64_t> data;          // [size][coeff_modulus_size][poly_modulus_degree], expanded

@@ -123,8 +123,18 @@ def prng_words(seed):
         yield from struct.unpack("<512Q", buf)
 
 
-def sample_poly_uniform(seed, q, n):
-    g = prng_words(seed)
+def shake_words(seed):
+    """SEAL's Shake256 generator [SEAL-recall]: 4096-byte buffer k = SHAKE256(seed || k as u64), python's hashlib as the pin of SHAKE256"""
+    key = struct.pack("<8Q", *seed)
+    counter = 0
+    while True:
+        buf = hashlib.shake_256(key + struct.pack("<Q", counter)).digest(4096)
+        counter += 1
+        yield from struct.unpack("<512Q", buf)
+
+
+def sample_poly_uniform(seed, q, n, shake=False):
+    g = shake_words(seed) if shake else prng_words(seed)
     L = len(q)
     out = np.array([next(g) for _ in range(L * n)], dtype=object).reshape(L, n)
     for j, qj in enumerate(q):
@@ -299,11 +309,10 @@ def test_ciphertext_rejects_malformed(ctx):
     sblob = obj(ct_members([9, 9, 9, 9], False, data, (4, 0), seed=seed), 0)
     with pytest.raises(apsu_amd.ApsuHeError, match="parms_id"):
         ctx.ct_load(sblob)
-    # Shake256 generator
+    # an unknown generator type
     m = ct_members(pid, False, data, (4, 0), seed=seed)
-    shake = obj(m[:-65] + bytes([2]) + m[-64:], 0)
-    with pytest.raises(apsu_amd.ApsuHeError, match="Shake256"):
-        ctx.ct_load(shake)
+    with pytest.raises(apsu_amd.ApsuHeError, match="generator"):
+        ctx.ct_load(obj(m[:-65] + bytes([3]) + m[-64:], 0))
     # corrupt zlib stream, and random corruptions never crash
     z = obj(ct_members(pid, False, data, (4, 0)), 1)
     with pytest.raises(apsu_amd.ApsuHeError):
@@ -346,3 +355,22 @@ def test_relin_keys_both_directions(ctx, compr, seeded):
     with pytest.raises((ValueError, apsu_amd.ApsuHeError)):          # seeded: unknown parms_id; unseeded: parameter mismatch
         other.relin_keys_load(blob)
     other.close()
+
+
+def test_seeded_objects_of_a_shake256_seal(ctx):
+    """a SEAL built with SEAL_DEFAULT_PRNG=Shake256 writes prng_type 2 into its seeded objects (sender/apsu/plaintext_powers.cpp:41-46
+    would produce such queries): expanded by the host codec in every load mode, SHAKE256 itself pinned by hashlib"""
+    rng = np.random.default_rng(9)
+    pid = parms_id(N, Q[:2], T)
+    seed = [int(x) for x in rng.integers(0, 2**63, 8, dtype=np.uint64)]
+    c0 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q[:2]])
+    c1 = sample_poly_uniform(seed, Q[:2], N, shake=True)
+    assert not (c1 == sample_poly_uniform(seed, Q[:2], N)).all()
+    m = ct_members(pid, False, np.stack([c0, c1]), (4, 0), seed=seed)
+    for compr in (0, 1):
+        blob = obj(m[:-65] + bytes([2]) + m[-64:], compr)
+        got = ctx.ct_load(blob)
+        assert got["seeded"] and got["chain_idx"] == 1 and (got["data"] == np.stack([c0, c1])).all()
+        # the load that leaves Blake2xb seeds to the device hands a Shake256 object back complete and marked unseeded
+        u = ctx.ct_load_unexpanded(blob, 2, N)
+        assert not u["seeded"] and (u["data"] == np.stack([c0, c1])).all()
