@@ -54,6 +54,9 @@ struct DevLevel {
     // lazy Shoup product (< 2m), sums stay below 8m < 2^64 and are reduced once
     ShoupConst s_q_to_bsk[DMAXB][DMAXL];
     ShoupConst s_prod_q_bsk[DMAXB];
+    // the same two with m_tilde^-1 folded in (sm_mrq's closing product becomes a plain reduction: behz_ext2_body)
+    ShoupConst s_q_to_bsk_mt[DMAXB][DMAXL];
+    ShoupConst s_prod_q_bsk_mt[DMAXB];
     ShoupConst s_fl[DMAXB];                     // i < nB: (Q^-1 * (B/b_i)^-1) mod b_i ; i = nB: Q^-1 mod m_sk
     ShoupConst s_B_to_q[DMAXL][DMAXB];
     ShoupConst s_B_to_msk[DMAXB];

@@ -226,6 +226,11 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                 d.s_prod_q_bsk[i] = shoup_const(h.prod_q_mod_bsk[i], m);
                 d.s_fl[i] = shoup_const(i < nB ? ModulusInfo(m).mul(h.inv_prod_q_mod_bsk[i], h.inv_punct_B[i]) : h.inv_prod_q_mod_bsk[i], m);
                 d.inv_mt_bsk[i] = shoup_const(h.inv_mtilde_mod_bsk[i], m);
+                {
+                    const ModulusInfo mi(m);
+                    for (int j = 0; j < L; j++) d.s_q_to_bsk_mt[i][j] = shoup_const(mi.mul(h.q_to_bsk[i][j] % m, h.inv_mtilde_mod_bsk[i]), m);
+                    d.s_prod_q_bsk_mt[i] = shoup_const(mi.mul(h.prod_q_mod_bsk[i], h.inv_mtilde_mod_bsk[i]), m);
+                }
                 d.t_bsk[i] = shoup_const(hp_.t % m, m);
                 d.inv_prod_q_bsk[i] = shoup_const(h.inv_prod_q_mod_bsk[i], m);
                 if (i < nB) {

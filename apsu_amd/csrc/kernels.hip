@@ -922,10 +922,12 @@ __device__ __forceinline__ void behz_ext2_body(const DevLevel *__restrict__ lv, 
         const u64 m = lv->bsk[i].q;
         u64 r = r32;
         if (r32 >= 0x80000000u) r += m - ((u64)1 << 32);          // centred lift of r into Z_m
-        u64 v = lazy2(r, lv->s_prod_q_bsk[i], m);                 // (2L + 2) m <= 8 m < 2^64
+        // sm_mrq: (x_i + q r) m_tilde^-1 mod m with x_i = sum_j xs_j (Q/q_j): m_tilde^-1 is folded into both constants (round 4), so
+        // the closing product is a reduction of the lazy sum v < (2L + 2) m <= 8 m < 2^64 -- the same residue, one Shoup product less
+        u64 v = lazy2(r, lv->s_prod_q_bsk_mt[i], m);
 #pragma unroll
-        for (int j = 0; j < L; j++) v += lazy2(xs[j], lv->s_q_to_bsk[i][j], m);
-        dst[(size_t)(L + i) * n + k] = mul_shoup(v, lv->inv_mt_bsk[i].w, lv->inv_mt_bsk[i].wq, m);
+        for (int j = 0; j < L; j++) v += lazy2(xs[j], lv->s_q_to_bsk_mt[i][j], m);
+        dst[(size_t)(L + i) * n + k] = csub(csub(csub(v, m << 2), m << 1), m);
     }
 }
 

@@ -12,6 +12,11 @@ template <class T> __device__ __forceinline__ T *uniform_ptr(T *p)
 }
 __device__ __forceinline__ u32 uniform_u32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
+// the job table seen through the CONSTANT address space: a load with a wave-uniform address from it is a scalar load (s_load, tracked
+// by lgkmcnt), so reading the next unit's descriptor does not wait for -- and thereby drain -- the vector loads in flight
+typedef const MacJob __attribute__((address_space(4))) *MacJobC;
+template <class T> __device__ __forceinline__ T *from_const(const T __attribute__((address_space(4))) *p) { return (T *)(uintptr_t)p; }
+
 // ---- k_mac_p: the same sums with workgroups that live for many units (round 4) -----------------------------------------
 // k_mac starts one workgroup per (coefficient block, limb, job).  Each pays a cold start (descriptor, stream pointers, first
 // terms: three dependent memory round trips) and a drain (fold, store) during which its CU streams at most half of what it
@@ -38,20 +43,20 @@ __global__ __launch_bounds__(EW_T, 2) void k_mac_p(const DevLevel *__restrict__ 
     // the unit at or behind (z, y) in this workgroup's walk; false at the end of the walk
     auto find = [&](u32 &z, u32 &y, Unit &u) -> bool {
         while (z < nz) {
-            const MacJob *__restrict__ jp = jobs + z / SPLIT;
-            const u32 g0 = (z % SPLIT) * G, ng = uniform_u32(jp->ng), nl = uniform_u32(jp->nl);
+            const MacJobC jp = (MacJobC)(uintptr_t)(jobs + z / SPLIT);
+            const u32 g0 = (z % SPLIT) * G, ng = jp->ng, nl = jp->nl;
             if (g0 < ng && y < nl) {
-                const u32 j = y + uniform_u32(jp->limb0);
+                const u32 j = y + jp->limb0;
                 const size_t off = (size_t)j * n;
-                u.p0 = uniform_ptr(jp->pw) + off;
-                u.pw_poly_stride = uniform_u32(jp->pw_poly_stride);
+                u.p0 = jp->pw + off;
+                u.pw_poly_stride = jp->pw_poly_stride;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const u32 gi = g0 + g < ng ? g0 + g : g0;                   // missing streams alias a real one
-                    u.pt[g] = uniform_ptr(jp->pt[gi]) + off;
+                    u.pt[g] = jp->pt[gi] + off;
                 }
-                u.jp = jp;
-                u.cnt = uniform_u32(jp->cnt); u.pt_stride = uniform_u32(jp->pt_stride); u.pw_stride = uniform_u32(jp->pw_stride);
+                u.jp = jobs + z / SPLIT;
+                u.cnt = jp->cnt; u.pt_stride = jp->pt_stride; u.pw_stride = jp->pw_stride;
                 u.g0 = g0; u.live = ng - g0 < (u32)G ? ng - g0 : (u32)G; u.j = j; u.y = y;
                 return true;
             }
@@ -85,10 +90,9 @@ __global__ __launch_bounds__(EW_T, 2) void k_mac_p(const DevLevel *__restrict__ 
     for (;;) {
         u32 z2 = z, y2 = y + 1;
         const bool has_next = find(z2, y2, nxt);                 // its descriptor loads overlap this unit's stream
-        const Mod mq = lv->q[cur.j];
-        const Mod m{ ((u64)uniform_u32((u32)(mq.q >> 32)) << 32) | uniform_u32((u32)mq.q), ((u64)uniform_u32((u32)(mq.r0 >> 32)) << 32) | uniform_u32((u32)mq.r0),
-                     ((u64)uniform_u32((u32)(mq.r1 >> 32)) << 32) | uniform_u32((u32)mq.r1) };
-        const u32 s = uniform_u32(lv->mac_shift[cur.j]), chunk = uniform_u32(KARA ? lv->mac_chunk_k[cur.j] : lv->mac_chunk[cur.j]);
+        const DevLevel __attribute__((address_space(4))) *lc = (const DevLevel __attribute__((address_space(4))) *)(uintptr_t)lv;
+        const Mod m{ lc->q[cur.j].q, lc->q[cur.j].r0, lc->q[cur.j].r1 };
+        const u32 s = lc->mac_shift[cur.j], chunk = KARA ? lc->mac_chunk_k[cur.j] : lc->mac_chunk[cur.j];
         const u32 lomask = (1u << s) - 1;
         u64 s00[G][C][2], sx[G][C][2], s11[G][C][2];
 #pragma unroll
@@ -169,8 +173,9 @@ __global__ __launch_bounds__(EW_T, 2) void k_mac_p(const DevLevel *__restrict__ 
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if ((u32)g < cur.live) {
-                u64 *o = uniform_ptr(cur.jp->out[cur.g0 + g]) + (size_t)cur.y * n + k;
-                const u32 ops = uniform_u32(cur.jp->out_poly_stride);
+                const MacJobC cj = (MacJobC)(uintptr_t)cur.jp;
+                u64 *o = cj->out[cur.g0 + g] + (size_t)cur.y * n + k;
+                const u32 ops = cj->out_poly_stride;
                 if (C == 2) {
                     u64x2 r0, r1;
                     r0[0] = s00[g][0][0]; r0[1] = s00[g][C - 1][0];
