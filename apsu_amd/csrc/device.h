@@ -25,6 +25,11 @@ struct DevLevel {
     u64 t;
     u32 mac_shift[DMAXL], mac_chunk[DMAXL];     // k_mac: operand split width s = ceil(bits(q_j)/2) and terms per carry-free chunk
     u32 mac_chunk_k[DMAXL];                     // ... of the three-product form (middle products have 2 s + 2 bits)
+    // Bit-packed database rows (round 4; k_mac<.., PACKED>): limb j of a stored NTT-form plaintext takes mac_bits[j] bits per
+    // coefficient -- the smallest width >= bits(q_j) for which a lane's 16-byte window covers its two coefficients at every
+    // position (48, 49, 50, 52, 56; else 64 = not packed) -- in rows of n * mac_bits[j] / 8 bytes at byte offset mac_row_off[j]
+    // inside a plaintext slot.  Rows depend on the limb only, so every level's prefix of them is the same.
+    u32 mac_bits[DMAXL], mac_row_off[DMAXL], mac_mask_hi[DMAXL];
     // add_plain (App. B7) and plaintext lift (B5)
     u64 coeff_div_plain[DMAXL];
     u64 q_mod_t, threshold;
@@ -102,6 +107,7 @@ struct MacJob {
     u32 pt_stride, pw_stride, pw_poly_stride;        // in u64 words
     u32 out_poly_stride;  // words between the two output polynomials (L*n for a full ciphertext)
     u32 limb0, nl;        // limbs limb0 .. limb0+nl-1 are handled (grid.y >= nl exits); modulus = q[limb]
+    u32 packed, pad;      // packed: pt[] point at bit-packed plaintext slots and pt_stride is in BYTES (DevLevel::mac_bits)
 };
 
 // ---- launch wrappers (all asynchronous on `st`) --------------------------------------------
@@ -191,7 +197,11 @@ void launch_ks_inner(const DevKey *key, int L, const u64 *tdec, const u64 *rk, u
 void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t ct_stride, size_t n, int batch,
                        hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0, bool raw = false);
 // kara: the three-product accumulation (k_mac<.., true>, lv->mac_chunk_k)
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false);
+// packed: every job of the launch reads bit-packed plaintexts (MacJob::packed)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false, bool packed = false);
+// dense [slots][L][n] u64 <-> bit-packed [slots][slot_bytes] (rows per DevLevel::mac_bits / mac_row_off of `lv`)
+void launch_pack_rows(const DevLevel *lv, int L, const u64 *dense, void *packed, size_t slot_bytes, size_t n, size_t slots, hipStream_t st);
+void launch_unpack_rows(const DevLevel *lv, int L, const void *packed, size_t slot_bytes, u64 *dense, size_t n, size_t slots, hipStream_t st);
 // Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
 // Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.
 struct EpiJob { const u64 *ct; const u64 *add1; const u64 *add2; const u64 *a0; const u64 *mask; u64 *out; };

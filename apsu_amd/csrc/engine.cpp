@@ -163,6 +163,12 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
+        // BinBundle plaintexts bit-packed in HBM (12.5 % fewer bytes for 56-bit primes, 22 % for 50-bit ones; k_mac<.., PACKED>): in-process
+        // A/B on 16M-4096 -0.146 +- 0.017 ms (-4.2 %) on the whole query, -2.4 % on the N = 8 shard, same bits
+        // (profiles/r04_ab_packed_rows.txt).  Default since round 4; APSU_HE_PACKED_ROWS=0 keeps dense 64-bit words.
+        // Only with key switching (the single-prime paths keep dense rows).
+        if (const char *v = std::getenv("APSU_HE_PACKED_ROWS")) packed_rows_ = std::atoi(v) != 0;
+        if (!hp_.using_keyswitching) packed_rows_ = false;
         if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
     }
     // level constants
@@ -201,6 +207,18 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                     // (r0, r0 + r1) < 2^(sh + 1): one slot as well
                     const u64 capk = 2 * sh + 2 < 64 ? ((u64)1 << (62 - 2 * sh)) : 0;
                     d.mac_chunk_k[j] = (u32)std::min<u64>(capk > 2 ? capk - 1 : 0, 1u << 20);   // 0: not usable for this modulus
+                    // packed row width: the smallest w >= max(bits, 32) whose 2-coefficient group fits a lane's 16-byte window at every
+                    // position: the group starts at bit 2 w m, i.e. (2 w m) mod 32 <= 32 - gcd(2 w, 32) into its first dword
+                    u32 w = 64;                                  // (the geometry is there in every context: images of either format load anywhere)
+                    if (hp_.using_keyswitching)
+                        for (u32 c = (u32)std::max(bits, 32); c < 64; c++) {
+                            u32 g = 2 * c, r = 32;
+                            while (r) { const u32 t2 = g % r; g = r; r = t2; }           // gcd(2 c, 32)
+                            if ((32 - g) + 2 * c <= 128) { w = c; break; }
+                        }
+                    d.mac_bits[j] = w;
+                    d.mac_row_off[j] = j ? d.mac_row_off[j - 1] + (u32)(hp_.n * d.mac_bits[j - 1] / 8) : 0;
+                    d.mac_mask_hi[j] = w == 64 ? 0xffffffffu : (u32)(((u64)1 << (w - sh)) - 1);
                 }
                 d.coeff_div_plain[j] = h.coeff_div_plain[j];
                 d.incr[j] = h.upper_half_incr[j];
@@ -580,7 +598,20 @@ static uint32_t mac_mean_cnt(const std::vector<MacJob> &mj)
 
 // single-stream description of a multiply-accumulate; group_mac() packs streams that share the
 // ciphertext powers and the term count into MacJobs of up to MAC_G streams
-struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0, nl; };
+struct MacStream { const u64 *pt; const u64 *pw; u64 *out; u32 cnt, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0, nl; u32 packed = 0; };
+// where slot `slot` of a BinBundle's NTT-form plaintexts (lifted = false) or of its pre-lifted coefficient-form ones starts, and the
+// distance between consecutive slots in the unit k_mac takes it in (words for dense rows, BYTES for bit-packed ones)
+static const u64 *bundle_slot(const Bundle &b, bool lifted, size_t slot, size_t dense_words)
+{
+    const DevBuf &buf = lifted ? b.lifted : b.ntt;
+    if (!b.packed) return buf.u() + slot * dense_words;
+    return reinterpret_cast<const u64 *>(static_cast<const char *>(buf.p()) + slot * (lifted ? b.lifted_slot_bytes : b.ntt_slot_bytes));
+}
+static u32 bundle_stride(const Bundle &b, bool lifted, size_t dense_words)
+{
+    return b.packed ? (u32)(lifted ? b.lifted_slot_bytes : b.ntt_slot_bytes) : (u32)dense_words;
+}
+static bool mac_packed(const std::vector<MacJob> &mj) { return !mj.empty() && mj[0].packed != 0; }
 static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
 {
     std::vector<MacJob> jobs;
@@ -598,11 +629,11 @@ static std::vector<MacJob> group_mac(const std::vector<MacStream> &ss)
         const MacStream &f = ss[order[x]];
         MacJob j{};
         j.pw = f.pw; j.cnt = f.cnt; j.pt_stride = f.pt_stride; j.pw_stride = f.pw_stride; j.pw_poly_stride = f.pw_poly_stride;
-        j.out_poly_stride = f.out_poly_stride; j.limb0 = f.limb0; j.nl = f.nl;
+        j.out_poly_stride = f.out_poly_stride; j.limb0 = f.limb0; j.nl = f.nl; j.packed = f.packed;
         u32 g = 0;
         while (x < order.size() && g < (u32)MAC_G) {
             const MacStream &s = ss[order[x]];
-            if (s.pw != f.pw || s.cnt != f.cnt || s.pt_stride != f.pt_stride || s.pw_stride != f.pw_stride ||
+            if (s.pw != f.pw || s.cnt != f.cnt || s.packed != f.packed || s.pt_stride != f.pt_stride || s.pw_stride != f.pw_stride ||
                 s.pw_poly_stride != f.pw_poly_stride || s.out_poly_stride != f.out_poly_stride || s.limb0 != f.limb0 || s.nl != f.nl) break;
             j.pt[g] = s.pt; j.out[g] = s.out; g++; x++;
         }
@@ -1029,6 +1060,76 @@ static void bundle_shape(const PSUParams &psu, const HeParams &hp, uint32_t degr
         throw std::invalid_argument("ps_low_degree == 1 leaves coefficient-form plaintexts that eval() cannot multiply");
 }
 
+// bytes of one NTT-form plaintext slot at a level: dense 64-bit words, or bit-packed rows (the same widths as DevLevel::mac_bits)
+size_t Engine::slot_bytes(int chain_idx, bool packed) const
+{
+    const size_t n = hp_.n;
+    if (!packed) return (size_t)(chain_idx + 1) * n * sizeof(u64);
+    size_t b = 0;
+    for (int j = 0; j <= chain_idx; j++) {
+        const int bits = 64 - __builtin_clzll(hp_.key_q[j]);
+        u32 w = 64;
+        for (u32 c = (u32)std::max(bits, 32); c < 64; c++) {
+            u32 g = 2 * c, r = 32;
+            while (r) { const u32 t2 = g % r; g = r; r = t2; }
+            if ((32 - g) + 2 * c <= 128) { w = c; break; }
+        }
+        b += n * w / 8;
+    }
+    return b;
+}
+
+void Engine::pack_bundle(Bundle &b)
+{
+    if (!packed_rows_ || b.packed) return;
+    const size_t n = hp_.n;
+    const int high = hp_.clamp_chain_idx(1);
+    b.ntt_slot_bytes = slot_bytes(b.pt_level, true);
+    b.lifted_slot_bytes = slot_bytes(high, true);
+    const size_t H = b.lifted.bytes() / ((size_t)(high + 1) * n * sizeof(u64));
+    if (b.ntt_count) {
+        DevBuf pk;
+        pk.alloc(b.ntt_count * b.ntt_slot_bytes + 16);
+        HIP_CHECK(hipMemsetAsync(static_cast<char *>(pk.p()) + b.ntt_count * b.ntt_slot_bytes, 0, 16, st_));
+        launch_pack_rows(dlevel(b.pt_level), b.pt_level + 1, b.ntt.u(), pk.p(), b.ntt_slot_bytes, n, b.ntt_count, st_);
+        sync();
+        b.ntt = std::move(pk);
+    }
+    if (H) {
+        DevBuf pk;
+        pk.alloc(H * b.lifted_slot_bytes + 16);
+        HIP_CHECK(hipMemsetAsync(static_cast<char *>(pk.p()) + H * b.lifted_slot_bytes, 0, 16, st_));
+        launch_pack_rows(dlevel(high), high + 1, b.lifted.u(), pk.p(), b.lifted_slot_bytes, n, H, st_);
+        sync();
+        b.lifted = std::move(pk);
+    }
+    b.packed = true;
+}
+
+void Engine::unpack_bundle(Bundle &b)
+{
+    if (!b.packed) return;
+    const size_t n = hp_.n;
+    const int high = hp_.clamp_chain_idx(1);
+    if (b.ntt_count) {
+        DevBuf dn;
+        dn.alloc(b.ntt_count * (size_t)(b.pt_level + 1) * n * sizeof(u64));
+        launch_unpack_rows(dlevel(b.pt_level), b.pt_level + 1, b.ntt.p(), b.ntt_slot_bytes, dn.u(), n, b.ntt_count, st_);
+        sync();
+        b.ntt = std::move(dn);
+    }
+    const size_t H = b.use_ps ? b.H : 0;
+    if (H && b.lifted.bytes()) {
+        DevBuf dn;
+        dn.alloc(H * (size_t)(high + 1) * n * sizeof(u64));
+        launch_unpack_rows(dlevel(high), high + 1, b.lifted.p(), b.lifted_slot_bytes, dn.u(), n, H, st_);
+        sync();
+        b.lifted = std::move(dn);
+    }
+    b.packed = false;
+    b.ntt_slot_bytes = b.lifted_slot_bytes = 0;
+}
+
 std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cache_idx, uint32_t n_coeffs,
                                               const u64 *const *coeff_ptrs, const unsigned char *is_ntt)
 {
@@ -1079,6 +1180,7 @@ std::unique_ptr<Bundle> Engine::upload_bundle(uint32_t bundle_idx, uint32_t cach
             sync();
         });
     }
+    pack_bundle(*b);
     return b;
 }
 
@@ -1498,6 +1600,7 @@ std::unique_ptr<Bundle> Engine::random_bundle(uint32_t bundle_idx, uint32_t cach
         finish_bundle(*b, raw);
         sync();
     });
+    pack_bundle(*b);
     return b;
 }
 
@@ -1542,6 +1645,7 @@ std::unique_ptr<Bundle> Engine::build_bundle(uint32_t bundle_idx, uint32_t cache
         finish_bundle(*b, raw);
         sync();
     });
+    pack_bundle(*b);
     return b;
 }
 
@@ -1573,7 +1677,7 @@ struct ImageHeader {                     // little-endian, 256 bytes
     uint64_t header_bytes, total_bytes;
     uint64_t n, t, K, q[8];
     uint32_t ps_low_degree, max_items_per_bin;
-    uint32_t bundle_idx, cache_idx, degree, use_ps, H, r, pt_level, reserved;
+    uint32_t bundle_idx, cache_idx, degree, use_ps, H, r, pt_level, row_format;   // row_format: 0 dense 64-bit words, 1 bit-packed rows (was `reserved`)
     uint64_t ntt_count, ntt_bytes, lifted_bytes, a0_bytes;
     uint64_t checksum;                   // checksum64 over the payload
     unsigned char pad[256 - 8 - 16 - 88 - 8 - 32 - 32 - 8];
@@ -1620,7 +1724,7 @@ size_t Engine::save_bundle(const Bundle &b, unsigned char *buf, size_t capacity)
     for (int j = 0; j < hp_.K && j < 8; j++) hd.q[j] = hp_.key_q[j];
     hd.ps_low_degree = psu_.query_params.ps_low_degree; hd.max_items_per_bin = psu_.table_params.max_items_per_bin;
     hd.bundle_idx = b.bundle_idx; hd.cache_idx = b.cache_idx; hd.degree = b.degree; hd.use_ps = b.use_ps; hd.H = b.H; hd.r = b.r;
-    hd.pt_level = (uint32_t)b.pt_level; hd.ntt_count = b.ntt_count;
+    hd.pt_level = (uint32_t)b.pt_level; hd.ntt_count = b.ntt_count; hd.row_format = b.packed ? 1 : 0;
     hd.ntt_bytes = b.ntt.bytes(); hd.lifted_bytes = b.lifted.bytes(); hd.a0_bytes = b.a0.bytes();
     unsigned char *p = buf + sizeof(hd);
     if (hd.ntt_bytes) HIP_CHECK(hipMemcpy(p, b.ntt.p(), hd.ntt_bytes, hipMemcpyDeviceToHost));
@@ -1652,9 +1756,14 @@ std::unique_ptr<Bundle> Engine::load_bundle(const unsigned char *buf, size_t siz
     b->bundle_idx = hd.bundle_idx; b->cache_idx = hd.cache_idx;
     bundle_shape(psu_, hp_, hd.degree, *b);                      // re-derive and cross-check the shape
     const size_t n = hp_.n, Lh = hp_.clamp_chain_idx(1) + 1;
+    if (hd.row_format > 1 || (hd.row_format == 1 && !hp_.using_keyswitching)) throw std::invalid_argument("BinBundle image header is inconsistent");
+    const bool img_packed = hd.row_format == 1;
+    const size_t ntt_slot = slot_bytes(b->pt_level, img_packed), lift_slot = slot_bytes(hp_.clamp_chain_idx(1), img_packed);
+    const size_t want_ntt = b->ntt_count ? b->ntt_count * ntt_slot + (img_packed ? 16 : 0) : 0;
+    const size_t want_lift = b->use_ps && b->H ? (size_t)b->H * lift_slot + (img_packed ? 16 : 0) : 0;
+    (void)Lh;
     if (b->H != hd.H || b->r != hd.r || (uint32_t)b->use_ps != hd.use_ps || (uint32_t)b->pt_level != hd.pt_level || b->ntt_count != hd.ntt_count ||
-        hd.ntt_bytes != b->ntt_count * (b->pt_level + 1) * n * sizeof(u64) || hd.a0_bytes != n * sizeof(u64) ||
-        hd.lifted_bytes != (b->use_ps ? (size_t)b->H * Lh * n * sizeof(u64) : 0) || hd.bundle_idx >= psu_.bundle_idx_count)
+        hd.ntt_bytes != want_ntt || hd.a0_bytes != n * sizeof(u64) || hd.lifted_bytes != want_lift || hd.bundle_idx >= psu_.bundle_idx_count)
         throw std::invalid_argument("BinBundle image header is inconsistent");
     const unsigned char *p = buf + sizeof(hd);
     b->ntt.alloc(hd.ntt_bytes); b->lifted.alloc(hd.lifted_bytes); b->a0.alloc(hd.a0_bytes);
@@ -1663,6 +1772,11 @@ std::unique_ptr<Bundle> Engine::load_bundle(const unsigned char *buf, size_t siz
     if (hd.lifted_bytes) HIP_CHECK(hipMemcpy(b->lifted.p(), p, hd.lifted_bytes, hipMemcpyHostToDevice));
     p += hd.lifted_bytes;
     HIP_CHECK(hipMemcpy(b->a0.p(), p, hd.a0_bytes, hipMemcpyHostToDevice));
+    b->packed = img_packed;
+    if (img_packed) { b->ntt_slot_bytes = ntt_slot; b->lifted_slot_bytes = lift_slot; }
+    // an image of the other row format is converted to this context's (APSU_HE_PACKED_ROWS)
+    if (packed_rows_ && !b->packed) pack_bundle(*b);
+    else if (!packed_rows_ && b->packed) unpack_bundle(*b);
     return b;
 }
 
@@ -1685,7 +1799,16 @@ size_t Engine::download_coeff(const Bundle &b, uint32_t d, u64 *out, size_t capa
         src = b.lifted.u() + (size_t)(d / h - 1) * Lh * n; words = Lh * n; k = 2;
     }
     if (capacity < words) throw std::invalid_argument("output buffer too small");
-    HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
+    if (b.packed && k != 0) {                                    // one bit-packed slot -> dense words
+        const int lvl = k == 1 ? b.pt_level : hp_.clamp_chain_idx(1);
+        const size_t sb = k == 1 ? b.ntt_slot_bytes : b.lifted_slot_bytes;
+        const size_t slot = k == 1 ? (size_t)(d - (ps ? d / h : 0) - 1) : (size_t)(d / h - 1);
+        const char *base = static_cast<const char *>(k == 1 ? b.ntt.p() : b.lifted.p());
+        DevBuf tmp(words * sizeof(u64));
+        launch_unpack_rows(dlevel(lvl), lvl + 1, base + slot * sb, sb, tmp.u(), n, 1, st_);
+        sync();
+        HIP_CHECK(hipMemcpy(out, tmp.p(), words * sizeof(u64), hipMemcpyDeviceToHost));
+    } else HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
     if (kind) *kind = k;
     return words;
 }
@@ -1943,12 +2066,13 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 for (int x = 0; x < Bp; x++) {
                     const Bundle &b = *bundles[c0 + pl_ids[x]];
                     u64 *o = acc + (size_t)x * 2 * Lv * n;
-                    if (b.degree) ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
-                                                          (u32)(Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv });   // :140-149
+                    if (b.degree) ms.push_back(MacStream{ bundle_slot(b, false, 0, Lv * n), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
+                                                          bundle_stride(b, false, Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv,
+                                                          (u32)b.packed });   // :140-149
                     else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
                     ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
                 }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj))); }
+                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj)); }
                 d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
                 // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
                 { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
@@ -1981,7 +2105,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     std::vector<int> imap;                              // modulus of every limb polynomial of the merged block
                     const MacJob *mac_jobs = nullptr;
                     int n_mac = 0;
-                    uint64_t units = 0; uint32_t mean_cnt = 0;
+                    uint64_t units = 0; uint32_t mean_cnt = 0; bool mac_is_packed = false;
                 } g;
                 g.ids = ps_ids;
                 std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
@@ -1992,8 +2116,9 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 auto cf_streams = [&](const PsBatch &g, std::vector<MacStream> &out) {
                     for (size_t x = 0; x < g.ids.size(); x++) {
                         const Bundle &b = *bundles[c0 + g.ids[x]];
-                        out.push_back(MacStream{ b.lifted.u(), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H, (u32)(Lh * n),
-                                                 (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh });
+                        out.push_back(MacStream{ bundle_slot(b, true, 0, Lh * n), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H,
+                                                 bundle_stride(b, true, Lh * n), (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh,
+                                                 (u32)b.packed });
                     }
                 };
 
@@ -2030,9 +2155,10 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                         const int bs = bslot[c0 + g.ids[x]];
                         for (int i = 1; i <= g.nin[x]; i++) {
                             const u32 cnt = (u32)i < b.H ? l : b.r;
-                            ms.push_back(MacStream{ b.ntt.u() + (size_t)i * l * Ll * n, low_ptr(1, bs),
+                            ms.push_back(MacStream{ bundle_slot(b, false, (size_t)i * l, Ll * n), low_ptr(1, bs),
                                                     g.inner + ((size_t)g.in_off[x] + i - 1) * 2 * Ll * n, cnt,
-                                                    (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll,
+                                                    (u32)b.packed });
                         }
                     }
                     map_push((size_t)g.NI * 2, 0, (int)Ll);
@@ -2040,8 +2166,9 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     if (i0_fast) {
                         for (int x = 0; x < Bs; x++) {
                             const Bundle &b = *bundles[c0 + g.ids[x]];
-                            ms.push_back(MacStream{ b.ntt.u(), low_ptr(1, bslot[c0 + g.ids[x]]), g.ssum + (size_t)x * 2 * Lh * n, l,
-                                                    (u32)(Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh });
+                            ms.push_back(MacStream{ bundle_slot(b, false, 0, Ll * n), low_ptr(1, bslot[c0 + g.ids[x]]), g.ssum + (size_t)x * 2 * Lh * n, l,
+                                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh,
+                                                    (u32)b.packed });
                         }
                         map_push((size_t)Bs * 2, 0, (int)Lh);
                         if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * 2 * Lh; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
@@ -2052,13 +2179,13 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             const int bs = bslot[c0 + g.ids[x]];
                             for (u32 j = 1; j <= l; j++) {
                                 if (i0_fast)
-                                    ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, (u32)(Ll * n), low_term_stride,
-                                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1 });
+                                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
+                                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
+                                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1, (u32)b.packed });
                                 else
-                                    ms.push_back(MacStream{ b.ntt.u() + (size_t)(j - 1) * Ll * n, low_ptr(j, bs),
-                                                            g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, (u32)(Ll * n), low_term_stride,
-                                                            (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll });
+                                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
+                                                            g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
+                                                            (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll, (u32)b.packed });
                             }
                         }
                         if (i0_fast) {
@@ -2072,6 +2199,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     g.n_mac = (int)mj.size();
                     g.units = mac_units(mj);
                     g.mean_cnt = mac_mean_cnt(mj);
+                    g.mac_is_packed = mac_packed(mj);
                 }
 
                 // ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
@@ -2080,7 +2208,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                     const int Bs = (int)g.ids.size(), NI = g.NI;
                     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
                     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt)); }
+                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
                     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
                     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
@@ -2124,7 +2252,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
                             std::vector<MacStream> cs;
                             cf_streams(g, cs);
-                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)));
+                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj));
                         }
                         std::vector<TensorSumJob> tj;
                         std::vector<FinishSumJob> fj;
@@ -2164,7 +2292,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                             g.cf = ws(w_cf);
                             std::vector<MacStream> cs;
                             cf_streams(g, cs);
-                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj))); }
+                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
                             d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
                         }
                         u64 *dbuf = ws((size_t)NI * 3 * Eh * n);

@@ -59,6 +59,11 @@ struct Bundle {
     DevBuf ntt;                      // [ntt_count][pt_level+1][n]
     DevBuf lifted;                   // PS only: NTT(lift(a_{i*h})) at the high level, i = 1..H : [H][Lh][n]
     DevBuf a0;                       // constant coefficient, n words mod t
+    // Row format of `ntt` and `lifted` (round 4).  false: dense 64-bit words as above.  true: every plaintext is a slot of
+    // ntt_slot_bytes / lifted_slot_bytes bytes whose limb rows are bit-packed (DevLevel::mac_bits: 7 bytes per coefficient of a
+    // 56-bit prime, 6.25 of a 50-bit one); both buffers carry 16 spare bytes behind the last slot (k_mac reads 16-byte windows).
+    bool packed = false;
+    size_t ntt_slot_bytes = 0, lifted_slot_bytes = 0;
     size_t db_bytes() const { return ntt.bytes() + lifted.bytes() + a0.bytes(); }
 };
 
@@ -302,6 +307,10 @@ private:
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
+    bool packed_rows_ = true;         // BinBundle plaintexts are kept bit-packed in HBM (APSU_HE_PACKED_ROWS=0: dense 64-bit words; Bundle::packed)
+    size_t slot_bytes(int chain_idx, bool packed) const;          // bytes of one NTT-form plaintext at a level, either format
+    void pack_bundle(Bundle &b);      // dense -> packed when this context keeps packed rows (no-op otherwise)
+    void unpack_bundle(Bundle &b);    // packed -> dense (images of the other format)
     int mac_kara_ = -1;               // k_mac with three products per term instead of four: -1 by chain length, 0 / 1 forced (APSU_HE_MAC_KARA)
     bool mac_kara(int lvl, uint32_t mean_cnt) const;
     bool gather_nored_ = true;        // gathered forward transforms skip the reduce-on-load where the lazy range allows (ntt_gather_nored_ok)

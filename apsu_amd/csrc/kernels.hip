@@ -1456,10 +1456,16 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // Smid += (a0 + a1)(c0 + c1), the cross sum recovered at fold time as Smid - S00 - S11; the power-side sums c0 + c1 are formed
 // once per term and shared by the G streams.  A middle product has 2s + 2 bits, so a carry-free chunk is half as long
 // (lv->mac_chunk_k) and the carried residue r re-enters as the "term" (a0 c0, mid) = (r mod 2^s, r mod 2^s + (r >> s)).
-template <int G, int C, bool KARA = false>
+// PACKED: the plaintexts are stored bit-packed, limb j at lv->mac_bits[j] bits per coefficient (56-bit primes: 7 bytes instead
+// of 8, 50-bit: 6.25).  A lane still issues ONE 16-byte load per term and stream: its two coefficients occupy 2 * bits
+// consecutive bits from bit 2 * bits * (k / 2) of the row, i.e. inside the 16-byte window that starts at the dword holding that
+// bit (the host picks widths for which shift + 2 * bits <= 128 everywhere); the window is shifted down by the lane's bit offset
+// with funnel shifts and the operand halves are cut out of it.  Fewer HBM bytes per term, the same number of load instructions.
+template <int G, int C, bool KARA = false, bool PACKED = false>
 __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
     static_assert(C == 1 || C == 2, "coefficients per lane");
+    static_assert(!PACKED || C == 2, "packed rows are read two coefficients per lane");
     const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * C;
     if (k >= n) return;
     constexpr int SPLIT = MAC_G / G;                            // a job's streams are covered by SPLIT blocks
@@ -1475,8 +1481,20 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
     const u64 *p0 = job.pw + (size_t)j * n + k;
     const u64 *p1 = p0 + job.pw_poly_stride;
     const u64 *pt[G];
+    const u32 *ptw[G];                                          // PACKED: first dword of this lane's 16-byte window
+    u32 psh = 0, kb = 64, himask = 0xffffffffu;
+    if constexpr (PACKED) {
+        kb = lv->mac_bits[j];
+        himask = lv->mac_mask_hi[j];
+        const u32 bitoff = (u32)(k >> 1) * 2 * kb;
+        psh = bitoff & 31;
 #pragma unroll
-    for (int g = 0; g < G; g++) pt[g] = jp->pt[g0 + g < (int)job.ng ? g0 + g : g0] + (size_t)j * n + k;   // missing streams alias a real one
+        for (int g = 0; g < G; g++)
+            ptw[g] = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(jp->pt[g0 + g < (int)job.ng ? g0 + g : g0]) + lv->mac_row_off[j]) + (bitoff >> 5);
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) pt[g] = jp->pt[g0 + g < (int)job.ng ? g0 + g : g0] + (size_t)j * n + k;   // missing streams alias a real one
+    }
 
     // accumulators [stream][coef][poly]
     u64 s00[G][C][2], sx[G][C][2], s11[G][C][2];
@@ -1494,8 +1512,13 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
             t.c[0][0] = v0[0]; t.c[0][C - 1] = v0[1]; t.c[1][0] = v1[0]; t.c[1][C - 1] = v1[1];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                const u64x2 a = ldg16_nt(pt[g] + (size_t)i * job.pt_stride);
-                t.a[g][0] = a[0]; t.a[g][C - 1] = a[1];
+                if constexpr (PACKED) {
+                    const u32x4a4 w = ldg16_a4_nt(ptw[g] + (size_t)i * (job.pt_stride >> 2));      // pt_stride in bytes
+                    t.a[g][0] = (u64)w[0] | ((u64)w[1] << 32); t.a[g][C - 1] = (u64)w[2] | ((u64)w[3] << 32);
+                } else {
+                    const u64x2 a = ldg16_nt(pt[g] + (size_t)i * job.pt_stride);
+                    t.a[g][0] = a[0]; t.a[g][C - 1] = a[1];
+                }
             }
         } else {
             t.c[0][0] = p0[(size_t)i * job.pw_stride]; t.c[1][0] = p1[(size_t)i * job.pw_stride];
@@ -1517,10 +1540,23 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
                 for (int c = 0; c < C; c++) csum[p][c] = clo[p][c] + chi[p][c];
         }
 #pragma unroll
-        for (int g = 0; g < G; g++)
+        for (int g = 0; g < G; g++) {
+            u64 av[C];
+            if constexpr (PACKED) {
+                // window >> psh, then coefficient 0 = bits [0, kb), coefficient 1 = bits [kb, 2 kb)
+                const u32 w0 = (u32)t.a[g][0], w1 = (u32)(t.a[g][0] >> 32), w2 = (u32)t.a[g][C - 1], w3 = (u32)(t.a[g][C - 1] >> 32);
+                const u32 n0 = __builtin_amdgcn_alignbit(w1, w0, psh), n1 = __builtin_amdgcn_alignbit(w2, w1, psh),
+                          n2 = __builtin_amdgcn_alignbit(w3, w2, psh), n3 = w3 >> psh;
+                const u64 lo64 = (u64)n0 | ((u64)n1 << 32), hi64 = (u64)n2 | ((u64)n3 << 32);
+                av[0] = lo64;
+                av[C - 1] = kb == 64 ? hi64 : ((lo64 >> kb) | (hi64 << (64 - kb)));
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; c++) av[c] = t.a[g][c];
+            }
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                const u32 alo = (u32)t.a[g][c] & lomask, ahi = (u32)(t.a[g][c] >> s);
+                const u32 alo = (u32)av[c] & lomask, ahi = PACKED ? ((u32)(av[c] >> s) & himask) : (u32)(av[c] >> s);
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     s00[g][c][p] += (u64)alo * clo[p][c];
@@ -1532,6 +1568,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
                     s11[g][c][p] += (u64)ahi * chi[p][c];
                 }
             }
+        }
     };
     // recombine S00 + Sx*2^s + S11*2^(2s) (< 2^128) and reduce; the residue re-enters as the next chunk's S00
     auto fold = [&](bool last) {
@@ -1593,7 +1630,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 #ifndef APSU_MAC_C
 #define APSU_MAC_C 2
 #endif
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara, bool packed)
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
@@ -1601,8 +1638,61 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
     //  costs ~0.26 ms more than its chains' length explains, i.e. ~14 us per workgroup; long-lived workgroups that keep the load
     //  pipeline running across chains were 4-9 % SLOWER, starting the first resident generation in phases changed nothing)
     const dim3 grid((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G)));
-    if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+    if (packed) {
+        if constexpr (C == 2) {
+            if (kara) hipLaunchKernelGGL((k_mac<G, C, true, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+            else hipLaunchKernelGGL((k_mac<G, C, false, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+        } else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
+    } else if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
     else hipLaunchKernelGGL((k_mac<G, C, false>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+    KERNEL_CHECK();
+}
+
+// ---- bit-packed database rows: dense u64 limbs <-> rows of mac_bits[j] bits per coefficient (DevLevel)
+// one thread per OUTPUT dword: bits [32 d, 32 d + 32) of the row come from at most two coefficients (widths are >= 32)
+__global__ __launch_bounds__(EW_T) void k_pack_rows(const DevLevel *__restrict__ lv, int L, const u64 *__restrict__ dense, char *__restrict__ packed,
+                                                    size_t slot_bytes, size_t n)
+{
+    const size_t slot = blockIdx.y / L;
+    const int j = (int)(blockIdx.y % L);
+    const u32 w = lv->mac_bits[j];
+    const size_t d = (size_t)blockIdx.x * EW_T + threadIdx.x, ndw = n * w / 32;
+    if (d >= ndw) return;
+    const u64 *src = dense + (slot * L + j) * n;
+    const size_t bit0 = d * 32, c0 = bit0 / w;
+    const u32 off = (u32)(bit0 - c0 * w), got = w - off;
+    u64 v = src[c0] >> off;
+    if (got < 32 && c0 + 1 < n) v |= src[c0 + 1] << got;
+    reinterpret_cast<u32 *>(packed + slot * slot_bytes + lv->mac_row_off[j])[d] = (u32)v;
+}
+// one thread per coefficient (a bit-packed slot is followed by at least 16 readable bytes: the engine pads its buffers)
+__global__ __launch_bounds__(EW_T) void k_unpack_rows(const DevLevel *__restrict__ lv, int L, const char *__restrict__ packed, size_t slot_bytes,
+                                                      u64 *__restrict__ dense, size_t n)
+{
+    const size_t slot = blockIdx.y / L;
+    const int j = (int)(blockIdx.y % L);
+    const size_t c = (size_t)blockIdx.x * EW_T + threadIdx.x;
+    if (c >= n) return;
+    const u32 w = lv->mac_bits[j];
+    const u32 *row = reinterpret_cast<const u32 *>(packed + slot * slot_bytes + lv->mac_row_off[j]);
+    const size_t bit0 = c * w, d0 = bit0 >> 5;
+    const u32 sh = (u32)(bit0 & 31);
+    u64 v = ((u64)row[d0] | ((u64)row[d0 + 1] << 32)) >> sh;
+    if (sh && w + sh > 64) v |= (u64)row[d0 + 2] << (64 - sh);
+    dense[(slot * L + j) * n + c] = w == 64 ? v : (v & (((u64)1 << w) - 1));
+}
+void launch_pack_rows(const DevLevel *lv, int L, const u64 *dense, void *packed, size_t slot_bytes, size_t n, size_t slots, hipStream_t st)
+{
+    if (!slots) return;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((n * 2 + EW_T - 1) / EW_T), (unsigned)(slots * L)), dim3(EW_T), 0, st, lv, L, dense,
+                       static_cast<char *>(packed), slot_bytes, n);
+    KERNEL_CHECK();
+}
+void launch_unpack_rows(const DevLevel *lv, int L, const void *packed, size_t slot_bytes, u64 *dense, size_t n, size_t slots, hipStream_t st)
+{
+    if (!slots) return;
+    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n + EW_T - 1) / EW_T), (unsigned)(slots * L)), dim3(EW_T), 0, st, lv, L,
+                       static_cast<const char *>(packed), slot_bytes, dense, n);
     KERNEL_CHECK();
 }
 

@@ -43,6 +43,21 @@ HD u64x2 ldg16_nt(const u64 *p)
 #endif
 }
 
+// 16 bytes from a 4-byte aligned address (bit-packed database rows): one global_load_dwordx4
+#if defined(__clang__)
+typedef u32 u32x4a4 __attribute__((ext_vector_type(4), __may_alias__, aligned(4)));
+#else
+typedef u32 u32x4a4 __attribute__((vector_size(16), __may_alias__, aligned(4)));
+#endif
+HD u32x4a4 ldg16_a4_nt(const u32 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load((const u32x4a4 __attribute__((address_space(1))) *)(const void *)p);
+#else
+    return *reinterpret_cast<const u32x4a4 *>(p);
+#endif
+}
+
 struct u128p { u64 lo, hi; };   // 128-bit value as a pair
 
 HD u64 mulhi64(u64 a, u64 b)
