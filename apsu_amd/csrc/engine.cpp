@@ -15,6 +15,7 @@
 #include <stdexcept>
 
 namespace apsu_he {
+static uint32_t packed_row_bits(u64 q);   // width of a bit-packed database row (see Engine::mac_units)
 
 void throw_hip(hipError_t e, const char *file, int line)
 {
@@ -209,13 +210,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
                     d.mac_chunk_k[j] = (u32)std::min<u64>(capk > 2 ? capk - 1 : 0, 1u << 20);   // 0: not usable for this modulus
                     // packed row width: the smallest w >= max(bits, 32) whose 2-coefficient group fits a lane's 16-byte window at every
                     // position: the group starts at bit 2 w m, i.e. (2 w m) mod 32 <= 32 - gcd(2 w, 32) into its first dword
-                    u32 w = 64;                                  // (the geometry is there in every context: images of either format load anywhere)
-                    if (hp_.using_keyswitching)
-                        for (u32 c = (u32)std::max(bits, 32); c < 64; c++) {
-                            u32 g = 2 * c, r = 32;
-                            while (r) { const u32 t2 = g % r; g = r; r = t2; }           // gcd(2 c, 32)
-                            if ((32 - g) + 2 * c <= 128) { w = c; break; }
-                        }
+                    // (the geometry is there in every context: images of either format load anywhere)
+                    const u32 w = hp_.using_keyswitching ? packed_row_bits(qj) : 64;
                     d.mac_bits[j] = w;
                     d.mac_row_off[j] = j ? d.mac_row_off[j - 1] + (u32)(hp_.n * d.mac_bits[j - 1] / 8) : 0;
                     d.mac_mask_hi[j] = w == 64 ? 0xffffffffu : (u32)(((u64)1 << (w - sh)) - 1);
@@ -587,7 +583,28 @@ struct ProfScope {
 // element-wise classes: units = ALGORITHMIC bytes of the launch (compulsory operand reads + result writes, 8 bytes per word;
 // level constants and the relinearisation keys -- shared by every coefficient, cache-resident -- not counted)
 #define PROFW(kind, words) ProfScope prof_scope_(this, kind, (uint64_t)(words) * 8)
-static uint64_t mac_units(const std::vector<MacJob> &mj) { uint64_t u = 0; for (auto &j : mj) u += (uint64_t)j.cnt * j.ng * j.nl; return u; }
+// P_MAC's profile unit: BITS of database rows streamed per coefficient index, summed over terms, streams and limbs (64 per limb of
+// a dense row, mac_bits of a bit-packed one) -- bytes streamed = units * n / 8
+static uint32_t packed_row_bits(u64 q)
+{
+    const int bits = 64 - __builtin_clzll(q);
+    for (u32 c = (u32)std::max(bits, 32); c < 64; c++) {
+        u32 g = 2 * c, r = 32;
+        while (r) { const u32 t2 = g % r; g = r; r = t2; }
+        if ((32 - g) + 2 * c <= 128) return c;
+    }
+    return 64;
+}
+uint64_t Engine::mac_units(const std::vector<MacJob> &mj) const
+{
+    uint64_t u = 0;
+    for (auto &j : mj) {
+        uint64_t w = 0;
+        for (u32 l = j.limb0; l < j.limb0 + j.nl; l++) w += j.packed ? packed_row_bits(hp_.key_q[l]) : 64;
+        u += (uint64_t)j.cnt * j.ng * w;
+    }
+    return u;
+}
 // mean number of terms per (stream, limb) chain of a launch: the three-product form pays for long chains only
 static uint32_t mac_mean_cnt(const std::vector<MacJob> &mj)
 {
@@ -1067,13 +1084,7 @@ size_t Engine::slot_bytes(int chain_idx, bool packed) const
     if (!packed) return (size_t)(chain_idx + 1) * n * sizeof(u64);
     size_t b = 0;
     for (int j = 0; j <= chain_idx; j++) {
-        const int bits = 64 - __builtin_clzll(hp_.key_q[j]);
-        u32 w = 64;
-        for (u32 c = (u32)std::max(bits, 32); c < 64; c++) {
-            u32 g = 2 * c, r = 32;
-            while (r) { const u32 t2 = g % r; g = r; r = t2; }
-            if ((32 - g) + 2 * c <= 128) { w = c; break; }
-        }
+        const u32 w = packed_row_bits(hp_.key_q[j]);
         b += n * w / 8;
     }
     return b;

@@ -313,6 +313,7 @@ private:
     void unpack_bundle(Bundle &b);    // packed -> dense (images of the other format)
     int mac_kara_ = -1;               // k_mac with three products per term instead of four: -1 by chain length, 0 / 1 forced (APSU_HE_MAC_KARA)
     bool mac_kara(int lvl, uint32_t mean_cnt) const;
+    uint64_t mac_units(const std::vector<MacJob> &mj) const;      // bits of database rows per coefficient index (profile unit of P_MAC)
     bool gather_nored_ = true;        // gathered forward transforms skip the reduce-on-load where the lazy range allows (ntt_gather_nored_ok)
     size_t eval_ws_budget_ = (size_t)6 << 30;
     bool raw_twist_ = true;           // inverse transforms in front of drop / mod-down kernels leave their twist to those kernels

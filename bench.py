@@ -367,7 +367,8 @@ def main():
             result["roofline"]["untimed_check"] = {"frac": round(u_ach / HBM_PEAK_GBS, 4),
                                                    "avg_launch_us": round(u_ms * 1e3 / max(1, u_l), 2), "launches": u_l}
         mac_ms, _, mac_units = prof_all["dyadic_mac"]
-        mac_bytes = mac_units * n * 8                                   # plaintext bytes streamed from HBM
+        mac_bytes = mac_units * n / 8                                   # database bytes really streamed from HBM (units = bits of rows per
+                                                                        # coefficient index: 56 per limb of a bit-packed 56-bit prime, 64 of a dense row)
         result["kernels_ms_per_step"] = {k: round(v[0] / 2, 4) for k, v in prof_all.items()}
         # element-wise classes: the engine reports the ALGORITHMIC bytes of every launch (compulsory operand reads + result writes;
         # apsu_amd/csrc/engine.cpp PROFW) next to its event time.  Their operands are produced by the kernel in front of them and sit in
@@ -384,8 +385,8 @@ def main():
         mac_gbps = mac_bytes / (mac_ms * 1e-3) / 1e9 if mac_ms > 0 else 0.0
         result["dyadic_mac"] = {"db_GBps": round(mac_gbps, 1), "frac_of_hbm_peak": round(mac_gbps / HBM_PEAK_GBS, 4),
                                 "db_bytes_per_step": int(mac_bytes / 2), "ms_per_step": round(mac_ms / 2, 4),
-                                "note": "k_mac, the one HBM-bound kernel of the path: database bytes streamed per launch / launch time "
-                                        "(HIP events, the two untimed profiling steps)"}
+                                "note": "k_mac, the one HBM-bound kernel of the path: database bytes really streamed per launch (rows are bit-packed since "
+                                        "round 4: 7 bytes per coefficient of a 56-bit prime) / launch time (HIP events, the two untimed profiling steps)"}
 
     # ---- NTT streaming micro-measurement: >= 1 GiB of distinct limbs (HBM, not cache) -----------
     if rank == 0 and not args.no_profile:

@@ -33,7 +33,7 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     p = ctx.profile_read(reset=True)
     ctx.profile_enable(0)
     print("allocation %d: k_mac %.4f ms per query (%.0f GB/s)  first bundle at %#x" %
-          (trial, p["dyadic_mac"][0] / 4, p["dyadic_mac"][2] * n * 8 / (p["dyadic_mac"][0] / 4) / 1e6 / 4, 0), flush=True)
+          (trial, p["dyadic_mac"][0] / 4, p["dyadic_mac"][2] * n / 8 / (p["dyadic_mac"][0] / 4) / 1e6 / 4, 0), flush=True)
     del bl, pw
     gc.collect()
     # perturb the allocator so that the next database does not land on the same pages
