@@ -840,8 +840,10 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
 }
 
 // ============================================================================ tier 1
-#define H2D(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyHostToDevice, st_))
-#define D2H(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyDeviceToHost, st_))
+// Tier-1 operands are host pointers by default; with apsu_he_set_tier1_on_device they are device (or page-locked) memory and the
+// calls only queue their work -- unified addressing lets one copy kind serve both
+#define H2D(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), tier1_device_ ? hipMemcpyDefault : hipMemcpyHostToDevice, st_))
+#define D2H(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), tier1_device_ ? hipMemcpyDefault : hipMemcpyDeviceToHost, st_))
 #define D2D(dst, src, words) HIP_CHECK(hipMemcpyAsync(dst, src, (words) * sizeof(u64), hipMemcpyDeviceToDevice, st_))
 
 void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
@@ -855,7 +857,7 @@ void Engine::transform_to_ntt(u64 *ct, int polys, int chain_idx)
         H2D(d, ct, w);
         d_ntt_ct(d, polys, chain_idx, false);
         D2H(ct, d, w);
-        sync();
+        tier1_done();
     });
 }
 
@@ -870,7 +872,7 @@ void Engine::transform_from_ntt(u64 *ct, int polys, int chain_idx)
         H2D(d, ct, w);
         d_ntt_ct(d, polys, chain_idx, true);
         D2H(ct, d, w);
-        sync();
+        tier1_done();
     });
 }
 
@@ -886,7 +888,7 @@ void Engine::multiply_plain_ntt(const u64 *ct, const u64 *pt_ntt, u64 *out, int 
         H2D(p, pt_ntt, L * n);
         launch_dyadic_plain(dlevel(chain_idx), d, p, o, polys, n, 1, 0, st_);
         D2H(out, o, w);
-        sync();
+        tier1_done();
     });
 }
 
@@ -911,7 +913,7 @@ void Engine::transform_plain_to_ntt(const u64 *pt, size_t pt_coeffs, u64 *out, i
         launch_lift(dlevel(chain_idx), p, o, n, 1, nullptr, st_);
         d_ntt_ct(o, 1, chain_idx, false);
         D2H(out, o, L * n);
-        sync();
+        tier1_done();
     });
 }
 
@@ -924,20 +926,21 @@ void Engine::multiply_plain(const u64 *ct, const u64 *pt, size_t pt_coeffs, u64 
     check_level(chain_idx);
     const size_t n = hp_.n, L = chain_idx + 1, w = polys * L * n;
     if (pt_coeffs > n) throw std::invalid_argument("plaintext has too many coefficients");
-    const unsigned char mono = is_monomial(pt, pt_coeffs) ? 1 : 0;
+    const unsigned char mono = !tier1_device_ && is_monomial(pt, pt_coeffs) ? 1 : 0;      // (device operands: flagged by a kernel below)
     WITH_ARENA({
         u64 *d = ws(w), *p = ws(n), *pl = ws(L * n), *o = ws(w), *flag = ws(1);
         H2D(d, ct, w);
         HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(u64), st_));
         H2D(p, pt, pt_coeffs);
-        HIP_CHECK(hipMemcpyAsync(flag, &mono, 1, hipMemcpyHostToDevice, st_));
+        if (tier1_device_) launch_flag_monomial(p, n, 1, reinterpret_cast<unsigned char *>(flag), st_);
+        else HIP_CHECK(hipMemcpyAsync(flag, &mono, 1, hipMemcpyHostToDevice, st_));
         launch_lift(dlevel(chain_idx), p, pl, n, 1, reinterpret_cast<const unsigned char *>(flag), st_);
         d_ntt_ct(pl, 1, chain_idx, false);
         d_ntt_ct(d, polys, chain_idx, false);
         launch_dyadic_plain(dlevel(chain_idx), d, pl, o, polys, n, 1, 0, st_);
         d_ntt_ct(o, polys, chain_idx, true);
         D2H(out, o, w);
-        sync();
+        tier1_done();
     });
 }
 
@@ -953,7 +956,7 @@ void Engine::add(u64 *acc, const u64 *x, int polys, int chain_idx)
         H2D(b, x, w);
         launch_add(dlevel(chain_idx), a, b, polys, hp_.n, 1, st_);
         D2H(acc, a, w);
-        sync();
+        tier1_done();
     });
 }
 
@@ -972,7 +975,7 @@ void Engine::add_plain(u64 *ct, const u64 *pt, size_t pt_coeffs, int chain_idx)
         std::vector<PlainJob> jobs{ PlainJob{ c0, p } };
         { PROF(P_OTHER, 0); launch_add_plain(dlevel(chain_idx), upload_jobs(jobs), n, 1, st_); }
         D2H(ct, c0, L * n);
-        sync();
+        tier1_done();
     });
 }
 
@@ -999,7 +1002,7 @@ void Engine::multiply(const u64 *a, const u64 *b, u64 *out3, int chain_idx)
         std::vector<FinishJob> fj{ FinishJob{ d, o, 1, 0 } };
         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(chain_idx), hlevel(chain_idx).L, hlevel(chain_idx).nB, upload_jobs(fj), false, n, 1, st_); }
         D2H(out3, o, 3 * L * n);
-        sync();
+        tier1_done();
     });
 }
 
@@ -1015,7 +1018,7 @@ void Engine::relinearize(u64 *ct3, const RelinKeys &rk, int chain_idx)
         H2D(d, ct3, 3 * L * n);
         d_relinearize(d, 3 * L * n, 1, rk, chain_idx);
         D2H(ct3, d, 2 * L * n);
-        sync();
+        tier1_done();
     });
 }
 
@@ -1031,7 +1034,7 @@ void Engine::mod_switch_to_next(u64 *ct, int polys, int chain_idx)
         H2D(d, ct, polys * L * n);
         { PROF(P_MODSWITCH, 0); launch_modswitch(dlevel(chain_idx), d, polys * L * n, polys, o, n, 1, st_); }
         D2H(ct, o, polys * (L - 1) * n);
-        sync();
+        tier1_done();
     });
 }
 
@@ -1045,7 +1048,7 @@ void Engine::clear_irrelevant_bits(u64 *ct, int polys)
         H2D(d, ct, w);
         launch_clear_bits(d, w, hp_.irrelevant_bit_count, st_);
         D2H(ct, d, w);
-        sync();
+        tier1_done();
     });
 }
 

@@ -192,6 +192,9 @@ public:
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
     // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
     void set_async_results(bool on) { std::lock_guard<std::mutex> g(mu_); async_results_ = on; }
+    // tier 1 on device-resident operands: the per-method calls take device pointers and return with their work queued on the
+    // engine's stream (no host round trip per Evaluator call); see apsu_he_set_tier1_on_device
+    void set_tier1_on_device(bool on) { std::lock_guard<std::mutex> g(mu_); tier1_device_ = on; }
     void wait();                                                  // locked sync()
     // test hook: copy one computed power to the host (serialised with the other calls on this context)
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
@@ -307,6 +310,8 @@ private:
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
+    bool tier1_device_ = false;       // tier-1 operands are device memory and calls do not synchronise
+    void tier1_done() { if (!tier1_device_ || prof_on_) sync(); }
     bool packed_rows_ = true;         // BinBundle plaintexts are kept bit-packed in HBM (APSU_HE_PACKED_ROWS=0: dense 64-bit words; Bundle::packed)
     size_t slot_bytes(int chain_idx, bool packed) const;          // bytes of one NTT-form plaintext at a level, either format
     void pack_bundle(Bundle &b);      // dense -> packed when this context keeps packed rows (no-op otherwise)

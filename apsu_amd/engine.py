@@ -410,6 +410,10 @@ class HeContext:
         """eval_bundles with device-resident masks and output returns once its work is queued; see sync() / stream"""
         _check(load_library().apsu_he_set_async_results(self.h, int(bool(on))))
 
+    def set_tier1_on_device(self, on):
+        """tier-1 calls take device pointers (ints) and only queue their work; see sync() / stream"""
+        _check(load_library().apsu_he_set_tier1_on_device(self.h, int(bool(on))))
+
     def sync(self):
         """wait for everything this context has queued"""
         _check(load_library().apsu_he_sync(self.h))

@@ -76,8 +76,10 @@ const char *apsu_he_last_error(void);
  * in one mmap-able file); apsu_he_seal_pt_load / _save, apsu_he_db_upload_bundle_serialized (BinBundle caches as the reference stores
  * them), apsu_he_db_upload_saved_bundle (a BinBundle as ReceiverDB::save wrote it); zstd bodies in the SEAL codec;
  * apsu_he_multi_run_query_request, apsu_he_multi_result_polys; the parameter exchange, plainResponse, PSUParams in binary form and
- * the header of a saved ReceiverDB (apsu_he_wire_peek_type ... apsu_he_wire_receiver_db_header). */
-#define APSU_HE_ABI_VERSION 4   /* what this header describes; compare with apsu_he_abi_version() of the loaded library */
+ * the header of a saved ReceiverDB (apsu_he_wire_peek_type ... apsu_he_wire_receiver_db_header).
+ * 5 (additive): apsu_he_set_tier1_on_device (tier-1 calls on device-resident operands without a host round trip per call);
+ * BinBundle images and DB files carry a row format (bit-packed database rows, the default, or dense words) and load into either. */
+#define APSU_HE_ABI_VERSION 5   /* what this header describes; compare with apsu_he_abi_version() of the loaded library */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -320,6 +322,13 @@ int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
  * stay alive and unmodified until then.  Host-memory arguments always synchronise, as does event profiling.
  * Default off (APSU_HE_ASYNC=1 turns it on for contexts that never call this). */
 int apsu_he_set_async_results(apsu_he_ctx *ctx, int on);
+/* Tier 1 on device-resident operands (ABI 5): with on != 0 every pointer argument of the tier-1 calls (apsu_he_transform_to_ntt ...
+ * apsu_he_clear_irrelevant_bits; relinearisation keys stay handles) is DEVICE memory -- or page-locked host memory, which the device
+ * addresses -- and the calls return with their work queued on the context's stream instead of copying in, waiting and copying out:
+ * a caller that replaces Evaluator methods one by one (receiver_osn.cpp:422-478, bin_bundle.cpp:143-170) keeps its ciphertexts in
+ * HBM across calls and pays no host round trip per method.  Ordering and completion as for apsu_he_set_async_results:
+ * calls on one context execute in call order; apsu_he_sync / apsu_he_stream give the completion point.  Default off. */
+int apsu_he_set_tier1_on_device(apsu_he_ctx *ctx, int on);
 int apsu_he_sync(apsu_he_ctx *ctx);
 int apsu_he_stream(apsu_he_ctx *ctx, void **hip_stream);
 
