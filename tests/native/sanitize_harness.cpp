@@ -100,6 +100,17 @@ int main(int argc, char **argv)
             if (sealio::load_ciphertext(sbuf2.data(), sbuf2.size(), chain).data != sc.data) return 13;
             rej += fuzz(sbuf2, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 8000);
         }
+        {   // a seeded ciphertext under SEAL's Shake256 generator: expanded by the host codec in both load modes
+            sealio::Ciphertext sh = ct;
+            sh.seeded = true; sh.prng_type = sealio::PRNG_SHAKE256;
+            for (int i = 0; i < 8; i++) sh.seed[i] = rnd();
+            sealio::sample_poly_uniform(sh.seed, chain[1].q.data(), 2, 64, sh.data.data() + 128, sealio::PRNG_SHAKE256);
+            const std::vector<uint8_t> hb = sealio::save_ciphertext(sh, sealio::COMPR_ZLIB);
+            if (sealio::load_ciphertext(hb.data(), hb.size(), chain).data != sh.data) return 21;
+            const sealio::Ciphertext un = sealio::load_ciphertext(hb.data(), hb.size(), chain, nullptr, false);
+            if (un.seeded || un.data != sh.data) return 22;
+            rej += fuzz(hb, [&](const uint8_t *p, size_t n) { (void)sealio::load_ciphertext(p, n, chain); }, 2000);
+        }
         {   // forged dimensions: (a) a tiny object that claims 64 x 64 x 2^20 words must allocate nothing; (b) a level's parms_id with
             // another coeff_modulus_size is refused with and without seed expansion
             sealio::Ciphertext big = ct;
