@@ -1456,16 +1456,32 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
 // Smid += (a0 + a1)(c0 + c1), the cross sum recovered at fold time as Smid - S00 - S11; the power-side sums c0 + c1 are formed
 // once per term and shared by the G streams.  A middle product has 2s + 2 bits, so a carry-free chunk is half as long
 // (lv->mac_chunk_k) and the carried residue r re-enters as the "term" (a0 c0, mid) = (r mod 2^s, r mod 2^s + (r >> s)).
+#ifdef APSU_MAC_STAMPS
+// diagnostic build of tools/microbench/macbench.hip only: where a k_mac workgroup's lifetime goes (shader-clock stamps of lane 0 of
+// wave 0: entry | descriptor and pointers read | first term consumed | last pair consumed | folded | stored; realtime at entry and exit)
+__device__ unsigned long long *g_mac_stamps = nullptr;
+#define MAC_STAMP(i) do { if (g_mac_stamps && threadIdx.x == 0) { asm volatile("" ::: "memory"); stamp_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } while (0)
+#else
+#define MAC_STAMP(i) do { } while (0)
+#endif
 // PACKED: the plaintexts are stored bit-packed, limb j at lv->mac_bits[j] bits per coefficient (56-bit primes: 7 bytes instead
 // of 8, 50-bit: 6.25).  A lane still issues ONE 16-byte load per term and stream: its two coefficients occupy 2 * bits
 // consecutive bits from bit 2 * bits * (k / 2) of the row, i.e. inside the 16-byte window that starts at the dword holding that
 // bit (the host picks widths for which shift + 2 * bits <= 128 everywhere); the window is shifted down by the lane's bit offset
 // with funnel shifts and the operand halves are cut out of it.  Fewer HBM bytes per term, the same number of load instructions.
+#ifndef APSU_MAC_MINWAVES
+#define APSU_MAC_MINWAVES 1                                        // waves per SIMD the register allocation must allow (experiment switch)
+#endif
 template <int G, int C, bool KARA = false, bool PACKED = false>
-__global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
+__global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
 {
     static_assert(C == 1 || C == 2, "coefficients per lane");
     static_assert(!PACKED || C == 2, "packed rows are read two coefficients per lane");
+#ifdef APSU_MAC_STAMPS
+    unsigned long long stamp_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    MAC_STAMP(0);
     const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * C;
     if (k >= n) return;
     constexpr int SPLIT = MAC_G / G;                            // a job's streams are covered by SPLIT blocks
@@ -1591,6 +1607,7 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
 
     const u32 cnt = job.cnt;
     Term A, B;                                                   // ping-pong register sets: no copies
+    MAC_STAMP(1);
     load_term(0, A);
     u32 in_chunk = 0;
     const u32 npairs = cnt >> 1;
@@ -1598,13 +1615,18 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
         const u32 i = pr * 2;
         load_term(i + 1, B);
         mac_term(A);
+#ifdef APSU_MAC_STAMPS
+        if (pr == 0) MAC_STAMP(2);
+#endif
         load_term(i + 2 < cnt ? i + 2 : cnt - 1, A);             // clamped prefetch (a re-read hits the cache)
         mac_term(B);
         in_chunk += 2;
         if (in_chunk + 3 > chunk) { fold(false); in_chunk = 1; } // the folded residue counts as one term
     }
     if (cnt & 1) mac_term(A);                                    // A holds the last term
+    MAC_STAMP(3);
     fold(true);
+    MAC_STAMP(4);
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {
@@ -1621,8 +1643,17 @@ __global__ __launch_bounds__(EW_T) void k_mac(const DevLevel *__restrict__ lv, c
             }
         }
     }
+#ifdef APSU_MAC_STAMPS
+    if (g_mac_stamps && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);                           // the stores have left
+        MAC_STAMP(5);
+        const size_t lin = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        unsigned long long *o = g_mac_stamps + lin * 8;
+        for (int i = 0; i < 6; i++) o[i] = stamp_[i];
+        o[6] = rt0_; o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
-
 
 #ifndef APSU_MAC_G
 #define APSU_MAC_G 4

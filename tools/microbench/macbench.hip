@@ -90,6 +90,37 @@ int main(int argc, char** argv) {
         printf("k_mac<%d,%d> ring=%d nb=%d pad=%zu: min %.3f ms (%.0f GB/s)  median %.3f ms (%.0f GB/s)  max %.3f\n", APSU_MAC_G, APSU_MAC_C, 2, nb, pad,
                t[0], words * 8 / (t[0] * 1e-3) / 1e9, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9, t.back());
     }
+#ifdef APSU_MAC_STAMPS
+    if (getenv("STAMPS")) {
+        // build with -DAPSU_MAC_STAMPS: the per-workgroup timeline of k_mac (in-kernel shader-clock stamps of lane 0)
+        const size_t nwg = (size_t)16 * 3 * jobs.size();
+        unsigned long long *dst; CHECK(hipMalloc(&dst, nwg * 8 * sizeof(unsigned long long))); CHECK(hipMemset(dst, 0, nwg * 8 * sizeof(unsigned long long)));
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(apsu_he::g_mac_stamps), &dst, sizeof(dst)));
+        for (int rep = 0; rep < 3; rep++) { launch_mac(lv, 3, dj, n, (int)jobs.size(), 0); CHECK(hipDeviceSynchronize()); }
+        std::vector<unsigned long long> h(nwg * 8);
+        CHECK(hipMemcpy(h.data(), dst, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long *nul = nullptr; CHECK(hipMemcpyToSymbol(HIP_SYMBOL(apsu_he::g_mac_stamps), &nul, sizeof(nul)));
+        const char *names[5] = { "setup (descriptor, pointers)", "first term arrives + consumed", "steady loop", "fold", "store + drain" };
+        std::vector<double> ph[5], life, start;
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < nwg; w++) if (h[w * 8 + 6] && h[w * 8 + 6] < t0) t0 = h[w * 8 + 6];
+        for (size_t w = 0; w < nwg; w++) {
+            const unsigned long long *s2 = &h[w * 8];
+            if (!s2[5]) continue;
+            for (int i = 0; i < 5; i++) ph[i].push_back((double)(s2[i + 1] - s2[i]));
+            life.push_back((double)(s2[7] - s2[6]) / 100.0);     // us (100 MHz)
+            start.push_back((double)(s2[6] - t0) / 100.0);
+        }
+        auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+        auto p90 = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() * 9 / 10]; };
+        double tot = 0; for (int i = 0; i < 5; i++) tot += med(ph[i]);
+        printf("workgroups stamped: %zu of %zu; median lifetime %.1f us (p90 %.1f); last start at %.1f us\n", life.size(), nwg, med(life), p90(life), *std::max_element(start.begin(), start.end()));
+        for (int i = 0; i < 5; i++) printf("  %-32s median %9.0f cycles (%4.1f %%)   p90 %9.0f\n", names[i], med(ph[i]), 100 * med(ph[i]) / tot, p90(ph[i]));
+        std::vector<int> hist(100, 0);
+        for (double st2 : start) { size_t b = (size_t)(st2 / 20.0); if (b < hist.size()) hist[b]++; }
+        printf("  starts per 20 us:"); for (size_t b = 0; b < hist.size() && b < 80; b++) printf(" %d", hist[b]); printf("\n");
+    }
+#endif
     if (getenv("PERSIST")) {
         // long-lived workgroups (k_mac_p) against one workgroup per unit (k_mac): separate output, bit-compared; A B A B timing
         u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
