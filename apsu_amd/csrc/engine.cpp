@@ -1988,6 +1988,377 @@ void Engine::decrypt_decode(const u64 *sk_ntt_host, const u64 *cts, bool on_devi
 }
 
 // ============================================================================ tier 2: BinBundle evaluation
+// ---- the evaluation of one chunk of BinBundles, in pieces (eval_bundles below is the driver) ------------------------------
+// What the pieces share: the call's arguments, the levels, the placement of the powers and the chunk's result / mask rows.
+struct Engine::EvalCall {
+    const Bundle *const *bundles; const Powers &pw; const RelinKeys *rk;
+    const u64 *const *masks; bool masks_on_device; u64 *const *out_rows;
+    size_t n; uint32_t l; int high, low; size_t Ll, Lh, Eh; u32 low_term_stride;
+    std::vector<int> bslot;                                  // powers slot of every BinBundle of the call
+    int c0 = 0;                                              // first BinBundle of the chunk being evaluated
+    u64 *res = nullptr, *mask_d = nullptr;                   // the chunk's result rows / staged masks (when they are not the caller's)
+    // powers are stored bundle-index major ([idx][power][2][L][n]): one index's powers are contiguous
+    const u64 *low_ptr(uint32_t power, int b) const { return pw.low.u() + (((size_t)b * pw.n_low + (power - 1)) * 2) * Ll * n; }
+    const u64 *hext_ptr(uint32_t i, int b) const { return pw.hext.u() + (((size_t)b * pw.n_high + (i - 1)) * 2) * Eh * n; }
+    u64 *res_ptr(int i) const { return out_rows ? out_rows[c0 + i] : res + (size_t)i * 2 * n; }
+    const u64 *mask_ptr(int i) const { return masks_on_device ? masks[c0 + i] : mask_d + (size_t)i * n; }
+};
+// which forms of the Paterson-Stockmeyer steps this call takes (decided once per chunk in eval_patstock)
+struct Engine::PsPlan { bool i0_fast, need_vlast, raw_drop, raw_i0, async_high, late_high; };
+
+// One batch: every Paterson-Stockmeyer BinBundle of the chunk, ordered by bundle index (the shared powers of
+// one index then stay in the same L2).  (Cutting the batch into groups whose database scans overlap the previous
+// group's VALU-bound tail on a second stream was built and measured in rounds 2 and 3, also with an LDS-DMA
+// multiply-accumulate that leaves room for an NTT workgroup per CU: slower to level, the chip is power-bound.
+// profiles/r03_eval_pipeline.txt; the code is in git history at 22dbbd1, engine.cpp:1600-1745.)
+struct PsBatch {
+    std::vector<int> ids;                               // positions in this chunk
+    std::vector<int> nin, in_off;                       // inner polynomials per BinBundle, prefix offsets
+    int NI = 0;
+    u64 *inner = nullptr, *ssum = nullptr, *vlast = nullptr, *term = nullptr, *cf = nullptr;
+    std::vector<int> imap;                              // modulus of every limb polynomial of the merged block
+    const MacJob *mac_jobs = nullptr;
+    int n_mac = 0;
+    uint64_t units = 0; uint32_t mean_cnt = 0; bool mac_is_packed = false;
+};
+
+// BatchedPlaintextPolyn::eval (bin_bundle.cpp:106-174) for the BinBundles pl_ids of the chunk
+void Engine::eval_plain(EvalCall &c, const std::vector<int> &pl_ids)
+{
+    const size_t n = c.n, Ll = c.Ll;
+    const int low = c.low, c0 = c.c0;
+    const Bundle *const *bundles = c.bundles;
+    const std::vector<int> &bslot = c.bslot;
+    const u32 low_term_stride = c.low_term_stride;
+    auto low_ptr = [&](uint32_t power, int b) { return c.low_ptr(power, b); };
+    auto res_ptr = [&](int i) { return c.res_ptr(i); };
+    auto mask_ptr = [&](int i) { return c.mask_ptr(i); };
+    const int Bp = (int)pl_ids.size();
+    const int lvl = low;                                   // level of powers[1]
+    const size_t Lv = lvl + 1;
+    u64 *acc = ws((size_t)Bp * 2 * Lv * n);
+    std::vector<MacStream> ms;
+    std::vector<EpiJob> ej;
+    for (int x = 0; x < Bp; x++) {
+        const Bundle &b = *bundles[c0 + pl_ids[x]];
+        u64 *o = acc + (size_t)x * 2 * Lv * n;
+        if (b.degree) ms.push_back(MacStream{ bundle_slot(b, false, 0, Lv * n), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
+                                              bundle_stride(b, false, Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv,
+                                              (u32)b.packed });   // :140-149
+        else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
+        ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
+    }
+    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj)); }
+    d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
+    // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
+    { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
+}
+
+// the sums of the pre-lifted coefficient-form plaintexts, sum_i lift(a_{i*h}) (.) C^{i*h} (bin_bundle.cpp:328-337), as MAC streams
+void Engine::ps_cf_streams(const EvalCall &c, const PsBatch &g, std::vector<MacStream> &out)
+{
+    const size_t n = c.n, Lh = c.Lh, Eh = c.Eh;
+    const int c0 = c.c0;
+    const Bundle *const *bundles = c.bundles;
+    const std::vector<int> &bslot = c.bslot;
+    auto hext_ptr = [&](uint32_t i, int b) { return c.hext_ptr(i, b); };
+    for (size_t x = 0; x < g.ids.size(); x++) {
+        const Bundle &b = *bundles[c0 + g.ids[x]];
+        out.push_back(MacStream{ bundle_slot(b, true, 0, Lh * n), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H,
+                                 bundle_stride(b, true, Lh * n), (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh,
+                                 (u32)b.packed });
+    }
+}
+
+// BatchedPlaintextPolyn::eval_patstock (bin_bundle.cpp:192-360) for the BinBundles ps_ids of the chunk: the plan, the batch, its
+// job tables (ps_tables) and the launch sequence (ps_run)
+void Engine::eval_patstock(EvalCall &c, const std::vector<int> &ps_ids)
+{
+    const size_t Ll = c.Ll;
+    const uint32_t l = c.l;
+    const int high = c.high, low = c.low, c0 = c.c0;
+    const Powers &pw = c.pw;
+    const std::vector<int> &bslot = c.bslot;
+    // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
+    // the sum (note N1).  With one dropped limb the sum of the rounded terms is
+    //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
+    // where the first sum is exact and may be taken in the NTT domain.  So only the LAST limb of each term
+    // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
+    const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
+    const bool need_vlast = i0_fast && low > high;
+    // RAW inverse transforms (no twist, no final reduction) where the consumer's own constants absorb the twist:
+    // the inner polynomials when the fused drop + extension kernel takes them, the i = 0 block's sums and last limbs
+    const bool raw_drop = raw_twist_ && low == high + 1 && hlevel(high).L == hlevel(high).nB && hlevel(high).L <= 3;
+    const bool raw_i0 = raw_twist_ && need_vlast;
+    PsBatch g;
+    g.ids = ps_ids;
+    std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
+    // high powers still in flight on the second stream (split ComputePowers): everything that needs only the low
+    // powers goes first, the cf products (which read the high powers) come later
+    const bool async_high = pw.high_async && pw.high_ready;
+    const bool late_high = async_high;
+    const PsPlan plan{ i0_fast, need_vlast, raw_drop, raw_i0, async_high, late_high };
+    ps_tables(c, plan, g);
+    ps_run(c, plan, g);
+}
+
+// phase A: workspace and the job array of the multiply-accumulate
+void Engine::ps_tables(EvalCall &c, const PsPlan &plan, PsBatch &g)
+{
+    const size_t n = c.n, Ll = c.Ll, Lh = c.Lh;
+    const uint32_t l = c.l;
+    const int c0 = c.c0;
+    const Bundle *const *bundles = c.bundles;
+    const std::vector<int> &bslot = c.bslot;
+    const u32 low_term_stride = c.low_term_stride;
+    auto low_ptr = [&](uint32_t power, int b) { return c.low_ptr(power, b); };
+    const bool i0_fast = plan.i0_fast, need_vlast = plan.need_vlast, raw_drop = plan.raw_drop, raw_i0 = plan.raw_i0;
+    const bool late_high = plan.late_high;
+    const int Bs = (int)g.ids.size();
+    // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
+    g.nin.resize(Bs); g.in_off.resize(Bs);
+    for (int x = 0; x < Bs; x++) {
+        const Bundle &b = *bundles[c0 + g.ids[x]];
+        g.nin[x] = (int)b.H - (b.r == 0 ? 1 : 0);
+        g.in_off[x] = g.NI;
+        g.NI += g.nin[x];
+    }
+    // Every dyadic multiply-accumulate of the evaluation reads only the query powers and the database, so
+    // all of a group run as ONE launch, and their results share ONE inverse-NTT launch:
+    //   inner [NI][2][Ll]   sum_j C^j (.) a_{i*h+j}                                  :258-264
+    //   ssum  [Bs][2][Lh]   sum_j C^j (.) a_j on the limbs that survive the switch  (i = 0 block, fast form)
+    //   vlast [Bs*l][2][1]  C^j (.) a_j on the dropped limb, per term               (i = 0 block, fast form)
+    //   term  [Bs*l][2][Ll] C^j (.) a_j, per term                                   (i = 0 block, general form)
+    //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
+    const size_t w_inner = (size_t)g.NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
+    const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
+    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
+    g.inner = ws(w_inner + w_ssum + w_vlast + w_term + (late_high ? 0 : w_cf));
+    g.ssum = g.inner + w_inner; g.vlast = g.ssum + w_ssum; g.term = g.vlast + w_vlast;
+    g.cf = late_high ? nullptr : g.term + w_term;
+    std::vector<MacStream> ms;
+    auto map_push = [&](size_t polys, int first_limb, int limbs) {
+        for (size_t p = 0; p < polys; p++) for (int j = 0; j < limbs; j++) g.imap.push_back(first_limb + j);
+    };
+    for (int x = 0; x < Bs; x++) {
+        const Bundle &b = *bundles[c0 + g.ids[x]];
+        const int bs = bslot[c0 + g.ids[x]];
+        for (int i = 1; i <= g.nin[x]; i++) {
+            const u32 cnt = (u32)i < b.H ? l : b.r;
+            ms.push_back(MacStream{ bundle_slot(b, false, (size_t)i * l, Ll * n), low_ptr(1, bs),
+                                    g.inner + ((size_t)g.in_off[x] + i - 1) * 2 * Ll * n, cnt,
+                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll,
+                                    (u32)b.packed });
+        }
+    }
+    map_push((size_t)g.NI * 2, 0, (int)Ll);
+    if (raw_drop) for (int &v : g.imap) v |= NTT_MAP_RAW;          // consumed by the fused drop + extension only
+    if (i0_fast) {
+        for (int x = 0; x < Bs; x++) {
+            const Bundle &b = *bundles[c0 + g.ids[x]];
+            ms.push_back(MacStream{ bundle_slot(b, false, 0, Ll * n), low_ptr(1, bslot[c0 + g.ids[x]]), g.ssum + (size_t)x * 2 * Lh * n, l,
+                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh,
+                                    (u32)b.packed });
+        }
+        map_push((size_t)Bs * 2, 0, (int)Lh);
+        if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * 2 * Lh; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
+    }
+    if (need_vlast || !i0_fast) {
+        for (int x = 0; x < Bs; x++) {
+            const Bundle &b = *bundles[c0 + g.ids[x]];
+            const int bs = bslot[c0 + g.ids[x]];
+            for (u32 j = 1; j <= l; j++) {
+                if (i0_fast)
+                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
+                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
+                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1, (u32)b.packed });
+                else
+                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
+                                            g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
+                                            (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll, (u32)b.packed });
+            }
+        }
+        if (i0_fast) {
+            map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
+            if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * l * 2; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
+        } else map_push((size_t)Bs * l * 2, 0, (int)Ll);
+    }
+    if (!late_high) { ps_cf_streams(c, g, ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
+    auto mj = group_mac(ms);
+    g.mac_jobs = upload_jobs(mj);
+    g.n_mac = (int)mj.size();
+    g.units = mac_units(mj);
+    g.mean_cnt = mac_mean_cnt(mj);
+    g.mac_is_packed = mac_packed(mj);
+}
+
+// ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
+// primes) and everything behind it
+void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
+{
+    const size_t n = c.n, Ll = c.Ll, Lh = c.Lh, Eh = c.Eh;
+    const uint32_t l = c.l;
+    const int high = c.high, low = c.low, c0 = c.c0;
+    const Powers &pw = c.pw;
+    const Bundle *const *bundles = c.bundles;
+    const std::vector<int> &bslot = c.bslot;
+    auto hext_ptr = [&](uint32_t i, int b) { return c.hext_ptr(i, b); };
+    auto res_ptr = [&](int i) { return c.res_ptr(i); };
+    auto mask_ptr = [&](int i) { return c.mask_ptr(i); };
+    const bool i0_fast = plan.i0_fast, raw_drop = plan.raw_drop, raw_i0 = plan.raw_i0;
+    const bool async_high = plan.async_high, late_high = plan.late_high;
+    auto cf_streams = [&](const PsBatch &gg, std::vector<MacStream> &out) { ps_cf_streams(c, gg, out); };
+    const RelinKeys *rk = c.rk;
+    const int Bs = (int)g.ids.size(), NI = g.NI;
+    const std::vector<int> &nin = g.nin, &in_off = g.in_off;
+    u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
+    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
+    d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
+
+    // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
+    // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
+    u64 *ext = ws((size_t)NI * 2 * Eh * n);
+    bool fused_drop = false;
+    if (low == high + 1) {
+        PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Ll + Eh));
+        fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_, raw_drop);
+    }
+    if (!fused_drop) {
+        u64 *innerh = inner;
+        for (int lv = low; lv > high; lv--) {
+            u64 *nxt = ws((size_t)NI * 2 * lv * n);
+            { PROFW(P_MODSWITCH, (size_t)NI * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
+            innerh = nxt;
+        }
+        { PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Lh + Eh)); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
+    }
+    d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
+    if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
+    u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
+    // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
+    // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
+    // kernel and finished once per BinBundle (see behz_finish_coeff).  Bit-identical, 6 instead of 15
+    // inverse transforms per term at L = 2.
+    int max_terms = 0;
+    for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
+    static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
+    // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
+    u64 q_widest = 0;
+    for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
+    const bool summed = !force_per_term && Lh <= 4 &&
+                        (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
+    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
+    if (summed) {
+        const size_t nBskh = Eh - Lh;
+        u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
+        u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
+        if (late_high) {                                    // the cf sums join this inverse-NTT launch
+            g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
+            std::vector<MacStream> cs;
+            cf_streams(g, cs);
+            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj));
+        }
+        std::vector<TensorSumJob> tj;
+        std::vector<FinishSumJob> fj;
+        std::vector<int> dmap;
+        for (int x = 0; x < Bs; x++) {
+            if (!nin[x]) { HIP_CHECK(hipMemsetAsync(result + (size_t)x * 3 * Lh * n, 0, 3 * Lh * n * sizeof(u64), st_)); continue; }
+            const size_t job = (size_t)in_off[x];
+            tj.push_back(TensorSumJob{ ext + job * 2 * Eh * n, hext_ptr(1, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n,
+                                       bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
+            fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+        }
+        // (the finish applies the inverse transform's twist itself where it is the unrolled kernel: raw output)
+        const int rawf = fast_finish(high) ? NTT_MAP_RAW : 0;
+        for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j | rawf);
+        for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i) | rawf);
+        if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
+        if (fuse_tensor_) {
+            // per-term q limbs: product formed by the inverse transform's load; the Bsk sums (and cf) join the launch
+            std::vector<TensorJob> pj;
+            for (int x = 0; x < Bs; x++)
+                for (int i = 0; i < nin[x]; i++) {
+                    const size_t job = (size_t)in_off[x] + i;
+                    pj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(1 + i, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n });
+                }
+            // (only the Bsk limbs: four operand limbs per term in, three sums per BinBundle out)
+            { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
+            PROF(P_NTT_FUSED, dmap.size());
+            launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
+                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
+        } else {
+            { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
+            d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
+        }
+        { PROFW(P_BEHZ_FINISH, ((size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh) + (size_t)Bs * 3 * Lh) * n); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
+    } else {
+        if (late_high) {
+            g.cf = ws(w_cf);
+            std::vector<MacStream> cs;
+            cf_streams(g, cs);
+            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
+            d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
+        }
+        u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
+        // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
+        // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
+        u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
+        std::vector<TensorJob> tj;
+        std::vector<FinishJob> fj;
+        std::vector<SumJob> sj;
+        for (int x = 0; x < Bs; x++) {
+            const int bs = bslot[c0 + g.ids[x]];
+            for (int i = 1; i <= nin[x]; i++) {
+                const size_t job = (size_t)in_off[x] + i - 1;
+                tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
+                fj.push_back(FinishJob{ dbuf + job * 3 * Eh * n, tbuf + job * 3 * Lh * n, 1, 0 });
+            }
+            sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
+        }
+        if (fuse_tensor_ && tj.size() == (size_t)NI) {
+            PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
+            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_);
+        } else {
+            if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
+            d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
+        }
+        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
+        { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
+    }
+    d_relinearize(result, 3 * Lh * n, Bs, *rk, high);                                          // :308-310
+
+    // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
+    u64 *i0 = nullptr;
+    if (i0_fast && low == high) {
+        i0 = ssum;
+    } else if (i0_fast) {
+        i0 = ws((size_t)Bs * 2 * Lh * n);
+        std::vector<I0Job> ij;
+        for (int x = 0; x < Bs; x++)
+            ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
+        { PROFW(P_MODSWITCH, (size_t)Bs * n * (4 * Lh + 2 * l)); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0); }
+    } else {
+        u64 *termh = term;
+        for (int lv = low; lv > high; lv--) {
+            u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
+            { PROFW(P_MODSWITCH, (size_t)Bs * l * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
+            termh = nxt;
+        }
+        i0 = ws((size_t)Bs * 2 * Lh * n);
+        HIP_CHECK(hipMemsetAsync(i0, 0, (size_t)Bs * 2 * Lh * n * sizeof(u64), st_));
+        { PROF(P_OTHER, 0); launch_add_many(dlevel(high), i0, 2 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
+    }
+
+    // :340-343 the two exact addends, :345 add_plain(a_0), :346 add_plain(mask), :354-356 mod switch to the last
+    // level, :357 clear bits — one pass over the result
+    std::vector<EpiJob> ej;
+    for (int x = 0; x < Bs; x++)
+        ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
+                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]) });
+    { PROFW(P_MODSWITCH, (size_t)Bs * n * (7 * Lh + 4)); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
+
+}
+
 void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers &pw, const RelinKeys *rk,
                           const u64 *const *masks, bool masks_on_device, u64 *out, bool out_on_device, u64 *const *out_rows)
 {
@@ -2034,10 +2405,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     }
     if (any_ps && !rk) throw std::invalid_argument("relinearization keys are required");
 
-    // powers are stored bundle-index major ([idx][power][2][L][n]): one index's powers are contiguous
-    auto low_ptr = [&](uint32_t power, int b) { return pw.low.u() + (((size_t)b * pw.n_low + (power - 1)) * 2) * Ll * n; };
-    const u32 low_term_stride = (u32)((size_t)2 * Ll * n);
-    auto hext_ptr = [&](uint32_t i, int b) { return pw.hext.u() + (((size_t)b * pw.n_high + (i - 1)) * 2) * Eh * n; };
+    EvalCall c{ bundles, pw, rk, masks, masks_on_device, out_rows, n, l, high, low, Ll, Lh, Eh, (u32)((size_t)2 * Ll * n), std::move(bslot) };
 
     // workspace budget -> chunk size
     size_t per_bundle_words = 0;
@@ -2057,317 +2425,21 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
         WITH_ARENA({
             // final [B][2][1][n]: written in place when the caller's buffer is on the device
             u64 *res = out_rows ? nullptr : (out_on_device ? out + (size_t)c0 * 2 * n : ws((size_t)B * 2 * n));
-            auto res_ptr = [&](int i) { return out_rows ? out_rows[c0 + i] : res + (size_t)i * 2 * n; };
             u64 *mask_d = nullptr;
             if (!masks_on_device) {
                 mask_d = ws((size_t)B * n);
                 for (int i = 0; i < B; i++) H2D(mask_d + (size_t)i * n, masks[c0 + i], n);
             }
-            auto mask_ptr = [&](int i) { return masks_on_device ? masks[c0 + i] : mask_d + (size_t)i * n; };
+            c.c0 = c0; c.res = res; c.mask_d = mask_d;
 
             // split the chunk into Paterson-Stockmeyer and plain evaluations
             std::vector<int> ps_ids, pl_ids;
             for (int i = 0; i < B; i++) (bundles[c0 + i]->use_ps ? ps_ids : pl_ids).push_back(i);
 
             // ---------------------------------------------------------------- plain: bin_bundle.cpp:106-174
-            if (!pl_ids.empty()) {
-                const int Bp = (int)pl_ids.size();
-                const int lvl = low;                                   // level of powers[1]
-                const size_t Lv = lvl + 1;
-                u64 *acc = ws((size_t)Bp * 2 * Lv * n);
-                std::vector<MacStream> ms;
-                std::vector<EpiJob> ej;
-                for (int x = 0; x < Bp; x++) {
-                    const Bundle &b = *bundles[c0 + pl_ids[x]];
-                    u64 *o = acc + (size_t)x * 2 * Lv * n;
-                    if (b.degree) ms.push_back(MacStream{ bundle_slot(b, false, 0, Lv * n), low_ptr(1, bslot[c0 + pl_ids[x]]), o, b.degree,
-                                                          bundle_stride(b, false, Lv * n), low_term_stride, (u32)(Ll * n), (u32)(Lv * n), 0, (u32)Lv,
-                                                          (u32)b.packed });   // :140-149
-                    else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
-                    ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
-                }
-                { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj)); }
-                d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
-                // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
-                { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
-            }
-
+            if (!pl_ids.empty()) eval_plain(c, pl_ids);
             // ---------------------------------------------------------------- Paterson-Stockmeyer: bin_bundle.cpp:192-360
-            if (!ps_ids.empty()) {
-                // i = 0 block (:314-324): every term C^j (.) a_j is INTT'd and rounded to the high level ON ITS OWN before
-                // the sum (note N1).  With one dropped limb the sum of the rounded terms is
-                //   (sum_j c_j[m] + l*half - sum_j ((c_j[last] + half) mod q_last)) * q_last^-1  mod q_m,
-                // where the first sum is exact and may be taken in the NTT domain.  So only the LAST limb of each term
-                // needs its own inverse transform (2 per term instead of 2*L_low), bit-identical to the reference.
-                const bool i0_fast = (low - high <= 1) && ((unsigned __int128)(l + 1) * hlevel(low).q[Ll - 1] < ((unsigned __int128)1 << 64));
-                const bool need_vlast = i0_fast && low > high;
-                // RAW inverse transforms (no twist, no final reduction) where the consumer's own constants absorb the twist:
-                // the inner polynomials when the fused drop + extension kernel takes them, the i = 0 block's sums and last limbs
-                const bool raw_drop = raw_twist_ && low == high + 1 && hlevel(high).L == hlevel(high).nB && hlevel(high).L <= 3;
-                const bool raw_i0 = raw_twist_ && need_vlast;
-
-                // One batch: every Paterson-Stockmeyer BinBundle of the chunk, ordered by bundle index (the shared powers of
-                // one index then stay in the same L2).  (Cutting the batch into groups whose database scans overlap the previous
-                // group's VALU-bound tail on a second stream was built and measured in rounds 2 and 3, also with an LDS-DMA
-                // multiply-accumulate that leaves room for an NTT workgroup per CU: slower to level, the chip is power-bound.
-                // profiles/r03_eval_pipeline.txt; the code is in git history at 22dbbd1, engine.cpp:1600-1745.)
-                struct PsBatch {
-                    std::vector<int> ids;                               // positions in this chunk
-                    std::vector<int> nin, in_off;                       // inner polynomials per BinBundle, prefix offsets
-                    int NI = 0;
-                    u64 *inner = nullptr, *ssum = nullptr, *vlast = nullptr, *term = nullptr, *cf = nullptr;
-                    std::vector<int> imap;                              // modulus of every limb polynomial of the merged block
-                    const MacJob *mac_jobs = nullptr;
-                    int n_mac = 0;
-                    uint64_t units = 0; uint32_t mean_cnt = 0; bool mac_is_packed = false;
-                } g;
-                g.ids = ps_ids;
-                std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
-                // high powers still in flight on the second stream (split ComputePowers): everything that needs only the low
-                // powers goes first, the cf products (which read the high powers) come later
-                const bool async_high = pw.high_async && pw.high_ready;
-                const bool late_high = async_high;
-                auto cf_streams = [&](const PsBatch &g, std::vector<MacStream> &out) {
-                    for (size_t x = 0; x < g.ids.size(); x++) {
-                        const Bundle &b = *bundles[c0 + g.ids[x]];
-                        out.push_back(MacStream{ bundle_slot(b, true, 0, Lh * n), hext_ptr(1, bslot[c0 + g.ids[x]]), g.cf + x * 2 * Lh * n, b.H,
-                                                 bundle_stride(b, true, Lh * n), (u32)((size_t)2 * Eh * n), (u32)(Eh * n), (u32)(Lh * n), 0, (u32)Lh,
-                                                 (u32)b.packed });
-                    }
-                };
-
-                // ---- phase A: workspace and the job array of the multiply-accumulate
-                {
-                    const int Bs = (int)g.ids.size();
-                    // inner polynomials i = 1..H (block H only if r > 0)                     :248-304
-                    g.nin.resize(Bs); g.in_off.resize(Bs);
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + g.ids[x]];
-                        g.nin[x] = (int)b.H - (b.r == 0 ? 1 : 0);
-                        g.in_off[x] = g.NI;
-                        g.NI += g.nin[x];
-                    }
-                    // Every dyadic multiply-accumulate of the evaluation reads only the query powers and the database, so
-                    // all of a group run as ONE launch, and their results share ONE inverse-NTT launch:
-                    //   inner [NI][2][Ll]   sum_j C^j (.) a_{i*h+j}                                  :258-264
-                    //   ssum  [Bs][2][Lh]   sum_j C^j (.) a_j on the limbs that survive the switch  (i = 0 block, fast form)
-                    //   vlast [Bs*l][2][1]  C^j (.) a_j on the dropped limb, per term               (i = 0 block, fast form)
-                    //   term  [Bs*l][2][Ll] C^j (.) a_j, per term                                   (i = 0 block, general form)
-                    //   cf    [Bs][2][Lh]   sum_i lift(a_{i*h}) (.) C^{i*h}                          :328-337 (exact)
-                    const size_t w_inner = (size_t)g.NI * 2 * Ll * n, w_ssum = i0_fast ? (size_t)Bs * 2 * Lh * n : 0;
-                    const size_t w_vlast = need_vlast ? (size_t)Bs * l * 2 * n : 0, w_term = i0_fast ? 0 : (size_t)Bs * l * 2 * Ll * n;
-                    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
-                    g.inner = ws(w_inner + w_ssum + w_vlast + w_term + (late_high ? 0 : w_cf));
-                    g.ssum = g.inner + w_inner; g.vlast = g.ssum + w_ssum; g.term = g.vlast + w_vlast;
-                    g.cf = late_high ? nullptr : g.term + w_term;
-                    std::vector<MacStream> ms;
-                    auto map_push = [&](size_t polys, int first_limb, int limbs) {
-                        for (size_t p = 0; p < polys; p++) for (int j = 0; j < limbs; j++) g.imap.push_back(first_limb + j);
-                    };
-                    for (int x = 0; x < Bs; x++) {
-                        const Bundle &b = *bundles[c0 + g.ids[x]];
-                        const int bs = bslot[c0 + g.ids[x]];
-                        for (int i = 1; i <= g.nin[x]; i++) {
-                            const u32 cnt = (u32)i < b.H ? l : b.r;
-                            ms.push_back(MacStream{ bundle_slot(b, false, (size_t)i * l, Ll * n), low_ptr(1, bs),
-                                                    g.inner + ((size_t)g.in_off[x] + i - 1) * 2 * Ll * n, cnt,
-                                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll,
-                                                    (u32)b.packed });
-                        }
-                    }
-                    map_push((size_t)g.NI * 2, 0, (int)Ll);
-                    if (raw_drop) for (int &v : g.imap) v |= NTT_MAP_RAW;          // consumed by the fused drop + extension only
-                    if (i0_fast) {
-                        for (int x = 0; x < Bs; x++) {
-                            const Bundle &b = *bundles[c0 + g.ids[x]];
-                            ms.push_back(MacStream{ bundle_slot(b, false, 0, Ll * n), low_ptr(1, bslot[c0 + g.ids[x]]), g.ssum + (size_t)x * 2 * Lh * n, l,
-                                                    bundle_stride(b, false, Ll * n), low_term_stride, (u32)(Ll * n), (u32)(Lh * n), 0, (u32)Lh,
-                                                    (u32)b.packed });
-                        }
-                        map_push((size_t)Bs * 2, 0, (int)Lh);
-                        if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * 2 * Lh; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
-                    }
-                    if (need_vlast || !i0_fast) {
-                        for (int x = 0; x < Bs; x++) {
-                            const Bundle &b = *bundles[c0 + g.ids[x]];
-                            const int bs = bslot[c0 + g.ids[x]];
-                            for (u32 j = 1; j <= l; j++) {
-                                if (i0_fast)
-                                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
-                                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
-                                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1, (u32)b.packed });
-                                else
-                                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
-                                                            g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
-                                                            (u32)(Ll * n), (u32)(Ll * n), 0, (u32)Ll, (u32)b.packed });
-                            }
-                        }
-                        if (i0_fast) {
-                            map_push((size_t)Bs * l * 2, (int)Ll - 1, 1);
-                            if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * l * 2; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
-                        } else map_push((size_t)Bs * l * 2, 0, (int)Ll);
-                    }
-                    if (!late_high) { cf_streams(g, ms); map_push((size_t)Bs * 2, 0, (int)Lh); }
-                    auto mj = group_mac(ms);
-                    g.mac_jobs = upload_jobs(mj);
-                    g.n_mac = (int)mj.size();
-                    g.units = mac_units(mj);
-                    g.mean_cnt = mac_mean_cnt(mj);
-                    g.mac_is_packed = mac_packed(mj);
-                }
-
-                // ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
-                // primes) and everything behind it
-                {
-                    const int Bs = (int)g.ids.size(), NI = g.NI;
-                    const std::vector<int> &nin = g.nin, &in_off = g.in_off;
-                    u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-                    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
-                    d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
-
-                    // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
-                    // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
-                    u64 *ext = ws((size_t)NI * 2 * Eh * n);
-                    bool fused_drop = false;
-                    if (low == high + 1) {
-                        PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Ll + Eh));
-                        fused_drop = launch_drop_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, inner, Ll * n, 1, ext, n, NI * 2, st_, raw_drop);
-                    }
-                    if (!fused_drop) {
-                        u64 *innerh = inner;
-                        for (int lv = low; lv > high; lv--) {
-                            u64 *nxt = ws((size_t)NI * 2 * lv * n);
-                            { PROFW(P_MODSWITCH, (size_t)NI * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), innerh, (size_t)2 * (lv + 1) * n, 2, nxt, n, NI, st_); }
-                            innerh = nxt;
-                        }
-                        { PROFW(P_BEHZ_EXT, (size_t)NI * 2 * n * (Lh + Eh)); launch_behz_ext(dlevel(high), hlevel(high).L, hlevel(high).nB, innerh, Lh * n, 1, ext, n, NI * 2, st_); }
-                    }
-                    d_ntt(ext, (size_t)NI * 2 * Eh, map_ext(high), (int)Eh, false);
-                    if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));
-                    u64 *result = ws((size_t)Bs * 3 * Lh * n);                                                  // :238-240
-                    // The products of one BinBundle are summed (:273,303).  Each keeps its own rounding (note N1), but only
-                    // the q limbs are needed per term for that: the Bsk limbs are summed in the NTT domain by the tensor
-                    // kernel and finished once per BinBundle (see behz_finish_coeff).  Bit-identical, 6 instead of 15
-                    // inverse transforms per term at L = 2.
-                    int max_terms = 0;
-                    for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
-                    static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
-                    // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
-                    u64 q_widest = 0;
-                    for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
-                    const bool summed = !force_per_term && Lh <= 4 &&
-                                        (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
-                    const size_t w_cf = (size_t)Bs * 2 * Lh * n;
-                    if (summed) {
-                        const size_t nBskh = Eh - Lh;
-                        u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
-                        u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
-                        if (late_high) {                                    // the cf sums join this inverse-NTT launch
-                            g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
-                            std::vector<MacStream> cs;
-                            cf_streams(g, cs);
-                            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj));
-                        }
-                        std::vector<TensorSumJob> tj;
-                        std::vector<FinishSumJob> fj;
-                        std::vector<int> dmap;
-                        for (int x = 0; x < Bs; x++) {
-                            if (!nin[x]) { HIP_CHECK(hipMemsetAsync(result + (size_t)x * 3 * Lh * n, 0, 3 * Lh * n * sizeof(u64), st_)); continue; }
-                            const size_t job = (size_t)in_off[x];
-                            tj.push_back(TensorSumJob{ ext + job * 2 * Eh * n, hext_ptr(1, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n,
-                                                       bsum + (size_t)x * 3 * nBskh * n, nin[x], 0 });
-                            fj.push_back(FinishSumJob{ dq + job * 3 * Lh * n, bsum + (size_t)x * 3 * nBskh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
-                        }
-                        // (the finish applies the inverse transform's twist itself where it is the unrolled kernel: raw output)
-                        const int rawf = fast_finish(high) ? NTT_MAP_RAW : 0;
-                        for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j | rawf);
-                        for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i) | rawf);
-                        if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
-                        if (fuse_tensor_) {
-                            // per-term q limbs: product formed by the inverse transform's load; the Bsk sums (and cf) join the launch
-                            std::vector<TensorJob> pj;
-                            for (int x = 0; x < Bs; x++)
-                                for (int i = 0; i < nin[x]; i++) {
-                                    const size_t job = (size_t)in_off[x] + i;
-                                    pj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(1 + i, bslot[c0 + g.ids[x]]), dq + job * 3 * Lh * n });
-                                }
-                            // (only the Bsk limbs: four operand limbs per term in, three sums per BinBundle out)
-                            { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
-                            PROF(P_NTT_FUSED, dmap.size());
-                            launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
-                                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
-                        } else {
-                            { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
-                            d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
-                        }
-                        { PROFW(P_BEHZ_FINISH, ((size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh) + (size_t)Bs * 3 * Lh) * n); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
-                    } else {
-                        if (late_high) {
-                            g.cf = ws(w_cf);
-                            std::vector<MacStream> cs;
-                            cf_streams(g, cs);
-                            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
-                            d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
-                        }
-                        u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
-                        // every (BinBundle, block) product is finished (x t, floor, Bsk -> q) by its own threads, then the
-                        // per-term results are summed per BinBundle (:273,303): the roundings stay per term (note N1)
-                        u64 *tbuf = ws((size_t)NI * 3 * Lh * n);
-                        std::vector<TensorJob> tj;
-                        std::vector<FinishJob> fj;
-                        std::vector<SumJob> sj;
-                        for (int x = 0; x < Bs; x++) {
-                            const int bs = bslot[c0 + g.ids[x]];
-                            for (int i = 1; i <= nin[x]; i++) {
-                                const size_t job = (size_t)in_off[x] + i - 1;
-                                tj.push_back(TensorJob{ ext + job * 2 * Eh * n, hext_ptr(i, bs), dbuf + job * 3 * Eh * n });
-                                fj.push_back(FinishJob{ dbuf + job * 3 * Eh * n, tbuf + job * 3 * Lh * n, 1, 0 });
-                            }
-                            sj.push_back(SumJob{ tbuf + (size_t)in_off[x] * 3 * Lh * n, result + (size_t)x * 3 * Lh * n, nin[x], 0 });
-                        }
-                        if (fuse_tensor_ && tj.size() == (size_t)NI) {
-                            PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
-                            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_);
-                        } else {
-                            if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
-                            d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
-                        }
-                        { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
-                        { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
-                    }
-                    d_relinearize(result, 3 * Lh * n, Bs, *rk, high);                                          // :308-310
-
-                    // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
-                    u64 *i0 = nullptr;
-                    if (i0_fast && low == high) {
-                        i0 = ssum;
-                    } else if (i0_fast) {
-                        i0 = ws((size_t)Bs * 2 * Lh * n);
-                        std::vector<I0Job> ij;
-                        for (int x = 0; x < Bs; x++)
-                            ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0 + (size_t)x * 2 * Lh * n, (int)l, 1 });
-                        { PROFW(P_MODSWITCH, (size_t)Bs * n * (4 * Lh + 2 * l)); launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0); }
-                    } else {
-                        u64 *termh = term;
-                        for (int lv = low; lv > high; lv--) {
-                            u64 *nxt = ws((size_t)Bs * l * 2 * lv * n);
-                            { PROFW(P_MODSWITCH, (size_t)Bs * l * 2 * n * (2 * lv + 1)); launch_modswitch(dlevel(lv), termh, (size_t)2 * (lv + 1) * n, 2, nxt, n, Bs * (int)l, st_); }
-                            termh = nxt;
-                        }
-                        i0 = ws((size_t)Bs * 2 * Lh * n);
-                        HIP_CHECK(hipMemsetAsync(i0, 0, (size_t)Bs * 2 * Lh * n * sizeof(u64), st_));
-                        { PROF(P_OTHER, 0); launch_add_many(dlevel(high), i0, 2 * Lh * n, termh, (int)l, 2, n, Bs, st_); }
-                    }
-
-                    // :340-343 the two exact addends, :345 add_plain(a_0), :346 add_plain(mask), :354-356 mod switch to the last
-                    // level, :357 clear bits — one pass over the result
-                    std::vector<EpiJob> ej;
-                    for (int x = 0; x < Bs; x++)
-                        ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
-                                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]) });
-                    { PROFW(P_MODSWITCH, (size_t)Bs * n * (7 * Lh + 4)); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
-                }
-            }
+            if (!ps_ids.empty()) eval_patstock(c, ps_ids);
             if (!out_on_device) D2H(out + (size_t)c0 * 2 * n, res, (size_t)B * 2 * n);
             // device-resident masks and results: nothing of the caller's is read or written by the host, so the call may
             // return with the work queued (stream order protects the workspace, the job tables and the pooled powers)

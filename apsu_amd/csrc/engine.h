@@ -90,6 +90,9 @@ struct Powers {
     int slot_of(uint32_t bundle_idx) const;
 };
 
+struct MacStream;
+struct PsBatch;
+
 class Engine {
 public:
     Engine(const HeParams &hp, const PSUParams *psu, int device);
@@ -329,6 +332,14 @@ private:
     struct DagRun;                    // per-call state of one walk over a schedule
     void run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *const *src, bool on_device, const RelinKeys *rk, Powers &pw,
                  bool do_low, bool do_high);
+    // eval_bundles in pieces (engine.cpp): per-call context, Paterson-Stockmeyer plan and batch
+    struct EvalCall;
+    struct PsPlan;
+    void eval_plain(EvalCall &c, const std::vector<int> &pl_ids);
+    void eval_patstock(EvalCall &c, const std::vector<int> &ps_ids);
+    void ps_cf_streams(const EvalCall &c, const PsBatch &g, std::vector<MacStream> &out);
+    void ps_tables(EvalCall &c, const PsPlan &plan, PsBatch &g);
+    void ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g);
     void finish_bundle(Bundle &b, const u64 *raw);     // raw: [degree+1][n] coefficient-form plaintexts mod t (device)
     DevBuf d_slot_map_;
     DevBuf d_seed_rej_, d_seed_mm_, d_key_level_;   // seed expansion: rejection lists, max_multiple per (level, limb), DevLevel-shaped view of the key level
