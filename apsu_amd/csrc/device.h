@@ -198,7 +198,12 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
                        hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0, bool raw = false);
 // kara: the three-product accumulation (k_mac<.., true>, lv->mac_chunk_k)
 // packed: every job of the launch reads bit-packed plaintexts (MacJob::packed)
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false, bool packed = false);
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false, bool packed = false, int limb_slow = 0);
+// single products on one limb: out[0][k] = a[k] * pw[limb][k], out[out_poly_stride + k] = a[k] * pw[pw_poly_stride + limb n + k]  (mod q_limb);
+// pt: the plaintext's slot as k_mac takes it (dense: [L][n] words; packed: the bit-packed slot, rows per DevLevel::mac_row_off)
+struct TermJob { const u64 *pt; const u64 *pw; u64 *out; };
+void launch_term_product(const DevLevel *lv, const TermJob *jobs, size_t njobs, size_t n, int limb, u32 pw_poly_stride, u32 out_poly_stride,
+                         bool packed, hipStream_t st);
 // dense [slots][L][n] u64 <-> bit-packed [slots][slot_bytes] (rows per DevLevel::mac_bits / mac_row_off of `lv`)
 void launch_pack_rows(const DevLevel *lv, int L, const u64 *dense, void *packed, size_t slot_bytes, size_t n, size_t slots, hipStream_t st);
 void launch_unpack_rows(const DevLevel *lv, int L, const void *packed, size_t slot_bytes, u64 *dense, size_t n, size_t slots, hipStream_t st);

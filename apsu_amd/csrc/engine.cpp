@@ -163,6 +163,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
+        if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
+        if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
         if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
         // BinBundle plaintexts bit-packed in HBM (12.5 % fewer bytes for 56-bit primes, 22 % for 50-bit ones; k_mac<.., PACKED>): in-process
         // A/B on 16M-4096 -0.146 +- 0.017 ms (-4.2 %) on the whole query, -2.4 % on the N = 8 shard, same bits
@@ -2020,6 +2022,8 @@ struct PsBatch {
     const MacJob *mac_jobs = nullptr;
     int n_mac = 0;
     uint64_t units = 0; uint32_t mean_cnt = 0; bool mac_is_packed = false;
+    const TermJob *term_jobs = nullptr;                 // the i = 0 block's per-term products on the dropped limb (k_term_product)
+    size_t n_term = 0; bool term_packed = false;
 };
 
 // BatchedPlaintextPolyn::eval (bin_bundle.cpp:106-174) for the BinBundles pl_ids of the chunk
@@ -2048,7 +2052,7 @@ void Engine::eval_plain(EvalCall &c, const std::vector<int> &pl_ids)
         else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
         ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
     }
-    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj)); }
+    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
     d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
     // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
     { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
@@ -2163,12 +2167,19 @@ void Engine::ps_tables(EvalCall &c, const PsPlan &plan, PsBatch &g)
         map_push((size_t)Bs * 2, 0, (int)Lh);
         if (raw_i0) for (size_t x = g.imap.size() - (size_t)Bs * 2 * Lh; x < g.imap.size(); x++) g.imap[x] |= NTT_MAP_RAW;
     }
+    std::vector<TermJob> tj;
     if (need_vlast || !i0_fast) {
         for (int x = 0; x < Bs; x++) {
             const Bundle &b = *bundles[c0 + g.ids[x]];
             const int bs = bslot[c0 + g.ids[x]];
+            if (i0_fast && term_kernel_) {
+                if (x == 0) g.term_packed = b.packed;
+                else if (g.term_packed != (bool)b.packed) throw std::logic_error("BinBundles of one evaluation differ in their row format");
+            }
             for (u32 j = 1; j <= l; j++) {
-                if (i0_fast)
+                if (i0_fast && term_kernel_)
+                    tj.push_back(TermJob{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs), g.vlast + ((size_t)x * l + j - 1) * 2 * n });
+                else if (i0_fast)
                     ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
                                             g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
                                             (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1, (u32)b.packed });
@@ -2190,6 +2201,7 @@ void Engine::ps_tables(EvalCall &c, const PsPlan &plan, PsBatch &g)
     g.units = mac_units(mj);
     g.mean_cnt = mac_mean_cnt(mj);
     g.mac_is_packed = mac_packed(mj);
+    if (!tj.empty()) { g.term_jobs = upload_jobs(tj); g.n_term = tj.size(); }
 }
 
 // ---- phase B: the multiply-accumulate (the level-`low` constants serve every limb: levels share their leading
@@ -2212,7 +2224,8 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     const int Bs = (int)g.ids.size(), NI = g.NI;
     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
+    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed, mac_limb_slow_); }
+    if (g.n_term) { PROF(P_MAC, (uint64_t)g.n_term * (g.term_packed ? packed_row_bits(hp_.key_q[Ll - 1]) : 64)); launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_); }
     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
@@ -2256,7 +2269,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
             std::vector<MacStream> cs;
             cf_streams(g, cs);
-            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj));
+            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_);
         }
         std::vector<TensorSumJob> tj;
         std::vector<FinishSumJob> fj;
@@ -2296,7 +2309,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             g.cf = ws(w_cf);
             std::vector<MacStream> cs;
             cf_streams(g, cs);
-            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
+            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
             d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
         }
         u64 *dbuf = ws((size_t)NI * 3 * Eh * n);

@@ -319,6 +319,8 @@ private:
     size_t slot_bytes(int chain_idx, bool packed) const;          // bytes of one NTT-form plaintext at a level, either format
     void pack_bundle(Bundle &b);      // dense -> packed when this context keeps packed rows (no-op otherwise)
     void unpack_bundle(Bundle &b);    // packed -> dense (images of the other format)
+    bool term_kernel_ = true;         // the i = 0 block's per-term products on the dropped limb by k_term_product instead of k_mac chains of length one
+    int mac_limb_slow_ = 1;           // k_mac grid order 0 / 1 / 2: what is resident behind one L2 together (1: -2.5 ... -2.9 % on the 256M-4096 query, level at 16M-4096) (APSU_HE_MAC_LIMB_SLOW; kernels.hip, launch_mac)
     int mac_kara_ = -1;               // k_mac with three products per term instead of four: -1 by chain length, 0 / 1 forced (APSU_HE_MAC_KARA)
     bool mac_kara(int lvl, uint32_t mean_cnt) const;
     uint64_t mac_units(const std::vector<MacJob> &mj) const;      // bits of database rows per coefficient index (profile unit of P_MAC)

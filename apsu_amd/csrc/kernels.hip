@@ -1473,7 +1473,7 @@ __device__ unsigned long long *g_mac_stamps = nullptr;
 #define APSU_MAC_MINWAVES 1                                        // waves per SIMD the register allocation must allow (experiment switch)
 #endif
 template <int G, int C, bool KARA = false, bool PACKED = false>
-__global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n)
+__global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel *__restrict__ lv, const MacJob *__restrict__ jobs, size_t n, int limb_slow)
 {
     static_assert(C == 1 || C == 2, "coefficients per lane");
     static_assert(!PACKED || C == 2, "packed rows are read two coefficients per lane");
@@ -1482,15 +1482,26 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
     MAC_STAMP(0);
-    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * C;
+    // grid order (launch_mac).  Workgroups go to the XCDs round-robin in launch order, so what is FAST in the grid decides which
+    // workgroups are resident behind one L2 together, i.e. how much of the shared powers that L2 has to hold:
+    //   0: (block, limb, job)        -- an XCD holds blocks x, x + 8 of every limb of ~10 jobs: 2 * limbs * terms * 8 KiB
+    //   1: (block, job, limb)        -- ... of ONE limb of ~32 jobs: 2 * terms * 8 KiB
+    //   2: (block mod 8, job, block / 8, limb) -- ONE block of one limb of 64 jobs: terms * 8 KiB (2.5 MiB for 310 terms)
+    unsigned b_x = blockIdx.x, b_limb = blockIdx.y, b_job = blockIdx.z;
+    if (limb_slow == 1) { b_limb = blockIdx.z; b_job = blockIdx.y; }
+    else if (limb_slow == 2) {
+        const unsigned xb = (unsigned)((n / C + EW_T - 1) / EW_T) >> 3;          // blocks per XCD lane (launch_mac: a multiple of 8 blocks)
+        b_x = blockIdx.x + 8 * (blockIdx.z % xb); b_limb = blockIdx.z / xb; b_job = blockIdx.y;
+    }
+    const size_t k = ((size_t)b_x * EW_T + threadIdx.x) * C;
     if (k >= n) return;
     constexpr int SPLIT = MAC_G / G;                            // a job's streams are covered by SPLIT blocks
-    const MacJob *__restrict__ jp = jobs + blockIdx.z / SPLIT;   // stream pointers are indexed dynamically: read them from memory
+    const MacJob *__restrict__ jp = jobs + b_job / SPLIT;        // stream pointers are indexed dynamically: read them from memory
     struct { const u64 *pw; u32 cnt, ng, pt_stride, pw_stride, pw_poly_stride, out_poly_stride, limb0; } job =
         { jp->pw, jp->cnt, jp->ng, jp->pt_stride, jp->pw_stride, jp->pw_poly_stride, jp->out_poly_stride, jp->limb0 };
-    const int g0 = (blockIdx.z % SPLIT) * G;
-    if (g0 >= (int)job.ng || blockIdx.y >= jp->nl) return;
-    const int j = blockIdx.y + job.limb0;                      // limb
+    const int g0 = (b_job % SPLIT) * G;
+    if (g0 >= (int)job.ng || b_limb >= jp->nl) return;
+    const int j = b_limb + job.limb0;                          // limb
     const Mod m = lv->q[j];
     const u32 s = lv->mac_shift[j], chunk = KARA ? lv->mac_chunk_k[j] : lv->mac_chunk[j];
     const u32 lomask = (1u << s) - 1;                          // s <= 30
@@ -1502,12 +1513,30 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
     if constexpr (PACKED) {
         kb = lv->mac_bits[j];
         himask = lv->mac_mask_hi[j];
+#ifdef APSU_MAC_TILED_EXPERIMENT
+        if (jp->pad == 1) {                                     // tools/microbench/macbench.hip: the G streams' tiles of one (term, limb, block) adjacent in memory
+            const u32 bitoff = threadIdx.x * 2 * kb, tile = EW_T * C * kb / 8, nblk = (u32)(n / (EW_T * C));
+            psh = bitoff & 31;
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                ptw[g] = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(jp->pt[0]) + ((size_t)(j * nblk + b_x) * G + g) * tile) + (bitoff >> 5);
+        } else
+#endif
+        {
         const u32 bitoff = (u32)(k >> 1) * 2 * kb;
         psh = bitoff & 31;
 #pragma unroll
         for (int g = 0; g < G; g++)
             ptw[g] = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(jp->pt[g0 + g < (int)job.ng ? g0 + g : g0]) + lv->mac_row_off[j]) + (bitoff >> 5);
+        }
     } else {
+#ifdef APSU_MAC_TILED_EXPERIMENT
+        if (jp->pad == 1) {
+            const u32 nblk = (u32)(n / (EW_T * C));
+#pragma unroll
+            for (int g = 0; g < G; g++) pt[g] = jp->pt[0] + ((size_t)(j * nblk + b_x) * G + g) * (EW_T * C) + threadIdx.x * C;
+        } else
+#endif
 #pragma unroll
         for (int g = 0; g < G; g++) pt[g] = jp->pt[g0 + g < (int)job.ng ? g0 + g : g0] + (size_t)j * n + k;   // missing streams alias a real one
     }
@@ -1630,7 +1659,7 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {
-            u64 *o = jp->out[g0 + g] + (size_t)blockIdx.y * n + k;
+            u64 *o = jp->out[g0 + g] + (size_t)b_limb * n + k;
             if (C == 2) {
                 u64x2 r0, r1;
                 r0[0] = s00[g][0][0]; r0[1] = s00[g][C - 1][0];
@@ -1661,21 +1690,74 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
 #ifndef APSU_MAC_C
 #define APSU_MAC_C 2
 #endif
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara, bool packed)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara, bool packed, int limb_slow)
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
     // (round 4, measured and not adopted -- tools/microbench/mac_persist.hip, profiles/r04_mac_{units,persist,stagger}.txt: a launch
     //  costs ~0.26 ms more than its chains' length explains, i.e. ~14 us per workgroup; long-lived workgroups that keep the load
     //  pipeline running across chains were 4-9 % SLOWER, starting the first resident generation in phases changed nothing)
-    const dim3 grid((unsigned)((n / C + EW_T - 1) / EW_T), (unsigned)nlimbs, (unsigned)(njobs * (MAC_G / G)));
+    const unsigned gx = (unsigned)((n / C + EW_T - 1) / EW_T), gl = (unsigned)nlimbs, gj = (unsigned)(njobs * (MAC_G / G));
+    int ls = gj <= 65535u ? limb_slow : 0;
+    if (ls == 2 && (gx % 8 != 0 || (size_t)gl * (gx / 8) > 65535u)) ls = 1;
+    const dim3 grid = ls == 2 ? dim3(8, gj, gl * (gx / 8)) : ls == 1 ? dim3(gx, gj, gl) : dim3(gx, gl, gj);
     if (packed) {
         if constexpr (C == 2) {
-            if (kara) hipLaunchKernelGGL((k_mac<G, C, true, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
-            else hipLaunchKernelGGL((k_mac<G, C, false, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+            if (kara) hipLaunchKernelGGL((k_mac<G, C, true, true>), grid, dim3(EW_T), 0, st, lv, jobs, n, ls);
+            else hipLaunchKernelGGL((k_mac<G, C, false, true>), grid, dim3(EW_T), 0, st, lv, jobs, n, ls);
         } else throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
-    } else if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n);
-    else hipLaunchKernelGGL((k_mac<G, C, false>), grid, dim3(EW_T), 0, st, lv, jobs, n);
+    } else if (kara) hipLaunchKernelGGL((k_mac<G, C, true>), grid, dim3(EW_T), 0, st, lv, jobs, n, ls);
+    else hipLaunchKernelGGL((k_mac<G, C, false>), grid, dim3(EW_T), 0, st, lv, jobs, n, ls);
+    KERNEL_CHECK();
+}
+
+// ---- single dyadic products on ONE limb (round 4): out[p][k] = a[k] * C_p[k] mod q_limb for p = 0, 1.
+// The i = 0 block of eval_patstock (bin_bundle.cpp:314-324) switches every term a_j (.) C^j to the next level on its own, so
+// the dropped limb of every term is needed by itself (k_i0_finish): terms x BinBundles chains of length ONE.  As k_mac jobs each
+// of them paid a whole workgroup's fixed costs (descriptor and pointer reads, the first term's latency, the 128-bit fold, the
+// drain of the stores: ~10 us at two workgroups per CU) for 1.4 us of work -- 9 % of the launch for 2.6 % of its bytes at
+// 16M-4096, more at 256M-4096 (31 620 such chains).  Here: one thread per coefficient pair, ~40 registers, full occupancy,
+// the same canonical residue (k_mac's fold of a single product IS barrett128 of that product).
+template <bool PACKED>
+__global__ __launch_bounds__(EW_T) void k_term_product(const DevLevel *__restrict__ lv, const TermJob *__restrict__ jobs, size_t njobs, size_t n, int limb,
+                                                       u32 pw_poly_stride, u32 out_poly_stride)
+{
+    const size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2;
+    const size_t u = blockIdx.y + (size_t)gridDim.y * blockIdx.z;
+    if (k >= n || u >= njobs) return;
+    const TermJob job = jobs[u];
+    const Mod m = lv->q[limb];
+    u64 a0, a1;
+    if constexpr (PACKED) {
+        const u32 kb = lv->mac_bits[limb];
+        const u32 bitoff = (u32)(k >> 1) * 2 * kb, psh = bitoff & 31;
+        const u32x4a4 w = ldg16_a4_nt(reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(job.pt) + lv->mac_row_off[limb]) + (bitoff >> 5));
+        const u32 n0 = __builtin_amdgcn_alignbit(w[1], w[0], psh), n1 = __builtin_amdgcn_alignbit(w[2], w[1], psh),
+                  n2 = __builtin_amdgcn_alignbit(w[3], w[2], psh), n3 = w[3] >> psh;
+        const u64 lo64 = (u64)n0 | ((u64)n1 << 32), hi64 = (u64)n2 | ((u64)n3 << 32);
+        if (kb == 64) { a0 = lo64; a1 = hi64; }
+        else { const u64 mask = ((u64)1 << kb) - 1; a0 = lo64 & mask; a1 = ((lo64 >> kb) | (hi64 << (64 - kb))) & mask; }
+    } else {
+        const u64x2 a = ldg16_nt(job.pt + (size_t)limb * n + k);
+        a0 = a[0]; a1 = a[1];
+    }
+    const u64 *pw = job.pw + (size_t)limb * n + k;
+    const u64x2 c0 = ldg16(pw), c1 = ldg16(pw + pw_poly_stride);
+    u64x2 r0, r1;
+    r0[0] = barrett128(mul128(a0, c0[0]), m); r0[1] = barrett128(mul128(a1, c0[1]), m);
+    r1[0] = barrett128(mul128(a0, c1[0]), m); r1[1] = barrett128(mul128(a1, c1[1]), m);
+    *reinterpret_cast<u64x2 *>(job.out + k) = r0;
+    *reinterpret_cast<u64x2 *>(job.out + out_poly_stride + k) = r1;
+}
+
+void launch_term_product(const DevLevel *lv, const TermJob *jobs, size_t njobs, size_t n, int limb, u32 pw_poly_stride, u32 out_poly_stride,
+                         bool packed, hipStream_t st)
+{
+    if (!njobs) return;
+    const unsigned gy = (unsigned)std::min<size_t>(njobs, 32768), gz = (unsigned)((njobs + gy - 1) / gy);
+    const dim3 grid((unsigned)((n / 2 + EW_T - 1) / EW_T), gy, gz);
+    if (packed) hipLaunchKernelGGL((k_term_product<true>), grid, dim3(EW_T), 0, st, lv, jobs, njobs, n, limb, pw_poly_stride, out_poly_stride);
+    else hipLaunchKernelGGL((k_term_product<false>), grid, dim3(EW_T), 0, st, lv, jobs, njobs, n, limb, pw_poly_stride, out_poly_stride);
     KERNEL_CHECK();
 }
 

@@ -37,11 +37,23 @@ template <bool WAVE> __device__ __forceinline__ void ntt_sync()
 // reads (L2 latency, 7 to 15 x 16 bytes per lane and pass) are in flight during the LDS turnaround instead of behind it.
 // Measured level to slightly slower than WS alone (tools/microbench/ntt_variants.hip, profiles/r04_ntt_variants.txt: the other
 // waves already cover that latency, and the held twiddles cost the compiler its scheduling room): off by default.
+// NEXT (round 4, second half): the workgroup that will occupy this workgroup's slot next -- in steady state the one `slots` further
+// on in the grid, which the round-robin dispatch puts on the same XCD and therefore behind the same L2 -- reads its limb from HBM
+// with nothing else to do while it waits.  `next` != nullptr: this thread touches one 128-byte line of that limb (T threads x
+// 128 B = the whole limb at n = 16 T) right before the pass executed LAST, so that the successor's first pass finds its input in
+// the L2 instead of waiting for HBM.  The load has no consumer: its destination register is kept reserved until the end of the body.
 // STAGGER: waves 4..7 (the SIMD partners of waves 0..3) sleep 64 x STAGGER cycles once, so that the two waves a workgroup has
 // on each SIMD do not reach their memory phases together (experiment switch of the microbenchmark).
-template <int LOGN, bool INV, int MODE, int T, int RED = 0, bool RAW = false, class SRC = SrcPlain, bool WS = true, bool PF = false, int STAGGER = 0>
+__device__ __forceinline__ void ntt_touch_line(const void *line, unsigned &sink)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(line));
+}
+__device__ __forceinline__ void ntt_touch_done(unsigned &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)); }
+
+template <int LOGN, bool INV, int MODE, int T, int RED = 0, bool RAW = false, class SRC = SrcPlain, bool WS = true, bool PF = false, int STAGGER = 0,
+          int NEXTPASS = -1>
 __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr,
-                                         const SRC &operands = SRC())
+                                         const SRC &operands = SRC(), const void *next = nullptr)
 {
     constexpr int N = 1 << LOGN;
     constexpr int P = plan_passes(LOGN);
@@ -55,6 +67,8 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     constexpr bool W3 = WS && P > 3 && ntt_wave_private<LOGN, T>(fp(2) < fp(3) ? fp(2) : fp(3));
     // the wave's own range for the coalesced loops (tensor staging, forward store): 16-byte pieces, 1 KiB per wave instruction
     const int wbase = (tid & ~63) << 4, lane = tid & 63;
+    unsigned sink = 0;
+    if constexpr (NEXTPASS == 0) { if (next) ntt_touch_line(next, sink); }
     if constexpr (STAGGER > 0 && INV) { if (tid & 256) __builtin_amdgcn_s_sleep(STAGGER); }
     // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
     //  line is consumed by the wave's eight consecutive loads.  Staging the limb through LDS with coalesced loads first was
@@ -113,10 +127,11 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     if constexpr (P > 1) {
         ntt_sync<W1>();
         if constexpr (STAGGER > 0 && !INV) { if (tid & 256) __builtin_amdgcn_s_sleep(STAGGER); }
+        if constexpr (NEXTPASS == 1) { if (next) ntt_touch_line(next, sink); }
         ntt_pass<LOGN, INV, MODE, 1, 0, RAW>(lds, p, tid, T, tab);
     }
-    if constexpr (P > 2) { ntt_sync<W2>(); ntt_pass<LOGN, INV, MODE, 2, 0, RAW>(lds, p, tid, T, tab); }
-    if constexpr (P > 3) { ntt_sync<W3>(); ntt_pass<LOGN, INV, MODE, 3, 0, RAW>(lds, p, tid, T, tab); }
+    if constexpr (P > 2) { ntt_sync<W2>(); if constexpr (NEXTPASS == 2) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 2, 0, RAW>(lds, p, tid, T, tab); }
+    if constexpr (P > 3) { ntt_sync<W3>(); if constexpr (NEXTPASS == 3) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 3, 0, RAW>(lds, p, tid, T, tab); }
     }
     if constexpr (!INV) {                        // forward: the last pass left 16 contiguous coefficients per lane in LDS
         constexpr bool WF = WS && ntt_wave_private<LOGN, T>(P - 1);
@@ -141,6 +156,7 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
             }
         }
     }
+    if constexpr (NEXTPASS >= 0) { if (next) ntt_touch_done(sink); }
 }
 
 #endif // __HIPCC__

@@ -1,3 +1,4 @@
+#define APSU_MAC_TILED_EXPERIMENT 1
 // Stand-alone timing of the engine's k_mac on a synthetic DB, to bisect its HBM efficiency (see readbw.hip for the ceilings).
 #include "../../apsu_amd/csrc/kernels.hip"
 #include "mac_ring.hip"
@@ -121,6 +122,59 @@ int main(int argc, char** argv) {
         printf("  starts per 20 us:"); for (size_t b = 0; b < hist.size() && b < 80; b++) printf(" %d", hist[b]); printf("\n");
     }
 #endif
+    if (getenv("ORDER")) {
+        // grid orders of k_mac (what is resident behind one L2 together) and the price of the shared power loads: the same jobs with
+        // pw_stride = 0 read ONE term's powers over and over (L1 / L2 hits only; wrong sums, timing only)
+        std::vector<MacJob> jobs0 = jobs;
+        for (auto &j : jobs0) j.pw_stride = 0;
+        MacJob *dj0; CHECK(hipMalloc(&dj0, jobs0.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj0, jobs0.data(), jobs0.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+        for (int pass = 0; pass < 2; pass++)
+            for (int pw0 = 0; pw0 < 2; pw0++)
+                for (int order = 0; order < 3; order++) {
+                    std::vector<float> t;
+                    for (int rep = 0; rep < 10; rep++) {
+                        CHECK(hipEventRecord(e0)); launch_mac(lv, 3, pw0 ? dj0 : dj, n, (int)jobs.size(), 0, false, false, order); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms);
+                    }
+                    std::sort(t.begin(), t.end());
+                    printf("terms %d  order %d  %s: median %.3f ms (%.0f GB/s)\n", terms, order, pw0 ? "one term's powers (cache hits)" : "real powers                  ", t[t.size() / 2],
+                           words * 8 / (t[t.size() / 2] * 1e-3) / 1e9);
+                }
+    }
+    if (getenv("TILED")) {
+        // Is the scan bound by bytes or by the NUMBER of separate pieces it reads?  Row layout (the engine's): a workgroup's G streams
+        // are G pieces of 4 KiB (dense) / 3.5 KiB (56-bit packed) per term, each in another stream's slot.  Tiled layout: the G pieces
+        // of one (term, limb, block) adjacent -- one piece of 16 / 14 KiB per workgroup and term.  Timing only (same bytes, other sums).
+        DevLevel hp = h;
+        const u32 kbits = getenv("KBITS") ? atoi(getenv("KBITS")) : 56;
+        for (int j = 0; j < 3; j++) { hp.mac_bits[j] = kbits; hp.mac_mask_hi[j] = (1u << (kbits - 28)) - 1; hp.mac_row_off[j] = (u32)(j * n * kbits / 8); }
+        DevLevel *lvp; CHECK(hipMalloc(&lvp, sizeof(hp))); CHECK(hipMemcpy(lvp, &hp, sizeof(hp), hipMemcpyHostToDevice));
+        const size_t slot_b = 3 * n * kbits / 8;
+        std::vector<MacJob> jd = jobs, jdt = jobs, jp = jobs, jpt = jobs;
+        for (size_t x = 0; x < jobs.size(); x++) {
+            const size_t s0 = x * MAC_G;
+            jdt[x].pad = 1; jdt[x].pt_stride = (u32)(ptw * MAC_G); jdt[x].pt[0] = db + s0 * terms * ptw;
+            for (int g = 0; g < MAC_G; g++) jp[x].pt[g] = reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(db) + (s0 + g) * terms * slot_b);
+            jp[x].packed = 1; jp[x].pt_stride = (u32)slot_b;
+            jpt[x] = jp[x]; jpt[x].pad = 1; jpt[x].pt_stride = (u32)(slot_b * MAC_G); jpt[x].pt[0] = reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(db) + s0 * terms * slot_b);
+        }
+        auto upj = [&](const std::vector<MacJob> &v) { MacJob *d; if (hipMalloc(&d, v.size() * sizeof(MacJob)) != hipSuccess) abort(); if (hipMemcpy(d, v.data(), v.size() * sizeof(MacJob), hipMemcpyHostToDevice) != hipSuccess) abort(); return d; };
+        MacJob *d_jd = upj(jd), *d_jdt = upj(jdt), *d_jp = upj(jp), *d_jpt = upj(jpt);
+        const double coefs = (double)streams * terms * ptw;
+        for (int pass = 0; pass < 2; pass++)
+            for (int v = 0; v < 4; v++) {
+                const bool packed = v >= 2; MacJob *dv = v == 0 ? d_jd : v == 1 ? d_jdt : v == 2 ? d_jp : d_jpt;
+                std::vector<float> t;
+                for (int rep = 0; rep < 10; rep++) {
+                    CHECK(hipEventRecord(e0)); launch_mac(packed ? lvp : lv, 3, dv, n, (int)jobs.size(), 0, false, packed, 1); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms);
+                }
+                std::sort(t.begin(), t.end());
+                const double by = coefs * (packed ? kbits / 8.0 : 8.0), med = t[t.size() / 2];
+                printf("terms %d  %-22s %s: median %.3f ms  %.0f GB/s  %.3f Tcoef/s\n", terms, packed ? (kbits == 56 ? "packed 56 bits" : "packed") : "dense", (v & 1) ? "tiled" : "rows ", med,
+                       by / (med * 1e-3) / 1e9, coefs / (med * 1e-3) / 1e12);
+            }
+    }
     if (getenv("PERSIST")) {
         // long-lived workgroups (k_mac_p) against one workgroup per unit (k_mac): separate output, bit-compared; A B A B timing
         u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
