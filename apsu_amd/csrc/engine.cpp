@@ -88,6 +88,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
 
     const size_t n = hp_.n;
     const int nmod = (int)hp_.ntt.size();
@@ -164,6 +166,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
+        if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
         if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
         if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
         // BinBundle plaintexts bit-packed in HBM (12.5 % fewer bytes for 56-bit primes, 22 % for 50-bit ones; k_mac<.., PACKED>): in-process
@@ -416,6 +419,8 @@ Engine::~Engine()
     for (hipEvent_t e : phase_pool_) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : { query_start_, query_end_ }) if (e) (void)hipEventDestroy(e);
     if (ev_main_) (void)hipEventDestroy(ev_main_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_side_) (void)hipEventDestroy(ev_side_);
     if (stage_) (void)hipHostFree(stage_);
     if (wire_pinned_) (void)hipHostFree(wire_pinned_);
 }
@@ -2228,6 +2233,44 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     if (g.n_term) { PROF(P_MAC, (uint64_t)g.n_term * (g.term_packed ? packed_row_bits(hp_.key_q[Ll - 1]) : 64)); launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_); }
     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
+    // Side lane (round 4).  Two pieces of the evaluation hang off nothing that follows on the main stream: the sums of the
+    // coefficient-form products (they read the high powers and the database, :328-337) and the i = 0 block's finish (it reads the
+    // inverse transforms above).  Both are launches that cannot fill the chip (224 workgroups of 28-term chains; one pass over
+    // the per-term last limbs) and used to sit in the tail of the main stream, where nothing could hide them.  They run on the
+    // second stream -- behind the high-power chain, whose results the first of them needs anyway -- next to the drop / extension /
+    // transform launches, and the epilogue waits for them.
+    const bool side = eval_side_ && late_high && !prof_on_ && i0_fast && low != high && parked_.st && cur_lane_ == 0;
+    // (the i = 0 finish only while it is small: 256M-4096's reads 4 GB of per-term limbs, a bandwidth-bound pass that gains nothing
+    //  from running next to the transforms -- measured +0.9 % there, -1.2 % at 16M-4096, -4.2 % on its N = 8 shard; profiles/r04_ab_eval_side.txt)
+    const bool side_i0 = side && (size_t)Bs * l <= 4096;
+    u64 *i0_side = nullptr;
+    if (side) {
+        g.cf = ws((size_t)Bs * 2 * Lh * n);
+        if (side_i0) i0_side = ws((size_t)Bs * 2 * Lh * n);
+    }
+    bool side_ran = false;
+    auto run_side = [&]() {
+        side_ran = true;
+        std::vector<MacStream> cs;
+        cf_streams(g, cs);
+        std::vector<I0Job> ij;
+        if (side_i0)
+            for (int x = 0; x < Bs; x++)
+                ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0_side + (size_t)x * 2 * Lh * n, (int)l, 1 });
+        HIP_CHECK(hipEventRecord(ev_fork_, st_));
+        switch_lane(1);
+        struct Back { Engine *e; ~Back() { e->switch_lane(0); } } back{ this };
+        HIP_CHECK(hipStreamWaitEvent(st_, ev_fork_, 0));
+        { auto mj = group_mac(cs); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
+        d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
+        if (side_i0) launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0);
+        HIP_CHECK(hipEventRecord(ev_side_, st_));
+    };
+    // where the side lane starts: 1 = behind the inverse transforms above (next to the drop / extension / transform launches),
+    // 2 = behind the tensor-on-load transform (next to the finish and the key switch of the sums: launches that leave most of the chip idle)
+    if (side && eval_side_ == 1) run_side();
+    const bool late_cf = late_high && !side;                 // the cf sums on the main stream, behind the wait for the high powers
+
     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
     // tensor, INTT, finish (+ sum over i, :273,303).  A single drop is folded into the extension's pass.
     u64 *ext = ws((size_t)NI * 2 * Eh * n);
@@ -2263,9 +2306,9 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     const size_t w_cf = (size_t)Bs * 2 * Lh * n;
     if (summed) {
         const size_t nBskh = Eh - Lh;
-        u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_high ? w_cf : 0));
+        u64 *dq = ws((size_t)NI * 3 * Lh * n + (size_t)Bs * 3 * nBskh * n + (late_cf ? w_cf : 0));
         u64 *bsum = dq + (size_t)NI * 3 * Lh * n;
-        if (late_high) {                                    // the cf sums join this inverse-NTT launch
+        if (late_cf) {                                      // the cf sums join this inverse-NTT launch
             g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
             std::vector<MacStream> cs;
             cf_streams(g, cs);
@@ -2285,7 +2328,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         const int rawf = fast_finish(high) ? NTT_MAP_RAW : 0;
         for (size_t p = 0; p < (size_t)NI * 3; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j | rawf);
         for (size_t p = 0; p < (size_t)Bs * 3; p++) for (size_t i = 0; i < nBskh; i++) dmap.push_back(hp_.bsk_id(hlevel(high).nB, (int)i) | rawf);
-        if (late_high) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
+        if (late_cf) for (size_t p = 0; p < (size_t)Bs * 2; p++) for (size_t j = 0; j < Lh; j++) dmap.push_back((int)j);
         if (fuse_tensor_) {
             // per-term q limbs: product formed by the inverse transform's load; the Bsk sums (and cf) join the launch
             std::vector<TensorJob> pj;
@@ -2299,13 +2342,14 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             PROF(P_NTT_FUSED, dmap.size());
             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
                                tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
+            if (side && eval_side_ == 2) run_side();
         } else {
             { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
             d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
         }
         { PROFW(P_BEHZ_FINISH, ((size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh) + (size_t)Bs * 3 * Lh) * n); launch_behz_finish_sum(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), n, (int)fj.size(), st_); }
     } else {
-        if (late_high) {
+        if (late_cf) {
             g.cf = ws(w_cf);
             std::vector<MacStream> cs;
             cf_streams(g, cs);
@@ -2342,7 +2386,11 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
 
     // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
     u64 *i0 = nullptr;
-    if (i0_fast && low == high) {
+    if (side && !side_ran) run_side();                        // (paths without the fused tensor launch)
+    if (side) HIP_CHECK(hipStreamWaitEvent(st_, ev_side_, 0));
+    if (side_i0) {
+        i0 = i0_side;
+    } else if (i0_fast && low == high) {
         i0 = ssum;
     } else if (i0_fast) {
         i0 = ws((size_t)Bs * 2 * Lh * n);

@@ -268,6 +268,8 @@ private:
     int cur_lane_ = 0, overflow_lane_ = 0;
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
+    hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
+    int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded
     // run-ahead (20 queued queries = 1300 launches + 200 stream events) makes the HIP runtime block the host inside a

@@ -35,6 +35,21 @@ __global__ __launch_bounds__(T, 4) void k_plain(u64 *__restrict__ data, const Nt
     else ntt_body<LOGN, INV, NTT_WIDE, T, 0, RAW, SrcPlain, true, false, 0, NP>(lds, p, tab, threadIdx.x, nullptr, SrcPlain(), next);
 }
 
+// the two workgroups a CU holds start together and, doing equal work, stay in lockstep: their global-memory phases coincide.
+// Variant: the second resident workgroup of every CU (first generation only: blocks 256 .. 511) sleeps `shift` x 64 cycles once.
+template <bool INV, bool RAW>
+__global__ __launch_bounds__(T, 4) void k_shift(u64 *__restrict__ data, const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period, int shift)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
+    const size_t g = blockIdx.x;
+    if (g >= 256 && g < 512) for (int i = 0; i < shift; i += 100) __builtin_amdgcn_s_sleep(100);
+    const NttTable tab = tabs[modmap[g % (size_t)period]];
+    u64 *p = data + g * N;
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, RAW>(lds, p, tab, threadIdx.x);
+    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, RAW>(lds, p, tab, threadIdx.x);
+    else ntt_body<LOGN, INV, NTT_WIDE, T, 0, RAW>(lds, p, tab, threadIdx.x);
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b)); }
@@ -143,6 +158,27 @@ int main(int argc, char **argv)
         ROW("inverse, data primes", true, false, d_map_q, 3);
         ROW("inverse RAW, data primes", true, true, d_map_q, 3);
         ROW("inverse, extended base", true, false, d_map_ext, 7);
+    }
+    printf("\nphase-shifted first generation (sleep of blocks 256..511, x 64 cycles)\n");
+    const int shifts[] = { 0, 100, 200, 300, 400 };
+#define SROW(NAME, INV, RAW, MAP, PER) do { \
+        const double by = (double)count * 16 * N; \
+        printf("%-26s %6zu limbs |", NAME, count); \
+        double t0 = 0; \
+        for (int sh : shifts) { \
+            const double t1 = tm.us([&] { hipLaunchKernelGGL((k_shift<INV, RAW>), g, dim3(T), 0, 0, d_a, d_tabs, MAP, PER, sh); }, reps); \
+            if (!sh) t0 = t1; \
+            printf(" shift %3d: %7.1f us %5.0f GB/s %+5.1f %% |", sh, t1, by / t1 / 1e3, (t1 / t0 - 1) * 100); \
+        } \
+        printf("\n"); \
+    } while (0)
+    for (size_t count : sizes) {
+        if (count > big || count < 1000) continue;
+        const dim3 g((unsigned)count);
+        SROW("forward, data primes", false, false, d_map_q, 3);
+        SROW("forward, extended base", false, false, d_map_ext, 7);
+        SROW("inverse RAW, data primes", true, true, d_map_q, 3);
+        SROW("inverse, extended base", true, false, d_map_ext, 7);
     }
     printf("\nok\n");
     return 0;
