@@ -184,7 +184,7 @@ void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size
 // output job.d[3][limbs][n], coefficient form), followed by n_plain limbs at `plain` transformed in place; modmap covers both
 // xcd: grid order that puts the three workgroups of one (product, limb) pair on one XCD (they read the same operand limbs)
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd = false);
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd = false, bool lazy_in = false);
 struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
 void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)

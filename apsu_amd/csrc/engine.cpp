@@ -164,6 +164,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // in-process A/B runs, level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
         // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
         if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
+        if (const char *v = std::getenv("APSU_HE_TENSOR_LAZY")) tensor_lazy_ = std::atoi(v) != 0;   // =0: the tensor-on-load transform reduces its products to canonical residues
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
         if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
@@ -1356,7 +1357,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 }
                 if (fuse_tensor_) {                                                                                              // :422/:424
                     PROF(P_NTT_FUSED, tj.size() * 3 * Ef);
-                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_, tensor_xcd_);
+                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_, tensor_xcd_, tensor_lazy_);
                 } else {
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
@@ -2341,7 +2342,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
             PROF(P_NTT_FUSED, dmap.size());
             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
-                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_);
+                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_, tensor_lazy_);
             if (side && eval_side_ == 2) run_side();
         } else {
             { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
@@ -2374,7 +2375,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         }
         if (fuse_tensor_ && tj.size() == (size_t)NI) {
             PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
-            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_);
+            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_, tensor_lazy_);
         } else {
             if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
             d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);

@@ -315,6 +315,7 @@ private:
     bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
     bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
     bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
+    bool tensor_lazy_ = true;         // tensor-on-load inverse transforms take the fold's last word (< 4q) instead of a canonical residue (ntt_core.h, ntt_lazy_input_ok; APSU_HE_TENSOR_LAZY)
     bool tier1_device_ = false;       // tier-1 operands are device memory and calls do not synchronise
     void tier1_done() { if (!tier1_device_ || prof_on_) sync(); }
     bool packed_rows_ = true;         // BinBundle plaintexts are kept bit-packed in HBM (APSU_HE_PACKED_ROWS=0: dense 64-bit words; Bundle::packed)

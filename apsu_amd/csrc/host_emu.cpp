@@ -113,7 +113,7 @@ int emu_intt_tensor_limb(int logn, uint64_t q, const uint64_t *x0, const uint64_
         ntt_fold_params(q, tab.fold_k, tab.fold_c);
         tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
         if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return -2;
-        const SrcTensor ops{ x0, y0, x1, y1 };
+        const SrcTensor ops{ x0, y0, x1, y1, false };
 #define CASE(L) case L: emu_intt_tensor<L>(out, tab, threads, ops); break;
         switch (logn) { CASE(14) CASE(13) CASE(12) CASE(11) CASE(10) CASE(8) CASE(6) default: throw std::invalid_argument("unsupported logn"); }
 #undef CASE

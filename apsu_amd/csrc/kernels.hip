@@ -144,7 +144,7 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
 template <int LOGN, int T>
 __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
                                                    u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
-                                                   const int *__restrict__ modmap, int period, int xcd)
+                                                   const int *__restrict__ modmap, int period, int xcd, int lazy_in)
 {
     constexpr int N = 1 << LOGN;
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
@@ -184,10 +184,11 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     const int r = (int)(g - jb * per), pl = r / limbs, e = r - pl * limbs;
     const TensorJob job = jobs[jb];
     const u64 *a0 = job.a + (size_t)e * N, *a1 = a0 + src_ps, *b0 = job.b + (size_t)e * N, *b1 = b0 + src_ps;
+    const bool lazy = lazy_in && ntt_lazy_input_ok(tab, LOGN);
     SrcTensor ops;
-    if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr };
-    else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0 };
-    else ops = SrcTensor{ a1, b1, nullptr, nullptr };
+    if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr, lazy };
+    else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0, lazy };
+    else ops = SrcTensor{ a1, b1, nullptr, nullptr, lazy };
     u64 *p = job.d + (size_t)r * N;
     if (mv & NTT_MAP_RAW) {
         if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
@@ -201,13 +202,13 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
 }
 
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd)
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd, bool lazy_in)
 {
     const size_t n_tensor = (size_t)njobs * 3 * limbs;
     const size_t count = (xcd ? (n_tensor / 3 + 7) / 8 * 24 : n_tensor) + n_plain;
     if (!(n_tensor + n_plain)) return;
     const int xm = xcd ? 1 : 0;
-#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period, xm); break;
+#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period, xm, lazy_in ? 1 : 0); break;
     switch (logn) {
     T_CASE(14, 1024) T_CASE(13, 512) T_CASE(12, 256) T_CASE(11, 128) T_CASE(10, 64) T_CASE(8, 64) T_CASE(6, 64)
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);

@@ -124,12 +124,30 @@ HD u64 ntt_reduce128(u64 hi, u64 lo, const NttTable &tab)
     if (ntt_fold128_ok(tab.fold_k, tab.fold_c)) return ntt_reduce128_fold(hi, lo, tab);
     return barrett128(u128p{ lo, hi }, Mod{ tab.q, tab.r0, tab.r1 });
 }
+// The same value as the INPUT of an inverse transform, which does not need a canonical residue: the fold's last word w
+// (< 2^(k+1) + 2^56 + 2^50, i.e. below 4q) enters as it is -- the closing ntt_reduce_any (a multiply and a conditional
+// subtraction per coefficient) is left out -- when the transform's range discipline takes it: a wide modulus takes any 64-bit
+// value (csub_top), a narrow one runs without range control and needs 4q + 4 logn q < 2^64 (round 4).
+HD bool ntt_lazy_input_ok(const NttTable &tab, int logn)
+{
+    if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return false;
+    return !tab.narrow || tab.q <= ~(u64)0 / (u64)(4 * logn + 4);
+}
+HD u64 ntt_reduce128_lazy(u64 hi, u64 lo, const NttTable &tab)
+{
+    const u32 k = tab.fold_k, c = tab.fold_c, s = k - 32;
+    const u64 pl = lo & (((u64)1 << k) - 1);
+    const u64 ph = (hi << (64 - k)) | (lo >> k);
+    const u64 a = (u64)(u32)ph * c;
+    const u64 t = (u64)(u32)(ph >> 32) * c;
+    return pl + a + (u64)(u32)(t >> s) * c + ((t & (((u64)1 << s) - 1)) << 32);
+}
 
 // Where a pass that reads global memory takes its coefficients from.
 struct SrcPlain {};                                               // the limb itself
 // The dyadic tensor product of two NTT-form ciphertexts, computed on load in front of the inverse transform
 // (BEHZ step 4, d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1): value(e) = x0[e]*y0[e] (+ x1[e]*y1[e]) mod q.
-struct SrcTensor { const u64 *x0, *y0, *x1, *y1; };               // x1 == nullptr: one product
+struct SrcTensor { const u64 *x0, *y0, *x1, *y1; bool lazy; };   // x1 == nullptr: one product; lazy: ntt_lazy_input_ok for this limb
 HD u64x2 src_load2(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return *reinterpret_cast<const u64x2 *>(glob + e); }
 HD u64 src_load1(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return glob[e]; }
 HD u64x2 src_load2(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
@@ -142,15 +160,20 @@ HD u64x2 src_load2(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
         mac128(p1, u[1], v[1]);
     }
     u64x2 r;
-    r[0] = ntt_reduce128(p0.hi, p0.lo, tab);
-    r[1] = ntt_reduce128(p1.hi, p1.lo, tab);
+    if (s.lazy) {                                                 // wave-uniform
+        r[0] = ntt_reduce128_lazy(p0.hi, p0.lo, tab);
+        r[1] = ntt_reduce128_lazy(p1.hi, p1.lo, tab);
+    } else {
+        r[0] = ntt_reduce128(p0.hi, p0.lo, tab);
+        r[1] = ntt_reduce128(p1.hi, p1.lo, tab);
+    }
     return r;
 }
 HD u64 src_load1(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
 {
     u128p p = mul128(s.x0[e], s.y0[e]);
     if (s.x1) mac128(p, s.x1[e], s.y1[e]);
-    return ntt_reduce128(p.hi, p.lo, tab);
+    return s.lazy ? ntt_reduce128_lazy(p.hi, p.lo, tab) : ntt_reduce128(p.hi, p.lo, tab);
 }
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
 // makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).

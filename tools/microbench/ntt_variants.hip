@@ -58,9 +58,9 @@ __global__ __launch_bounds__(T, 4) void k_tensor(const u64 *__restrict__ A, cons
     const size_t ps = (size_t)limbs * N;
     const u64 *a0 = A + jb * 2 * ps + (size_t)e * N, *a1 = a0 + ps, *b0 = B + jb * 2 * ps + (size_t)e * N, *b1 = b0 + ps;
     SrcTensor ops;
-    if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr };
-    else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0 };
-    else ops = SrcTensor{ a1, b1, nullptr, nullptr };
+    if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr, false };
+    else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0, false };
+    else ops = SrcTensor{ a1, b1, nullptr, nullptr, false };
     u64 *p = D + g * N;
     if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcTensor, (WS > 0), false, (WS == 2 ? 12 : WS == 3 ? 40 : 0)>(lds, p, tab, threadIdx.x, nullptr, ops);
     else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcTensor, (WS > 0), false, (WS == 2 ? 12 : WS == 3 ? 40 : 0)>(lds, p, tab, threadIdx.x, nullptr, ops);
