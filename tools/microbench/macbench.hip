@@ -1,8 +1,10 @@
 #define APSU_MAC_TILED_EXPERIMENT 1
 // Stand-alone timing of the engine's k_mac on a synthetic DB, to bisect its HBM efficiency (see readbw.hip for the ceilings).
 #include "../../apsu_amd/csrc/kernels.hip"
+#ifndef MACBENCH_PLAIN      // -DMACBENCH_PLAIN: k_mac only (the ring / persistent variants are written for four streams per job)
 #include "mac_ring.hip"
 #include "mac_persist.hip"
+#endif
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -175,6 +177,7 @@ int main(int argc, char** argv) {
                        by / (med * 1e-3) / 1e9, coefs / (med * 1e-3) / 1e12);
             }
     }
+#ifndef MACBENCH_PLAIN
     if (getenv("PERSIST")) {
         // long-lived workgroups (k_mac_p) against one workgroup per unit (k_mac): separate output, bit-compared; A B A B timing
         u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
@@ -201,6 +204,7 @@ int main(int argc, char** argv) {
             CHECK(hipMemset(out2, 0, ow * 8));
         }
     }
+#endif
     if (getenv("B2B")) {
         // is part of a launch's time a fixed cost per launch?  N launches queued back to back (no host wait in between) against N x one launch
         for (int nl : { 1, 2, 4 }) {
@@ -240,6 +244,7 @@ int main(int argc, char** argv) {
         printf("three vs four products: %zu of %zu output words differ\n", bad, ow);
         if (getenv("TERMS")) return 0;
     }
+#ifndef MACBENCH_PLAIN
     if (getenv("RING")) {
         // LDS-DMA ring variant: same jobs, separate output, bit-compared with k_mac's
         u64 *out2; CHECK(hipMalloc(&out2, (size_t)streams * 2 * L * n * 8));
@@ -268,7 +273,8 @@ int main(int argc, char** argv) {
         std::sort(t.begin(), t.end());
         printf("k_mac again: min %.3f median %.3f\n", t[0], t[t.size() / 2]);
     }
-    if (!getenv("MORPH")) return 0;
+#endif
+    if (!getenv("MORPH") || MAC_G != 4) return 0;
     for (int rep = 0; rep < 2; rep++) {
 #define MORPH(M, NAME) { CHECK(hipEventRecord(e0)); hipLaunchKernelGGL((k_morph<M>), dim3(16, 3, (unsigned)jobs.size() * 2), dim3(256), 0, 0, dj, n, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep) printf("%-40s %.3f ms  %.0f GB/s\n", NAME, ms, words * 8 / (ms * 1e-3) / 1e9); }
         MORPH(0, "morph simple loop")

@@ -13,6 +13,10 @@ qs = {}
 for r in step:
     q = qs.setdefault(r["Queue_Id"], len(qs))
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    wg = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1))))
+    if "Grid_Size_X" in r:
+        wg = 1
+        for d in "XYZ": wg *= max(1, int(r["Grid_Size_" + d]) // max(1, int(r["Workgroup_Size_" + d])))
+    else:
+        wg = int(r.get("Grid_Size", 0)) // max(1, int(r.get("Workgroup_Size", 1)))
     print("%8.1f %8.1f  q%d %s%-40s wg %6d" % ((s - t0) / 1e3, (e - s) / 1e3, q, "    " * q, r["Kernel_Name"].split("(")[0].replace("void apsu_he::", "")[:40], wg))
 print("wall %.1f us" % ((max(int(r["End_Timestamp"]) for r in step) - t0) / 1e3))
