@@ -201,6 +201,29 @@ HD u64 mul_lazy4(u64 x, u64 w, u64 wq, u64 nq)
 // Lazy butterfly (x, y) -> (x + v, x - v + 4q) with v = y*w mod q in [0,4q).  The sum rides on the multiply-add
 // chain of the low product (its 64-bit addend is free), the difference is (2x + 4q) - (x + v): three 64-bit
 // add-class instructions fewer per butterfly pair than add / sub / add (64-bit adds cost as much as a multiply here).
+// Round 4 (second half): the four cross products y0 w1 + y1 w0 + h0 n1 + h1 n0 (mod 2^32) as ONE chain of four v_mad_u64_u32
+// whose 64-bit addend starts as the high word of the low product -- so the chain ends with that word already summed -- instead
+// of four v_mul_lo_u32, two adds and the 64-bit shift-add that joined them: 16.1 instead of 17.8 VALU instructions per butterfly,
+// the register-only butterfly loop 10 % faster (tools/microbench/bfly.hip, profiles/r04_bfly_mad_chain.txt).  The compiler
+// narrows the same chain written in C back to 32-bit multiplies, hence the instruction by name.  UNI: the twiddle is
+// wave-uniform (scalar registers; one scalar source per instruction is what gfx9 allows); nq always is.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APSU_NTT_NO_MAD_CHAIN)
+template <bool SB> __device__ __forceinline__ u64 ntt_mad64(u32 a, u32 b, u64 c)
+{
+    u64 d;
+    unsigned long long carry;
+    if constexpr (SB) asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    else asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+#define NTT_MAD_CHAIN 1
+#endif
+// CHAIN: where the chain pays (measured per direction, profiles/r04_ntt_mad_chain.txt); APSU_NTT_MAD_CHAIN_MODE: 1 forward passes
+// (default), 2 forward passes with wave-uniform twiddles only, 3 every pass of both directions
+#ifndef APSU_NTT_MAD_CHAIN_MODE
+#define APSU_NTT_MAD_CHAIN_MODE 1
+#endif
+template <bool UNI = false, bool CHAIN = false>
 HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
 {
     const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
@@ -208,8 +231,21 @@ HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
     const u64 h = (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);          // floor(y*wq / 2^64) - {0,1,2}
     const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
     const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
-    const u32 mid = y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
-    const u64 s = lo + ((u64)mid << 32);                           // x + v  (mod 2^64)
+    u64 s;
+#if defined(NTT_MAD_CHAIN)
+    if constexpr (CHAIN) {
+        u64 acc = lo >> 32;
+        acc = ntt_mad64<UNI>(y0, w1, acc);
+        acc = ntt_mad64<UNI>(y1, w0, acc);
+        acc = ntt_mad64<true>(h0, n1, acc);
+        acc = ntt_mad64<true>(h1, n0, acc);
+        s = (u64)(u32)lo | (acc << 32);                            // x + v  (mod 2^64)
+    } else
+#endif
+    {
+        const u32 mid = y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+        s = lo + ((u64)mid << 32);                                 // x + v  (mod 2^64)
+    }
     y = ((x << 1) + q4) - s;                                       // x - v + 4q
     x = s;
 }
@@ -389,7 +425,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                        bfly_lazy4(x, y, tv[0], tv[1], nq, q4);
+                        bfly_lazy4<false, (APSU_NTT_MAD_CHAIN_MODE == 3)>(x, y, tv[0], tv[1], nq, q4);
                     }
                     continue;
                 }
@@ -405,7 +441,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
                     if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                    bfly_lazy4(x, y, t.w, t.wq, nq, q4);
+                    bfly_lazy4<UNIFORM_TW && !PRE, (APSU_NTT_MAD_CHAIN_MODE == 2 ? (UNIFORM_TW && !PRE) : true)>(x, y, t.w, t.wq, nq, q4);
                 }
             }
         }

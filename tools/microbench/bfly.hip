@@ -59,6 +59,44 @@ HD void bfly2(u64 &x, u64 &y, u64 w, u64, const Cst &k)
     y = (x + k.q2) - v;
     x = s;
 }
+// 4: the four cross products as ONE v_mad_u64_u32 chain that accumulates straight into the high word of the low product
+//    (4 multiply-adds instead of 4 v_mul_lo_u32 + 2 adds + the 64-bit shift-add); twiddle and -q words as scalar operands
+HD u64 mad_vs(u32 a, u32 b_sgpr, u64 c)
+{
+    u64 d; unsigned long long cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b_sgpr), "v"(c));
+    return d;
+}
+HD void bfly4(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
+{
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u64 t1 = (u64)y1 * a0, t2 = (u64)y0 * a1;
+    const u64 h = (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)k.nq, n1 = (u32)(k.nq >> 32);
+    const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
+    u64 acc = lo >> 32;
+    acc = mad_vs(y0, w1, acc);
+    acc = mad_vs(y1, w0, acc);
+    acc = mad_vs(h0, n1, acc);
+    acc = mad_vs(h1, n0, acc);
+    const u64 s = (u64)(u32)lo | (acc << 32);
+    y = ((x << 1) + k.q4) - s;
+    x = s;
+}
+// 5: the same chain written in C (what the compiler makes of it)
+HD void bfly5(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
+{
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u64 t1 = (u64)y1 * a0, t2 = (u64)y0 * a1;
+    const u64 h = (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)k.nq, n1 = (u32)(k.nq >> 32);
+    const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
+    u64 acc = lo >> 32;
+    acc = (u64)y0 * w1 + acc; acc = (u64)y1 * w0 + acc; acc = (u64)h0 * n1 + acc; acc = (u64)h1 * n0 + acc;
+    const u64 s = (u64)(u32)lo | (acc << 32);
+    y = ((x << 1) + k.q4) - s;
+    x = s;
+}
 HD void bfly3(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
 {
     x = x + ((u64)((int64_t)x >> 63) & k.n4);
@@ -87,6 +125,8 @@ __global__ __launch_bounds__(512, 4) void kern(u64 *data, const u64 *tw, Cst k, 
                     if (V == 1) bfly1(x, y, w, wq, k);
                     if (V == 2) bfly2(x, y, w, wq, k);
                     if (V == 3) bfly3(x, y, w, wq, k);
+                    if (V == 4) bfly4(x, y, w, wq, k);
+                    if (V == 5) bfly5(x, y, w, wq, k);
                 }
             }
         }
@@ -141,5 +181,8 @@ int main()
     run<1>("shoup-lazy, complement add", d, dt, k);
     run<2>("fold 2^k - c (7 multiplies)", d, dt, k);
     run<3>("shoup-lazy + top-bit csub", d, dt, k);
+    run<4>("cross terms as a mad chain (asm)", d, dt, k);
+    run<5>("cross terms as a mad chain (C)", d, dt, k);
+    run<0>("shoup-lazy (k_ntt today), again", d, dt, k);
     return 0;
 }
