@@ -425,7 +425,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                        bfly_lazy4<false, (APSU_NTT_MAD_CHAIN_MODE == 3)>(x, y, tv[0], tv[1], nq, q4);
+                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
                     }
                     continue;
                 }

@@ -97,6 +97,29 @@ HD void bfly5(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
     y = ((x << 1) + k.q4) - s;
     x = s;
 }
+// 6: the chain started from zero and its low word added to the high word of the low product (no register-pair shuffling)
+HD u64 mad_vs0(u32 a, u32 b_sgpr)
+{
+    u64 d; unsigned long long cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "s"(b_sgpr));
+    return d;
+}
+HD void bfly6(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
+{
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u64 t1 = (u64)y1 * a0, t2 = (u64)y0 * a1;
+    const u64 h = (u64)y1 * a1 + (t1 >> 32) + (t2 >> 32);
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)k.nq, n1 = (u32)(k.nq >> 32);
+    const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
+    u64 acc = mad_vs0(y0, w1);
+    acc = mad_vs(y1, w0, acc);
+    acc = mad_vs(h0, n1, acc);
+    acc = mad_vs(h1, n0, acc);
+    const u32 shi = (u32)(lo >> 32) + (u32)acc;
+    const u64 s = (u64)(u32)lo | ((u64)shi << 32);
+    y = ((x << 1) + k.q4) - s;
+    x = s;
+}
 HD void bfly3(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
 {
     x = x + ((u64)((int64_t)x >> 63) & k.n4);
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(512, 4) void kern(u64 *data, const u64 *tw, Cst k, 
                     if (V == 3) bfly3(x, y, w, wq, k);
                     if (V == 4) bfly4(x, y, w, wq, k);
                     if (V == 5) bfly5(x, y, w, wq, k);
+                    if (V == 6) bfly6(x, y, w, wq, k);
                 }
             }
         }
@@ -183,6 +207,9 @@ int main()
     run<3>("shoup-lazy + top-bit csub", d, dt, k);
     run<4>("cross terms as a mad chain (asm)", d, dt, k);
     run<5>("cross terms as a mad chain (C)", d, dt, k);
+    run<6>("mad chain from zero + add (asm)", d, dt, k);
     run<0>("shoup-lazy (k_ntt today), again", d, dt, k);
+    run<4>("cross terms as a mad chain (asm), again", d, dt, k);
+    run<6>("mad chain from zero + add (asm), again", d, dt, k);
     return 0;
 }
