@@ -218,12 +218,24 @@ template <bool SB> __device__ __forceinline__ u64 ntt_mad64(u32 a, u32 b, u64 c)
 }
 #define NTT_MAD_CHAIN 1
 #endif
-// CHAIN: where the chain pays (measured per direction, profiles/r04_ntt_mad_chain.txt); APSU_NTT_MAD_CHAIN_MODE: 1 forward passes
-// (default), 2 forward passes with wave-uniform twiddles only, 3 every pass of both directions
+// where the chain pays (measured per direction, profiles/r04_ntt_mad_chain.txt); APSU_NTT_MAD_CHAIN_MODE: 1 forward passes
+// (default), 2 forward passes with wave-uniform twiddles only, 3 every pass of both directions, 4 forward as 1 + inverse with the
+// chain started from zero, 5 both directions from zero
 #ifndef APSU_NTT_MAD_CHAIN_MODE
 #define APSU_NTT_MAD_CHAIN_MODE 1
 #endif
-template <bool UNI = false, bool CHAIN = false>
+#if defined(NTT_MAD_CHAIN)
+template <bool SB> __device__ __forceinline__ u64 ntt_mul64(u32 a, u32 b)         // a * b as the head of a chain (addend 0)
+{
+    u64 d;
+    unsigned long long carry;
+    if constexpr (SB) asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+#endif
+// CHAIN: 0 the compiler's form; 1 chain on top of the low product's high word; 2 chain from zero, joined by one 64-bit shift-add
+template <bool UNI = false, int CHAIN = 0>
 HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
 {
     const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
@@ -233,7 +245,13 @@ HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
     const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
     u64 s;
 #if defined(NTT_MAD_CHAIN)
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN == 2) {
+        u64 acc = ntt_mul64<UNI>(y0, w1);
+        acc = ntt_mad64<UNI>(y1, w0, acc);
+        acc = ntt_mad64<true>(h0, n1, acc);
+        acc = ntt_mad64<true>(h1, n0, acc);
+        s = lo + (acc << 32);
+    } else if constexpr (CHAIN == 1) {
         u64 acc = lo >> 32;
         acc = ntt_mad64<UNI>(y0, w1, acc);
         acc = ntt_mad64<UNI>(y1, w0, acc);
@@ -425,7 +443,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
+                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : APSU_NTT_MAD_CHAIN_MODE >= 4 ? 2 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
                     }
                     continue;
                 }
@@ -441,7 +459,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
                     if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                    bfly_lazy4<UNIFORM_TW && !PRE, (APSU_NTT_MAD_CHAIN_MODE == 2 ? (UNIFORM_TW && !PRE) : true)>(x, y, t.w, t.wq, nq, q4);
+                    bfly_lazy4<UNIFORM_TW && !PRE, (APSU_NTT_MAD_CHAIN_MODE == 2 ? ((UNIFORM_TW && !PRE) ? 1 : 0) : APSU_NTT_MAD_CHAIN_MODE == 5 ? 2 : 1)>(x, y, t.w, t.wq, nq, q4);
                 }
             }
         }
