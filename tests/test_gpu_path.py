@@ -357,7 +357,8 @@ def test_fallback_paths_match():
     # applying its own twist instead of leaving it to the drop / mod-down kernel behind it (APSU_HE_RAW_TWIST=0); ComputePowers forced
     # onto one / two streams (APSU_HE_SPLIT=0/1); the fused tensor transform in launch order instead of its XCD-aware grid order
     # (APSU_HE_TENSOR_XCD=0); the gathered transforms with their reduce-on-load (APSU_HE_GATHER_NORED=0); the three-product k_mac forced on
-    # (APSU_HE_MAC_KARA=1); the database rows as dense 64-bit words instead of bit-packed (APSU_HE_PACKED_ROWS=0); a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte
+    # (APSU_HE_MAC_KARA=1); the database rows as dense 64-bit words instead of bit-packed (APSU_HE_PACKED_ROWS=0); the round-4 switches
+    # APSU_HE_TERM_KERNEL / APSU_HE_EVAL_SIDE / APSU_HE_TENSOR_LAZY / APSU_HE_MAC_LIMB_SLOW; a 1 MiB initial arena exercises overflow -> grow -> retry, and a 1-byte
     # workspace budget evaluates one BinBundle per chunk.  All must give the same bits; scenarios run in child processes.
     import subprocess, sys, os
     head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu_path as t\n"
@@ -369,6 +370,10 @@ def test_fallback_paths_match():
                            ({"APSU_HE_FUSE_TENSOR": "0", "APSU_HE_FUSE_EXT": "0", "APSU_HE_SPLIT": "0", "APSU_HE_RAW_TWIST": "0"}, small + big),
                            ({"APSU_HE_SPLIT": "1", "APSU_HE_TENSOR_XCD": "0", "APSU_HE_GATHER_NORED": "0", "APSU_HE_MAC_KARA": "1"}, small + big),
                            ({"APSU_HE_PACKED_ROWS": "0"}, small + big),
+                           # round 4, second half: the i = 0 block's per-term products as k_mac chains of length one, the cf sums and the
+                           # i = 0 finish on the main stream, canonical tensor products, k_mac's other grid orders, late side lane
+                           ({"APSU_HE_TERM_KERNEL": "0", "APSU_HE_EVAL_SIDE": "0", "APSU_HE_TENSOR_LAZY": "0", "APSU_HE_MAC_LIMB_SLOW": "0"}, small + big),
+                           ({"APSU_HE_EVAL_SIDE": "2", "APSU_HE_MAC_LIMB_SLOW": "2", "APSU_HE_PACKED_ROWS": "0", "APSU_HE_SPLIT": "1"}, small + big),
                            ({"APSU_HE_ARENA_BYTES": "1048576", "APSU_HE_EVAL_WS_BYTES": "1"}, small)):
         env = dict(os.environ, **switches)
         r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)
