@@ -83,7 +83,12 @@ struct Powers {
     // consumers on the main stream wait for this event first.  Null / never recorded = already ordered.
     hipEvent_t high_ready = nullptr;
     bool high_async = false;
-    ~Powers() { if (high_ready) (void)hipEventDestroy(high_ready); }
+    // recorded on the main stream behind the last evaluation that read these powers: when the buffer comes back from the pool,
+    // the second stream may start writing its high half as soon as THAT evaluation is over -- it does not have to wait for whatever
+    // else the main stream has queued since (Engine::compute_powers, early_high_)
+    mutable hipEvent_t last_use = nullptr;
+    mutable bool last_use_set = false;
+    ~Powers() { if (high_ready) (void)hipEventDestroy(high_ready); if (last_use) (void)hipEventDestroy(last_use); }
     Powers() = default;
     Powers(const Powers &) = delete;
     Powers &operator=(const Powers &) = delete;
@@ -269,6 +274,7 @@ private:
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
+    bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
     int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded
