@@ -774,7 +774,7 @@ void Engine::recycle_powers(std::unique_ptr<Powers> p)
     if (!p) return;
     // keep the most recently released buffers: a context that changes its batch shape must not be left with a pool
     // full of buffers of the old shape (every call would then allocate and free ~100 MB)
-    if (powers_pool_.size() >= 4) powers_pool_.erase(powers_pool_.begin());
+    if (powers_pool_.size() >= 4) { powers_pool_.erase(powers_pool_.begin()); if (powers_alive_ > 0) powers_alive_--; }
     powers_pool_.push_back(std::move(p));
 }
 
@@ -1450,19 +1450,30 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     const size_t need_high = s.high_powers.size() * nb * 2 * Lh_ * n * sizeof(u64);
     const size_t need_hext = s.high_powers.size() * nb * 2 * Eh_ * n * sizeof(u64);
     std::unique_ptr<Powers> pw;
-    for (size_t i = 0; i < powers_pool_.size(); i++) {
-        Powers &c = *powers_pool_[i];
-        if (c.low.bytes() == need_low && c.high.bytes() == need_high && c.hext.bytes() == need_hext) {
-            pw = std::move(powers_pool_[i]);
-            powers_pool_.erase(powers_pool_.begin() + i);
-            break;
+    // (round 4) a pooled buffer whose last reader -- the evaluation of the query in front -- is still running would make this
+    // query's second stream wait for that evaluation's end; with early_high_ the engine rather keeps TWO buffers of a shape and
+    // takes the one whose reader is done (a caller that frees its powers right after queueing the evaluation, as the reference's
+    // RunQuery does, then gets the alternation for free: 68 MB more at 16M-4096)
+    {
+        size_t fits = 0, pick = SIZE_MAX, first = SIZE_MAX;
+        for (size_t i = 0; i < powers_pool_.size(); i++) {
+            Powers &c = *powers_pool_[i];
+            if (c.low.bytes() != need_low || c.high.bytes() != need_high || c.hext.bytes() != need_hext) continue;
+            fits++;
+            if (first == SIZE_MAX) first = i;
+            if (pick == SIZE_MAX && (!early_high_ || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
+        }
+        if (pick == SIZE_MAX && (fits >= 2 || powers_alive_ >= 2)) pick = first;   // a second buffer exists already (pooled or in the caller's hands): the older pooled one
+        if (pick != SIZE_MAX) {
+            pw = std::move(powers_pool_[pick]);
+            powers_pool_.erase(powers_pool_.begin() + pick);
         }
     }
     const bool recycled = (bool)pw;
     // a pooled buffer whose high half was produced on the second stream and never consumed: the main stream must not
     // overwrite it before those kernels have finished
     if (recycled && pw->high_async && pw->high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw->high_ready, 0));
-    if (!pw) pw = std::make_unique<Powers>();
+    if (!pw) { pw = std::make_unique<Powers>(); powers_alive_++; }
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
     pw->low_level = low_target;

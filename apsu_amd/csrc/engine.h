@@ -274,6 +274,7 @@ private:
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
+    int powers_alive_ = 0;            // Powers buffers this context has created and not yet destroyed (pooled or in the caller's hands)
     bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
     int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued

@@ -287,7 +287,7 @@ def main():
                       "streams (apsu_he_set_async_results) and the clock stops after barrier + device synchronise: `value` is the "
                       "back-to-back rate, `latency_ms_sync` one query with a host wait at its end.  Queued queries overlap at ONE "
                       "place: the next query's high-power chain (second stream) starts as soon as the last reader of its powers "
-                      "buffer is done, i.e. next to the previous query's tail (APSU_HE_EARLY_HIGH=0 serialises it: +3.3 % on `value`, "
+                      "buffer is done, i.e. next to the previous query's tail (APSU_HE_EARLY_HIGH=0 serialises it: +1.7 % on `value` in the in-process A/B, "
                       "`latency_ms_sync` unchanged; profiles/r04_ab_early_high.txt)",
         "latency_ms_sync": round(latency_sync_ms, 4),
         "config": {"workload": "%s: n=%d, %d bundle indices x %d BinBundles (degrees %s), %d source -> %d target powers, "

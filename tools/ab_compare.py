@@ -15,6 +15,7 @@ ap.add_argument("--config", default="16M-4096")
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--nokeep", action="store_true", help="free each query's powers right after queueing its evaluation (bench.py's pattern) instead of holding them across the next ComputePowers")
 args = ap.parse_args()
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", args.config + ".json")).read()
 
@@ -43,6 +44,10 @@ def make(envs):
     ctx.set_async_results(True)
     keep = [None, sd, md, rk]
     def step():
+        if args.nokeep:
+            pw = ctx.compute_powers(idx, sp, rk, on_device=True)
+            ctx.eval_bundles(bl, pw, rk, mp, out=out.data_ptr(), masks_on_device=True, out_on_device=True)
+            return
         keep[0] = ctx.compute_powers(idx, sp, rk, on_device=True)
         ctx.eval_bundles(bl, keep[0], rk, mp, out=out.data_ptr(), masks_on_device=True, out_on_device=True)
     return ctx, step, out
