@@ -220,7 +220,7 @@ template <bool SB> __device__ __forceinline__ u64 ntt_mad64(u32 a, u32 b, u64 c)
 #endif
 // where the chain pays (measured per direction, profiles/r04_ntt_mad_chain.txt); APSU_NTT_MAD_CHAIN_MODE: 1 forward passes
 // (default), 2 forward passes with wave-uniform twiddles only, 3 every pass of both directions, 4 forward as 1 + inverse with the
-// chain started from zero, 5 both directions from zero
+// chain started from zero, 5 both directions from zero, 6 forward as 1 + the inverse's contiguous pass (constant twiddle indices) only
 #ifndef APSU_NTT_MAD_CHAIN_MODE
 #define APSU_NTT_MAD_CHAIN_MODE 1
 #endif
@@ -443,7 +443,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : APSU_NTT_MAD_CHAIN_MODE >= 4 ? 2 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
+                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 4 || APSU_NTT_MAD_CHAIN_MODE == 5) ? 2 : (APSU_NTT_MAD_CHAIN_MODE == 6 && !COLS && !PRE) ? 1 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
                     }
                     continue;
                 }
