@@ -220,7 +220,8 @@ template <bool SB> __device__ __forceinline__ u64 ntt_mad64(u32 a, u32 b, u64 c)
 #endif
 // where the chain pays (measured per direction, profiles/r04_ntt_mad_chain.txt); APSU_NTT_MAD_CHAIN_MODE: 1 forward passes
 // (default), 2 forward passes with wave-uniform twiddles only, 3 every pass of both directions, 4 forward as 1 + inverse with the
-// chain started from zero, 5 both directions from zero, 6 forward as 1 + the inverse's contiguous pass (constant twiddle indices) only
+// chain started from zero, 5 both directions from zero, 6 forward as 1 + the inverse's contiguous pass (constant twiddle indices) only,
+// 7 both directions with the chain in C behind opaque sums, 8 forward as 1 + inverse as 7
 #ifndef APSU_NTT_MAD_CHAIN_MODE
 #define APSU_NTT_MAD_CHAIN_MODE 1
 #endif
@@ -251,6 +252,13 @@ HD void bfly_lazy4(u64 &x, u64 &y, u64 w, u64 wq, u64 nq, u64 q4)
         acc = ntt_mad64<true>(h0, n1, acc);
         acc = ntt_mad64<true>(h1, n0, acc);
         s = lo + (acc << 32);
+    } else if constexpr (CHAIN == 3) {                           // the chain in C; an empty statement keeps every sum whole (64 bits), so the
+        u64 acc = lo >> 32;                                        // compiler takes v_mad_u64_u32 but picks registers and operand kinds itself
+        acc = (u64)y0 * w1 + acc; asm("" : "+v"(acc));
+        acc = (u64)y1 * w0 + acc; asm("" : "+v"(acc));
+        acc = (u64)h0 * n1 + acc; asm("" : "+v"(acc));
+        acc = (u64)h1 * n0 + acc; asm("" : "+v"(acc));
+        s = (u64)(u32)lo | (acc << 32);
     } else if constexpr (CHAIN == 1) {
         u64 acc = lo >> 32;
         acc = ntt_mad64<UNI>(y0, w1, acc);
@@ -443,7 +451,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 4 || APSU_NTT_MAD_CHAIN_MODE == 5) ? 2 : (APSU_NTT_MAD_CHAIN_MODE == 6 && !COLS && !PRE) ? 1 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
+                        bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 4 || APSU_NTT_MAD_CHAIN_MODE == 5) ? 2 : (APSU_NTT_MAD_CHAIN_MODE == 6 && !COLS && !PRE) ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 7 || APSU_NTT_MAD_CHAIN_MODE == 8) ? 3 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant
                     }
                     continue;
                 }
@@ -459,7 +467,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                     u64 &x = r[gg][j], &y = r[gg][j | bit];
                     if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
-                    bfly_lazy4<UNIFORM_TW && !PRE, (APSU_NTT_MAD_CHAIN_MODE == 2 ? ((UNIFORM_TW && !PRE) ? 1 : 0) : APSU_NTT_MAD_CHAIN_MODE == 5 ? 2 : 1)>(x, y, t.w, t.wq, nq, q4);
+                    bfly_lazy4<UNIFORM_TW && !PRE, (APSU_NTT_MAD_CHAIN_MODE == 2 ? ((UNIFORM_TW && !PRE) ? 1 : 0) : APSU_NTT_MAD_CHAIN_MODE == 5 ? 2 : APSU_NTT_MAD_CHAIN_MODE == 7 ? 3 : 1)>(x, y, t.w, t.wq, nq, q4);
                 }
             }
         }
