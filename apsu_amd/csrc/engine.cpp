@@ -2447,6 +2447,17 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     if (count <= 0) return;
     const size_t n = hp_.n;
     job_seq_base_ = 256;                                     // job-cache slots 256..: eval_bundles
+    // the powers' last reader (see Powers::last_use): marked on the main stream when this call leaves, also by an exception --
+    // kernels that read the powers may have been queued by then
+    struct LastUse {
+        Engine *e; const Powers &p;
+        ~LastUse()
+        {
+            if (e->cur_lane_ != 0) e->switch_lane(0);
+            if (!p.last_use && hipEventCreateWithFlags(&p.last_use, hipEventDisableTiming) != hipSuccess) { p.last_use = nullptr; p.last_use_set = false; return; }
+            p.last_use_set = hipEventRecord(p.last_use, e->st_) == hipSuccess;
+        }
+    } last_use_mark{ this, pw };
     PhaseSpan ev_span;
     if (phase_on_) { ev_span.phase = PH_PROCESS_BIN_BUNDLE_CACHE; ev_span.a = phase_event(st_); }
     const uint32_t ps = psu_.query_params.ps_low_degree, l = ps;
@@ -2531,10 +2542,6 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             else mark_inflight();
         });
     }
-    // the powers' last reader (see Powers::last_use)
-    if (!pw.last_use) HIP_CHECK(hipEventCreateWithFlags(&pw.last_use, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(pw.last_use, st_));
-    pw.last_use_set = true;
 }
 
 // ============================================================================ no key switching: ciphertexts of any size
