@@ -270,6 +270,8 @@ int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_two_stream(mode); }); }
 int apsu_he_set_async_results(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_async_results(on != 0); }); }
+int apsu_he_set_query_overlap(apsu_he_ctx *c, int on)
+{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_inputs_ready(on != 0); }); }
 int apsu_he_set_tier1_on_device(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_tier1_on_device(on != 0); }); }
 int apsu_he_sync(apsu_he_ctx *c)

@@ -167,6 +167,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_TENSOR_LAZY")) tensor_lazy_ = std::atoi(v) != 0;   // =0: the tensor-on-load transform reduces its products to canonical residues
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
+        if (const char *v = std::getenv("APSU_HE_INPUTS_READY")) inputs_ready_ = std::atoi(v) != 0;   // default of apsu_he_set_query_overlap
         if (const char *v = std::getenv("APSU_HE_EARLY_HIGH")) early_high_ = std::atoi(v) != 0;    // =0: the second stream waits for everything queued on the main stream
         if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
         if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
@@ -1461,7 +1462,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             if (c.low.bytes() != need_low || c.high.bytes() != need_high || c.hext.bytes() != need_hext) continue;
             fits++;
             if (first == SIZE_MAX) first = i;
-            if (pick == SIZE_MAX && (!early_high_ || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
+            if (pick == SIZE_MAX && (!(early_high_ && inputs_ready_) || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
         }
         if (pick == SIZE_MAX && (fits >= 2 || powers_alive_ >= 2)) pick = first;   // a second buffer exists already (pooled or in the caller's hands): the older pooled one
         if (pick != SIZE_MAX) {
@@ -1520,10 +1521,12 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             // both streams have work from the start
             DagRun rl, rh;
             const int depth = (int)std::max(sched_low_.levels.size(), sched_high_.levels.size());
-            // (round 4: with device-resident inputs the second stream waits for the LAST READER of this powers buffer -- the
+            // (round 4: with device-resident inputs that the caller has declared complete -- apsu_he_set_query_overlap; lane 1 reads
+            //  the sources and the relinearisation keys, which a caller may otherwise still be producing on the main stream -- the
+            //  second stream waits for the LAST READER of this powers buffer -- the
             //  evaluation that used it before it went back to the pool -- not for everything the main stream has queued: the next
             //  query's high-power chain then runs next to the tail of the query in front of it, whose launches leave CUs idle)
-            const bool early = early_high_ && on_device && (!recycled || pw->last_use_set);   // (a pooled buffer whose reader left no mark: wait for all)
+            const bool early = early_high_ && inputs_ready_ && on_device && (!recycled || pw->last_use_set);   // (a pooled buffer whose reader left no mark: wait for all)
             if (!early) HIP_CHECK(hipEventRecord(ev_main_, st_));
             run_dag(sched_low_, rl, 0, nb, src, on_device, rk, *pw, true, false);
             switch_lane(1);

@@ -200,6 +200,7 @@ public:
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
     // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
     void set_async_results(bool on) { std::lock_guard<std::mutex> g(mu_); async_results_ = on; }
+    void set_inputs_ready(bool on) { std::lock_guard<std::mutex> g(mu_); inputs_ready_ = on; }   // apsu_he_set_query_overlap
     // tier 1 on device-resident operands: the per-method calls take device pointers and return with their work queued on the
     // engine's stream (no host round trip per Evaluator call); see apsu_he_set_tier1_on_device
     void set_tier1_on_device(bool on) { std::lock_guard<std::mutex> g(mu_); tier1_device_ = on; }
@@ -275,6 +276,7 @@ private:
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
     int powers_alive_ = 0;            // Powers buffers this context has created and not yet destroyed (pooled or in the caller's hands)
+    bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap (APSU_HE_INPUTS_READY=1 for contexts that never call it)
     bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
     int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued

@@ -164,6 +164,7 @@ def main():
     # consecutive queries run back to back on the GPU without a host round trip in between; the collective is ordered after
     # the engine's stream with an event, and a result buffer is not refilled before the collective that read it has finished.
     ctx.set_async_results(os.environ.get("APSU_BENCH_ASYNC", "1") != "0")       # =0: every step ends with a host wait (A/B)
+    ctx.set_query_overlap(True)                                # sources and keys were uploaded and synchronised during setup
     eng_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
     buf_free = [None, None]
 

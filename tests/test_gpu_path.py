@@ -187,8 +187,11 @@ def test_device_resident_io_and_profile_hooks():
     G.close()
 
 
-def test_async_device_results():
-    """apsu_he_set_async_results: with device-resident sources, masks and results the calls return with their work queued;
+@pytest.mark.parametrize("overlap", [False, True])
+def test_async_device_results(overlap):
+    """apsu_he_set_query_overlap (second case): the next query's high-power chain may start before the query in front has finished --
+    the inputs below are complete when compute_powers is called (torch's blocking uploads), as that mode requires.
+    apsu_he_set_async_results: with device-resident sources, masks and results the calls return with their work queued;
     back-to-back queries without a host synchronisation give the bits of the synchronous path, results are complete
     after apsu_he_sync and in stream order on apsu_he_stream"""
     import torch
@@ -205,6 +208,8 @@ def test_async_device_results():
     mp = [mask_d.data_ptr() + i * G.n * 8 for i in range(len(gb))]
     want = np.stack([common.oracle_eval(S, opw, b) for b in S.bundles])
     G.set_async_results(True)
+    G.set_query_overlap(overlap)
+    torch.cuda.synchronize()
     outs = [torch.zeros((len(gb), 2, G.n), dtype=torch.int64, device="cuda") for _ in range(3)]
     srcs = []
     for k in range(6):                                     # queries back to back; every second one on zeroed sources
@@ -231,7 +236,8 @@ def test_async_device_results():
     G.close()
 
 
-def test_async_results_soak_with_changing_shapes(monkeypatch):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_async_results_soak_with_changing_shapes(monkeypatch, overlap):
     """queued-back-to-back queries whose batch shape changes every call (different BinBundle subsets and bundle-index sets:
     the job-table cache misses, the workspace arena grows, pooled powers buffers change size) under both stream policies
     give the bits of the synchronous path; nothing is waited for until the end"""
@@ -267,6 +273,7 @@ def test_async_results_soak_with_changing_shapes(monkeypatch):
         run(sub, o)
         want.append(o.cpu().numpy())
     G.set_async_results(True)
+    G.set_query_overlap(overlap)                                          # (sd / mask_d were uploaded by blocking copies)
     for split in (1, 0):
         G.set_two_stream(split)
         outs = [torch.zeros((len(sub), 2, G.n), dtype=torch.int64, device="cuda") for sub in subsets]

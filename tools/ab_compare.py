@@ -42,6 +42,7 @@ def make(envs):
     sp = [[sd.data_ptr() + ((b * ns + s) * 2 * Lf * n) * 8 for s in range(ns)] for b in idx]
     mp = [md.data_ptr() + i * n * 8 for i in range(len(mine))]
     ctx.set_async_results(True)
+    ctx.set_query_overlap(True)                                  # static, synchronised inputs
     keep = [None, sd, md, rk]
     def step():
         if args.nokeep:

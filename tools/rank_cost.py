@@ -10,6 +10,7 @@ REPEAT = int(os.environ.get("RANK_COST_REPEAT", "1"))            # > 1: that man
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", cfg + ".json")).read()
 ctx = apsu_amd.HeContext(js)
 ctx.set_async_results(True)                                     # bench.py's mode: queries queued back to back
+ctx.set_query_overlap(True)
 n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
 Lf = first + 1; D = ctx.max_items_per_bin - 1
 units = [(b, ci, deg) for b in range(ctx.bundle_idx_count) for ci, deg in enumerate(WORKLOADS[cfg]["degrees"](D))]
