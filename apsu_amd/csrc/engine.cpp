@@ -168,6 +168,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
         if (const char *v = std::getenv("APSU_HE_INPUTS_READY")) inputs_ready_ = std::atoi(v) != 0;   // default of apsu_he_set_query_overlap
+        if (const char *v = std::getenv("APSU_HE_PIPE_CP")) pipe_cp_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_EARLY_HIGH")) early_high_ = std::atoi(v) != 0;    // =0: the second stream waits for everything queued on the main stream
         if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
         if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
@@ -717,7 +718,9 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
             return reinterpret_cast<const T *>(w.buf.p());                                            // unchanged since an earlier call
         }
     counters_[C_JOB_UPLOAD]++;
-    JobWay &way = slot.way[slot.way[0].stamp <= slot.way[1].stamp ? 0 : 1];                           // least recently used
+    JobWay *lru = &slot.way[0];
+    for (JobWay &w : slot.way) if (w.stamp < lru->stamp) lru = &w;                                    // least recently used
+    JobWay &way = *lru;
     way.stamp = ++job_stamp_;
     if (way.buf.bytes() < bytes) {
         counters_[C_JOB_REALLOC]++;
@@ -775,7 +778,7 @@ void Engine::recycle_powers(std::unique_ptr<Powers> p)
     if (!p) return;
     // keep the most recently released buffers: a context that changes its batch shape must not be left with a pool
     // full of buffers of the old shape (every call would then allocate and free ~100 MB)
-    if (powers_pool_.size() >= 4) { powers_pool_.erase(powers_pool_.begin()); if (powers_alive_ > 0) powers_alive_--; }
+    if (powers_pool_.size() >= 6) { powers_pool_.erase(powers_pool_.begin()); if (powers_alive_ > 0) powers_alive_--; }
     powers_pool_.push_back(std::move(p));
 }
 
@@ -1464,7 +1467,8 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             if (first == SIZE_MAX) first = i;
             if (pick == SIZE_MAX && (!(early_high_ && inputs_ready_) || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
         }
-        if (pick == SIZE_MAX && (fits >= 2 || powers_alive_ >= 2)) pick = first;   // a second buffer exists already (pooled or in the caller's hands): the older pooled one
+        if (pick == SIZE_MAX && (fits >= 3 || !(early_high_ && inputs_ready_))) pick = first;   // three pooled ones, all busy: the oldest (else: a new buffer).
+        // (three: the host runs up to two queries ahead -- one buffer is being read, one is written or waits for its evaluation, the third takes the next query)
         if (pick != SIZE_MAX) {
             pw = std::move(powers_pool_[pick]);
             powers_pool_.erase(powers_pool_.begin() + pick);
@@ -1508,9 +1512,31 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     const bool split = split_ok_ && !prof_on_ && (split_mode < 0 || split_mode == 1);   // (host inputs are uploaded per lane and end with a sync)
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
+    // Pipelined queries (round 4; APSU_HE_PIPE_CP=0 turns it off): the WHOLE walk on the second stream -- one merged chain of
+    // launches -- next to the evaluation of the query in front, the main stream only evaluates: -2.5 % on the rate of queued
+    // 16M-4096 queries, -7.7 % on the N = 8 shard (profiles/r04_ab_pipe_cp.txt).  Needs the caller's apsu_he_set_query_overlap promise.
+    // Only while an evaluation queued earlier is still running: a query that finds the device idle takes the split walk (the merged
+    // chain is ~3 % slower for one query alone, profiles/r02_pipe_sweep.txt), a stream of queued queries takes this one.
+    bool busy = false;
+    if (pipe_cp_ && inflight_count_ > 0 && !inflight_.empty())
+        busy = hipEventQuery(inflight_[(inflight_head_ + inflight_count_ - 1) % inflight_.size()]) == hipErrorNotReady;
+    // ... and only into a buffer nobody reads any more (fresh, or its last evaluation is over): waiting for that evaluation would
+    // serialise the two streams, with the slower walk
+    const bool buffer_idle = !recycled || (pw->last_use_set && hipEventQuery(pw->last_use) == hipSuccess);
+    const bool pipe = pipe_cp_ && busy && buffer_idle && split && early_high_ && inputs_ready_ && on_device;
+    pw->low_async = pipe;
     WITH_ARENA({
         for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
-        if (!split) {
+        if (pipe) {
+            switch_lane(1);
+            if (recycled && pw->last_use_set) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
+            DagRun r;
+            run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
+            for (int d = 1; d < (int)sched_.levels.size(); d++) run_dag(sched_, r, d, nb, src, on_device, rk, *pw, true, true);
+            run_dag(sched_, r, -1, nb, src, on_device, rk, *pw, true, true);
+            HIP_CHECK(hipEventRecord(pw->high_ready, st_));
+            switch_lane(0);
+        } else if (!split) {
             DagRun r;
             run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
             for (int d = 1; d < (int)sched_.levels.size(); d++) run_dag(sched_, r, d, nb, src, on_device, rk, *pw, true, true);
@@ -2260,7 +2286,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     // the per-term last limbs) and used to sit in the tail of the main stream, where nothing could hide them.  They run on the
     // second stream -- behind the high-power chain, whose results the first of them needs anyway -- next to the drop / extension /
     // transform launches, and the epilogue waits for them.
-    const bool side = eval_side_ && late_high && !prof_on_ && i0_fast && low != high && parked_.st && cur_lane_ == 0;
+    const bool side = eval_side_ && late_high && !pw.low_async && !prof_on_ && i0_fast && low != high && parked_.st && cur_lane_ == 0;
     // (the i = 0 finish only while it is small: 256M-4096's reads 4 GB of per-term limbs, a bandwidth-bound pass that gains nothing
     //  from running next to the transforms -- measured +0.9 % there, -1.2 % at 16M-4096, -4.2 % on its N = 8 shard; profiles/r04_ab_eval_side.txt)
     const bool side_i0 = side && (size_t)Bs * l <= 4096;
@@ -2450,6 +2476,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     if (count <= 0) return;
     const size_t n = hp_.n;
     job_seq_base_ = 256;                                     // job-cache slots 256..: eval_bundles
+    if (pw.low_async && pw.high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // (APSU_HE_PIPE_CP: every power comes from the second stream)
     // the powers' last reader (see Powers::last_use): marked on the main stream when this call leaves, also by an exception --
     // kernels that read the powers may have been queued by then
     struct LastUse {

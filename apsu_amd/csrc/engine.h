@@ -83,6 +83,7 @@ struct Powers {
     // consumers on the main stream wait for this event first.  Null / never recorded = already ordered.
     hipEvent_t high_ready = nullptr;
     bool high_async = false;
+    bool low_async = false;                      // pipelined queries (Engine::compute_powers): the low powers come from the second stream too
     // recorded on the main stream behind the last evaluation that read these powers: when the buffer comes back from the pool,
     // the second stream may start writing its high half as soon as THAT evaluation is over -- it does not have to wait for whatever
     // else the main stream has queued since (Engine::compute_powers, early_high_)
@@ -277,6 +278,7 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
     int powers_alive_ = 0;            // Powers buffers this context has created and not yet destroyed (pooled or in the caller's hands)
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap (APSU_HE_INPUTS_READY=1 for contexts that never call it)
+    bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (APSU_HE_PIPE_CP)
     bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
     int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
@@ -296,7 +298,7 @@ private:
     // Two ways per slot: a caller that still holds the previous query's powers while it computes the next one alternates
     // between two powers buffers, hence between two versions of every table that names them (tools/shard_probe.py).
     struct JobWay { DevBuf buf; std::vector<unsigned char> host; uint64_t stamp = 0; };
-    struct JobSlot { JobWay way[2]; };
+    struct JobSlot { JobWay way[4]; };                  // four-way: a stream of queries cycles through up to three powers buffers (compute_powers), whose addresses are in the tables
     uint64_t job_stamp_ = 0;
     std::vector<JobSlot> job_slots_;
     size_t job_seq_ = 0, job_seq_base_ = 0;   // slots [base, ..) belong to the running top-level op

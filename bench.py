@@ -286,10 +286,10 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "step_issue": "device-resident inputs, masks and results; the K timed queries are queued back to back on the engine's "
                       "streams (apsu_he_set_async_results) and the clock stops after barrier + device synchronise: `value` is the "
-                      "back-to-back rate, `latency_ms_sync` one query with a host wait at its end.  Queued queries overlap at ONE "
-                      "place: the next query's high-power chain (second stream) starts as soon as the last reader of its powers "
-                      "buffer is done, i.e. next to the previous query's tail (APSU_HE_EARLY_HIGH=0 serialises it: +1.7 % on `value` in the in-process A/B, "
-                      "`latency_ms_sync` unchanged; profiles/r04_ab_early_high.txt)",
+                      "back-to-back rate, `latency_ms_sync` one query with a host wait at its end.  Queued queries are PIPELINED "
+                      "(apsu_he_set_query_overlap): while an evaluation is running, the next query's ComputePowers runs on the engine's "
+                      "second stream next to it and the main stream only evaluates (APSU_HE_PIPE_CP=0 APSU_HE_EARLY_HIGH=0 serialises "
+                      "the queries: +4.5 % on `value` in the in-process A/B, `latency_ms_sync` unchanged; profiles/r04_ab_pipe_cp.txt)",
         "latency_ms_sync": round(latency_sync_ms, 4),
         "config": {"workload": "%s: n=%d, %d bundle indices x %d BinBundles (degrees %s), %d source -> %d target powers, "
                                "ps_low_degree=%d" % (args.config, n, ctx.bundle_idx_count, wl["bundles_per_idx"],
