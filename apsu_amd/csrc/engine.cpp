@@ -85,7 +85,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // of the main stream (the BinBundle inner products): highest dispatch priority
         int least = 0, greatest = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&parked_.st, hipStreamNonBlocking, greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&lanes_[1].st, hipStreamNonBlocking, greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&lanes_[2].st, hipStreamNonBlocking, greatest));
     }
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -402,7 +403,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     size_t init = 4096 * n * sizeof(u64);          // 256 MiB at n = 8192; grows on demand
     if (const char *env = std::getenv("APSU_HE_ARENA_BYTES")) init = std::strtoull(env, nullptr, 10);
     arena_.alloc(init);
-    parked_.arena.alloc(std::max<size_t>(init / 4, (size_t)1 << 20));
+    lanes_[1].arena.alloc(std::max<size_t>(init / 4, (size_t)1 << 20));
+    lanes_[2].arena.alloc((size_t)1 << 20);
     stage_bytes_ = 4u << 20;
     HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
 }
@@ -414,10 +416,10 @@ Engine::~Engine()
     struct Back { bool on; int dev; ~Back() { if (on) (void)hipSetDevice(dev); } } back{ switched, cur };
     // queued work first (apsu_he_set_async_results leaves evaluations in flight), then the buffers it uses
     if (st_) (void)hipStreamSynchronize(st_);
-    if (parked_.st) (void)hipStreamSynchronize(parked_.st);
+    for (Lane &l : lanes_) if (l.st) (void)hipStreamSynchronize(l.st);
     powers_pool_.clear();
     if (st_) (void)hipStreamDestroy(st_);
-    if (parked_.st) (void)hipStreamDestroy(parked_.st);
+    for (Lane &l : lanes_) if (l.st) (void)hipStreamDestroy(l.st);
     for (hipEvent_t e : inflight_) if (e) (void)hipEventDestroy(e);
     for (PhaseSpan &sp : phase_spans_) for (hipEvent_t e : { sp.a, sp.b, sp.b2 }) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : phase_pool_) if (e) (void)hipEventDestroy(e);
@@ -448,7 +450,7 @@ void Engine::sync()
 {
     counters_[C_HOST_SYNC]++;
     HIP_CHECK(hipStreamSynchronize(st_));
-    HIP_CHECK(hipStreamSynchronize(parked_.st));
+    for (Lane &l : lanes_) if (l.st) HIP_CHECK(hipStreamSynchronize(l.st));
     if (prof_on_) prof_collect();
 }
 
@@ -461,10 +463,12 @@ void Engine::wait()
 void Engine::switch_lane(int lane)
 {
     if (lane == cur_lane_) return;
-    std::swap(st_, parked_.st);
-    std::swap(arena_, parked_.arena);
-    std::swap(arena_off_, parked_.off);
-    std::swap(job_seq_, parked_.job_seq);
+    for (Lane *l : { &lanes_[cur_lane_], &lanes_[lane] }) {      // park the current lane in its (empty) place, take the other one out of its
+        std::swap(st_, l->st);
+        std::swap(arena_, l->arena);
+        std::swap(arena_off_, l->off);
+        std::swap(job_seq_, l->job_seq);
+    }
     cur_lane_ = lane;
 }
 
@@ -473,7 +477,7 @@ void Engine::profile_enable(int mode)
 {
     Enter g(this);
     HIP_CHECK(hipStreamSynchronize(st_));
-    HIP_CHECK(hipStreamSynchronize(parked_.st));
+    for (Lane &l : lanes_) if (l.st) HIP_CHECK(hipStreamSynchronize(l.st));
     prof_collect();
     prof_on_ = mode != 0;
     prof_ntt_only_ = mode == 2;
@@ -483,7 +487,7 @@ void Engine::profile_read(ProfStats *out, bool reset)
 {
     Enter g(this);
     HIP_CHECK(hipStreamSynchronize(st_));
-    HIP_CHECK(hipStreamSynchronize(parked_.st));
+    for (Lane &l : lanes_) if (l.st) HIP_CHECK(hipStreamSynchronize(l.st));
     prof_collect();
     if (out) *out = prof_;
     if (reset) prof_ = ProfStats{};
@@ -701,8 +705,10 @@ void Engine::ws_reset(size_t need)
     switch_lane(0);
     arena_off_ = 0;
     job_seq_ = job_seq_base_;
-    parked_.off = 0;
-    parked_.job_seq = job_seq_base_ + 128;        // lane 1 uses the upper half of the call's job-cache slots
+    lanes_[1].off = 0;
+    lanes_[1].job_seq = job_seq_base_ + 128;      // lane 1 uses the upper half of the call's job-cache slots,
+    lanes_[2].off = 0;
+    lanes_[2].job_seq = job_seq_base_ + 240;      // lane 2 (a handful of tables) its last sixteen
 }
 
 template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
@@ -2283,10 +2289,11 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     // Side lane (round 4).  Two pieces of the evaluation hang off nothing that follows on the main stream: the sums of the
     // coefficient-form products (they read the high powers and the database, :328-337) and the i = 0 block's finish (it reads the
     // inverse transforms above).  Both are launches that cannot fill the chip (224 workgroups of 28-term chains; one pass over
-    // the per-term last limbs) and used to sit in the tail of the main stream, where nothing could hide them.  They run on the
-    // second stream -- behind the high-power chain, whose results the first of them needs anyway -- next to the drop / extension /
-    // transform launches, and the epilogue waits for them.
-    const bool side = eval_side_ && late_high && !pw.low_async && !prof_on_ && i0_fast && low != high && parked_.st && cur_lane_ == 0;
+    // the per-term last limbs) and used to sit in the tail of the main stream, where nothing could hide them.  They run on a
+    // third stream (lane 2; the first of them waits for the high-power chain's event) next to the drop / extension / transform
+    // launches, and the epilogue waits for them.  (With pipelined queries the next query's ComputePowers fills the same holes and the
+    // lane is level, profiles/r04_ab_eval_side.txt; it still serves a query that runs alone.)
+    const bool side = eval_side_ && late_high && !prof_on_ && i0_fast && low != high && lanes_[2].st && cur_lane_ == 0;
     // (the i = 0 finish only while it is small: 256M-4096's reads 4 GB of per-term limbs, a bandwidth-bound pass that gains nothing
     //  from running next to the transforms -- measured +0.9 % there, -1.2 % at 16M-4096, -4.2 % on its N = 8 shard; profiles/r04_ab_eval_side.txt)
     const bool side_i0 = side && (size_t)Bs * l <= 4096;
@@ -2305,9 +2312,10 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             for (int x = 0; x < Bs; x++)
                 ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0_side + (size_t)x * 2 * Lh * n, (int)l, 1 });
         HIP_CHECK(hipEventRecord(ev_fork_, st_));
-        switch_lane(1);
+        switch_lane(2);
         struct Back { Engine *e; ~Back() { e->switch_lane(0); } } back{ this };
         HIP_CHECK(hipStreamWaitEvent(st_, ev_fork_, 0));
+        if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // the cf sums read the high powers (second stream)
         { auto mj = group_mac(cs); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
         d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
         if (side_i0) launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0);

@@ -271,7 +271,8 @@ private:
     // the main chain (the high-power half of ComputePowers).  st_/arena_/arena_off_/job_seq_ always describe the
     // CURRENT lane; switch_lane() parks them and loads the other lane's, so every helper works on either.
     struct Lane { hipStream_t st = nullptr; DevBuf arena; size_t off = 0, job_seq = 0; };
-    Lane parked_;                     // the lane that is not current
+    Lane lanes_[3];                   // the lanes that are not current (the current one's state lives in st_ / arena_ / arena_off_ / job_seq_): 0 main,
+                                      // 1 second stream (high-power chain; a queued query's whole ComputePowers), 2 the evaluation's side work
     int cur_lane_ = 0, overflow_lane_ = 0;
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
