@@ -715,6 +715,10 @@ template <class T> const T *Engine::upload_jobs(const std::vector<T> &v)
 {
     if (v.empty()) return nullptr;
     const size_t bytes = v.size() * sizeof(T);
+    // lanes 1 and 2 run next to other lanes' kernels: their tables must stay inside their own slot ranges (ws_reset; a pipelined
+    // ComputePowers uses 12 of lane 1's 112)
+    if ((cur_lane_ == 1 && job_seq_ >= job_seq_base_ + 240) || (cur_lane_ == 2 && job_seq_ >= job_seq_base_ + 256))
+        throw std::logic_error("job-table slots of a side lane exhausted");
     if (job_seq_ >= job_slots_.size()) job_slots_.resize(job_seq_ + 1);
     JobSlot &slot = job_slots_[job_seq_++];
     for (JobWay &w : slot.way)
