@@ -5,6 +5,8 @@ import numpy as np, torch, apsu_amd
 from bench import SEED0
 js = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "params", "16M-4096.json")).read()
 ctx = apsu_amd.HeContext(js)
+if os.environ.get("TRACE_ASYNC", "1") != "0":
+    ctx.set_async_results(True); ctx.set_query_overlap(True)       # bench.py's mode: queued, pipelined queries
 n, t, K, first = ctx.n, ctx.t, ctx.K, ctx.first_chain_idx
 Lf = first + 1
 rng = np.random.default_rng(SEED0); ns = ctx.source_power_count
@@ -16,7 +18,7 @@ md = torch.from_numpy(rng.integers(0, t, (4, n), dtype=np.uint64).view(np.int64)
 out = torch.zeros((4, 2, n), dtype=torch.int64, device="cuda")
 sp = [[sd.data_ptr() + (s * 2 * Lf * n) * 8 for s in range(ns)]]
 mp = [md.data_ptr() + i * n * 8 for i in range(4)]
-for _ in range(6):
+for _ in range(int(os.environ.get("TRACE_STEPS", "12"))):
     pw = ctx.compute_powers([0], sp, rk, on_device=True)
     ctx.eval_bundles(bl, pw, rk, mp, out=out.data_ptr(), masks_on_device=True, out_on_device=True)
     pw = None
