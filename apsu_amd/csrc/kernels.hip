@@ -1470,6 +1470,16 @@ __device__ unsigned long long *g_mac_stamps = nullptr;
 // consecutive bits from bit 2 * bits * (k / 2) of the row, i.e. inside the 16-byte window that starts at the dword holding that
 // bit (the host picks widths for which shift + 2 * bits <= 128 everywhere); the window is shifted down by the lane's bit offset
 // with funnel shifts and the operand halves are cut out of it.  Fewer HBM bytes per term, the same number of load instructions.
+// Kept sums (round 4): an empty assembly statement on every partial sum of k_mac's inner loop.  Without it the compiler pairs two
+// products first (v_mad_u64_u32 with a zero addend, then one with the first product as addend) and adds the pair to the running sum
+// with a separate 64-bit add; with it every product is ONE v_mad_u64_u32 whose addend is the sum: 283 instead of 315 VALU instructions
+// per two terms, -2.2 % on the 16M-4096 query (the cycles go to the next query's ComputePowers, which runs next to the scan;
+// profiles/r04_ab_mac_kept_sums.txt).  APSU_MAC_NO_KEEP restores the compiler's form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APSU_MAC_NO_KEEP)
+#define MAC_KEEP(v) asm("" : "+v"(v))
+#else
+#define MAC_KEEP(v) do { } while (0)
+#endif
 #ifndef APSU_MAC_MINWAVES
 #define APSU_MAC_MINWAVES 1                                        // waves per SIMD the register allocation must allow (experiment switch)
 #endif
@@ -1605,13 +1615,15 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
                 const u32 alo = (u32)av[c] & lomask, ahi = PACKED ? ((u32)(av[c] >> s) & himask) : (u32)(av[c] >> s);
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    s00[g][c][p] += (u64)alo * clo[p][c];
-                    if (KARA) sx[g][c][p] += (u64)(alo + ahi) * csum[p][c];
+                    // (MAC_KEEP: an empty statement on every sum keeps the compiler from pairing two products first and adding the pair
+                    //  to the sum with a separate 64-bit add: one v_mad_u64_u32 per product and nothing else)
+                    s00[g][c][p] += (u64)alo * clo[p][c]; MAC_KEEP(s00[g][c][p]);
+                    if (KARA) { sx[g][c][p] += (u64)(alo + ahi) * csum[p][c]; MAC_KEEP(sx[g][c][p]); }
                     else {
-                        sx[g][c][p] += (u64)alo * chi[p][c];
-                        sx[g][c][p] += (u64)ahi * clo[p][c];
+                        sx[g][c][p] += (u64)alo * chi[p][c]; MAC_KEEP(sx[g][c][p]);
+                        sx[g][c][p] += (u64)ahi * clo[p][c]; MAC_KEEP(sx[g][c][p]);
                     }
-                    s11[g][c][p] += (u64)ahi * chi[p][c];
+                    s11[g][c][p] += (u64)ahi * chi[p][c]; MAC_KEEP(s11[g][c][p]);
                 }
             }
         }
