@@ -1210,6 +1210,14 @@ __global__ __launch_bounds__(EW_T) void k_behz_finish(const DevLevel *__restrict
 // Fully unrolled variant for L = nB = TL <= 3 with Shoup-form matrices (same values as behz_finish_coeff).
 // dq / dbsk come from an inverse NTT that left out its twist (NTT_MAP_RAW): raw lazy values, any 64-bit number; the twist
 // is part of the per-position constants fin_q / fin_b (kidx = coefficient index).
+// The level constants of the unrolled finish (four conversion rows of Shoup pairs, ...) are ~100 scalar registers when the compiler
+// hoists every load to the top of the kernel: it then spills scalar registers into vector lanes (v_writelane / v_readlane, 16 % of
+// the instructions of k_behz_finish2<3>).  A compiler-level memory fence per output row keeps each row's loads next to their use.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(APSU_FIN_NO_FENCE)
+#define FIN_LOAD_FENCE() asm volatile("" ::: "memory")
+#else
+#define FIN_LOAD_FENCE() do { } while (0)
+#endif
 template <int TL>
 __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ lv, const u64 *__restrict__ dq, size_t term_stride,
                                                    int terms, const u64 *__restrict__ dbsk, size_t n, u64 *res, size_t kidx)
@@ -1230,6 +1238,7 @@ __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ 
     u64 fl_sk = 0;
 #pragma unroll
     for (int i = 0; i < nBsk; i++) {
+        FIN_LOAD_FENCE();
         const u64 m = lv->bsk[i].q;
         u64 conv = 0;                                            // < 2 L m
 #pragma unroll
@@ -1249,6 +1258,7 @@ __device__ __forceinline__ void behz_finish_coeff2(const DevLevel *__restrict__ 
     const u64 a_abs = neg ? msk - alpha : alpha;
 #pragma unroll
     for (int j = 0; j < L; j++) {
+        FIN_LOAD_FENCE();
         const u64 q = lv->q[j].q;
         u64 z = lazy2(a_abs, neg ? lv->s_prod_B_q[j] : lv->s_neg_prod_B_q[j], q);       // < (2 nB + 2) q <= 8 q
 #pragma unroll
