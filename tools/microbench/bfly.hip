@@ -139,6 +139,25 @@ HD void bfly7(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
     y = ((x << 1) + k.q4) - s;
     x = s;
 }
+// 8: variant 7 + the second high word joined by a multiply-add with an opaque factor 1 (one instruction instead of a move and a 64-bit add)
+HD void bfly8(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
+{
+    const u32 y0 = (u32)y, y1 = (u32)(y >> 32), a0 = (u32)wq, a1 = (u32)(wq >> 32);
+    const u32 t1h = (u32)(((u64)y1 * a0) >> 32), t2h = (u32)(((u64)y0 * a1) >> 32);
+    u32 one = 1; asm("" : "+v"(one));
+    u64 h = (u64)y1 * a1 + t1h; OPAQUE64(h);
+    h = (u64)t2h * one + h; OPAQUE64(h);
+    const u32 h0 = (u32)h, h1 = (u32)(h >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)k.nq, n1 = (u32)(k.nq >> 32);
+    const u64 lo = (u64)h0 * n0 + ((u64)y0 * w0 + x);
+    u64 acc = lo >> 32;
+    acc = (u64)y0 * w1 + acc; OPAQUE64(acc);
+    acc = (u64)y1 * w0 + acc; OPAQUE64(acc);
+    acc = (u64)h0 * n1 + acc; OPAQUE64(acc);
+    acc = (u64)h1 * n0 + acc; OPAQUE64(acc);
+    const u64 s = (u64)(u32)lo | (acc << 32);
+    y = ((x << 1) + k.q4) - s;
+    x = s;
+}
 HD void bfly3(u64 &x, u64 &y, u64 w, u64 wq, const Cst &k)
 {
     x = x + ((u64)((int64_t)x >> 63) & k.n4);
@@ -171,6 +190,7 @@ __global__ __launch_bounds__(512, 4) void kern(u64 *data, const u64 *tw, Cst k, 
                     if (V == 5) bfly5(x, y, w, wq, k);
                     if (V == 6) bfly6(x, y, w, wq, k);
                     if (V == 7) bfly7(x, y, w, wq, k);
+                    if (V == 8) bfly8(x, y, w, wq, k);
                 }
             }
         }
@@ -235,5 +255,8 @@ int main()
     run<0>("shoup-lazy (k_ntt today), once more", d, dt, k);
     run<7>("mad chain in C behind opaque sums, again", d, dt, k);
     run<4>("cross terms as a mad chain (asm), once more", d, dt, k);
+    run<8>("variant 7 + high words joined by a mad", d, dt, k);
+    run<7>("mad chain in C behind opaque sums, third", d, dt, k);
+    run<8>("variant 7 + high words joined by a mad, again", d, dt, k);
     return 0;
 }
