@@ -357,10 +357,11 @@ def main():
             "achieved_actual_bytes": round(f_actual, 1), "frac_actual_bytes": round(f_actual / HBM_PEAK_GBS, 4),
             "note": "achieved / frac count 16 n bytes per limb like a plain transform; *_actual_bytes count the operand limbs the load "
                     "really reads (served by L2 / Infinity Cache, an upper bound when the launch also carries plain limbs)"}
-        result["roofline"]["note"] = ("the transform is instruction-issue bound, not HBM-bound: 9 integer multiplies + 6 sixty-four-bit add-class "
-                                      "instructions per butterfly at 4.6-5.4 cycles each (profiles/r01_intmul_microbench.txt), VALU busy 80-83 % "
-                                      "at 2.05 GHz (profiles/r03_ntt_pmc.txt; round 4 see profiles/r04_ntt_pmc.txt), HBM traffic 1.05x "
-                                      "algorithmic; a butterfly-only kernel would reach 4.9 TB/s = 0.61 (profiles/r02_bfly_microbench.txt). "
+        result["roofline"]["note"] = ("the transform is instruction-issue bound, not HBM-bound: 9 integer multiplies + 64-bit add-class instructions "
+                                      "per butterfly at 4.6-5.4 cycles each (profiles/r01_intmul_microbench.txt); round 4: 18.7 (forward, its cross "
+                                      "products as one v_mad_u64_u32 chain) / 21.6 (inverse with twist) VALU instructions per butterfly, VALU busy "
+                                      "83 / 80 % at 2.05 GHz (profiles/r04_ntt_pmc.txt), HBM traffic 1.04x algorithmic; the forward butterfly alone in "
+                                      "registers would reach 6.3 TB/s = 0.79 (profiles/r04_bfly_mad_chain.txt). "
                                       "In-path launches are mostly Infinity-Cache resident and 13 of 15 are below 2 000 limbs (launch-round bound); "
                                       "see ntt_stream for >= 1 GiB batches")
         result["roofline"]["all_transforms"] = {"achieved": round(a_ach, 1), "frac": round(a_ach / HBM_PEAK_GBS, 4),
