@@ -788,7 +788,7 @@ void Engine::recycle_powers(std::unique_ptr<Powers> p)
     if (!p) return;
     // keep the most recently released buffers: a context that changes its batch shape must not be left with a pool
     // full of buffers of the old shape (every call would then allocate and free ~100 MB)
-    if (powers_pool_.size() >= 6) { powers_pool_.erase(powers_pool_.begin()); if (powers_alive_ > 0) powers_alive_--; }
+    if (powers_pool_.size() >= 6) powers_pool_.erase(powers_pool_.begin());
     powers_pool_.push_back(std::move(p));
 }
 
@@ -1488,7 +1488,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // a pooled buffer whose high half was produced on the second stream and never consumed: the main stream must not
     // overwrite it before those kernels have finished
     if (recycled && pw->high_async && pw->high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw->high_ready, 0));
-    if (!pw) { pw = std::make_unique<Powers>(); powers_alive_++; }
+    if (!pw) pw = std::make_unique<Powers>();
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
     pw->low_level = low_target;

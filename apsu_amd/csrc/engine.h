@@ -277,7 +277,6 @@ private:
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
-    int powers_alive_ = 0;            // Powers buffers this context has created and not yet destroyed (pooled or in the caller's hands)
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap (APSU_HE_INPUTS_READY=1 for contexts that never call it)
     bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (APSU_HE_PIPE_CP)
     bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
