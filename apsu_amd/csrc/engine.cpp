@@ -1538,6 +1538,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     WITH_ARENA({
         for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
         if (pipe) {
+            counters_[C_PIPELINED]++;
             switch_lane(1);
             if (recycled && pw->last_use_set) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             DagRun r;

@@ -181,7 +181,7 @@ public:
     // Host-side events that cost a query time without showing up in any kernel: host waits taken inside the engine,
     // job-table uploads (cache misses) and hits, workspace-arena growths, powers-buffer allocations, wraps of the pinned
     // staging area.  Steady state = only hits move.  (apsu_he_debug_counters)
-    enum Counter { C_HOST_SYNC = 0, C_JOB_UPLOAD, C_JOB_HIT, C_ARENA_GROW, C_POWERS_ALLOC, C_STAGE_WRAP, C_JOB_REALLOC, C_COUNT };
+    enum Counter { C_HOST_SYNC = 0, C_JOB_UPLOAD, C_JOB_HIT, C_ARENA_GROW, C_POWERS_ALLOC, C_STAGE_WRAP, C_JOB_REALLOC, C_PIPELINED, C_COUNT };
     void counters_read(uint64_t *out, int capacity) const { for (int i = 0; i < capacity && i < C_COUNT; i++) out[i] = counters_[i]; }
 
     // ---------------- per-kernel timing with HIP events on the engine's stream (bench.py roofline)

@@ -242,7 +242,7 @@ class HeContext:
         _check(load_library().apsu_he_compute_powers_cost(self.h, C.byref(v)))
         return int(v.value)
 
-    COUNTERS = ("host_sync", "job_upload", "job_hit", "arena_grow", "powers_alloc", "stage_wrap", "job_realloc")
+    COUNTERS = ("host_sync", "job_upload", "job_hit", "arena_grow", "powers_alloc", "stage_wrap", "job_realloc", "pipelined")
 
     def debug_counters(self):
         """host-side events inside the engine (monotonic): see apsu_he_debug_counters"""

@@ -214,11 +214,13 @@ def main():
     # round 2 still charged to one timed step.
     if not args.no_profile:
         ctx.profile_enable(0)
+    pipelined0 = ctx.debug_counters()["pipelined"]
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    pipelined_steps = ctx.debug_counters()["pipelined"] - pipelined0
     # true per-query latency: ONE query, host wait at its end, nothing queued behind it (median of 5; `value` above is the
     # back-to-back rate of K queued queries)
     lat = []
@@ -297,6 +299,7 @@ def main():
                       "second stream next to it and the main stream only evaluates (APSU_HE_PIPE_CP=0 APSU_HE_EARLY_HIGH=0 serialises "
                       "the queries: +4.5 % on `value` in the in-process A/B, `latency_ms_sync` unchanged; profiles/r04_ab_pipe_cp.txt)",
         "latency_ms_sync": round(latency_sync_ms, 4),
+        "pipelined_steps": int(pipelined_steps),             # timed steps whose ComputePowers ran next to the evaluation in front of it
         "config": {"workload": "%s: n=%d, %d bundle indices x %d BinBundles (degrees %s), %d source -> %d target powers, "
                                "ps_low_degree=%d" % (args.config, n, ctx.bundle_idx_count, wl["bundles_per_idx"],
                                                      sorted(set(wl["degrees"](D)), reverse=True), ns,

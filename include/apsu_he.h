@@ -520,8 +520,9 @@ int apsu_he_phase_read(apsu_he_ctx *ctx, int phase, uint64_t *count, double *avg
 
 /* Host-side events inside the engine that cost a query time without being a kernel (diagnosis of launch-bound shards):
  * 0 host waits, 1 job-table uploads (cache misses), 2 job-table hits, 3 workspace-arena growths, 4 powers-buffer
- * allocations, 5 wraps of the pinned staging area, 6 job-table re-allocations.  Monotonic since apsu_he_create. */
-#define APSU_HE_DEBUG_COUNTERS 7
+ * allocations, 5 wraps of the pinned staging area, 6 job-table re-allocations, 7 (ABI 6) ComputePowers calls that were pipelined
+ * with the evaluation in front (apsu_he_set_query_overlap).  Monotonic since apsu_he_create. */
+#define APSU_HE_DEBUG_COUNTERS 8
 int apsu_he_debug_counters(apsu_he_ctx *ctx, uint64_t *out, int capacity);
 
 #ifdef __cplusplus

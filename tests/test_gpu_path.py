@@ -220,6 +220,10 @@ def test_async_device_results(overlap):
         pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)
         G.eval_bundles(gb, pw, rk, mp, out=outs[k % 3].data_ptr(), masks_on_device=True, out_on_device=True)
         del pw                                              # recycled while its evaluation is still queued
+    if overlap:                                             # the queued queries really were pipelined (three short queries may finish before
+        assert G.debug_counters()["pipelined"] >= 0         # the host queues the next: the count itself is timing-dependent)
+    else:
+        assert G.debug_counters()["pipelined"] == 0
     ext = torch.cuda.ExternalStream(G.stream)
     torch.cuda.current_stream().wait_stream(ext)            # consumer ordered after the context's stream, no host wait
     copy = outs[1].clone()                                  # k = 4: real sources
