@@ -271,7 +271,7 @@ int apsu_he_set_two_stream(apsu_he_ctx *c, int mode)
 int apsu_he_set_async_results(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_async_results(on != 0); }); }
 int apsu_he_set_query_overlap(apsu_he_ctx *c, int on)
-{ return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_inputs_ready(on != 0); }); }
+{ return guarded([&] { REQUIRE(c, "null argument"); if (on < 0 || on > 3) throw std::invalid_argument("apsu_he_set_query_overlap: mode must be 0 .. 3"); c->eng->set_query_overlap(on); }); }
 int apsu_he_set_tier1_on_device(apsu_he_ctx *c, int on)
 { return guarded([&] { REQUIRE(c, "null argument"); c->eng->set_tier1_on_device(on != 0); }); }
 int apsu_he_sync(apsu_he_ctx *c)
@@ -1102,6 +1102,17 @@ int apsu_he_seal_relin_keys_save(const apsu_he_seal_ctx *c, const uint64_t *ksk,
 namespace {
 // The query of one request, decoded onto engine E's device: relinearisation keys in apsu_he_relin_upload's layout (empty without
 // key switching) and the source ciphertexts of the bundle indices `idx`, in (index, ascending exponent) order.
+// seal::is_data_valid_for: every word of limb j of every polynomial is below q_j
+static void check_residues(const u64 *data, size_t polys, const u64 *q, size_t limbs, size_t n, const char *what)
+{
+    for (size_t p = 0; p < polys; p++)
+        for (size_t j = 0; j < limbs; j++) {
+            const u64 *row = data + (p * limbs + j) * n, qj = q[j];
+            u64 bad = 0;
+            for (size_t k = 0; k < n; k++) bad |= (u64)(row[k] >= qj);
+            if (bad) throw std::invalid_argument(what);
+        }
+}
 struct DecodedQuery {
     std::vector<uint64_t> relin_flat;
     // seeded RelinKeys left for the device to expand (keys_on_device): c1 of key d sits at word key_c1_at[i] of relin_flat / of the uploaded keys
@@ -1150,6 +1161,9 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
             const sealio::KSwitchKeys kk = sealio::load_kswitch_keys(q.relin_keys.p, q.relin_keys.n, sc->chain, nullptr, !keys_on_device);
             if (std::memcmp(kk.parms_id, sc->chain[0].parms_id, 32)) throw std::invalid_argument("RelinKeys were generated for other encryption parameters");
             out.relin_flat = sealio::relin_keys_layout(kk, sc->K, n);
+            // (is_valid_for on the keys as well; a seeded entry's c1 is still zero here and sampled below [0, q) by construction)
+            for (size_t d = 0; d + 1 < sc->K; d++)
+                check_residues(out.relin_flat.data() + d * 2 * sc->K * n, 2, hp.key_q.data(), sc->K, n, "RelinKeys hold a coefficient outside [0, q)");
             if (keys_on_device && !kk.keys.empty())
                 for (size_t d = 0; d < kk.keys[0].size(); d++)
                     if (kk.keys[0][d].seeded) {
@@ -1166,6 +1180,9 @@ void decode_query(Engine &E, const apsu_he_seal_ctx *sc, const uint8_t *request,
         if (std::memcmp(ct.parms_id, seal_level(sc, first).parms_id, 32) || ct.size != 2 || ct.is_ntt_form || ct.poly_modulus_degree != n ||
             ct.coeff_modulus_size != Lf || ct.data.size() != ct_words)
             throw std::invalid_argument("query ciphertext is not a fresh size-2 ciphertext at the first data level");
+        // ... and every coefficient a canonical residue of its limb's prime (seal::is_data_valid_for, part of is_valid_for): the engine's
+        // lazy transforms take source limbs as they are (Engine::run_dag, ntt_gather_nored_ok), a word >= q_j would overflow their range
+        check_residues(ct.data.data(), ct.seeded ? 1 : 2, hp.key_q.data(), Lf, n, "query ciphertext holds a coefficient outside [0, q)");
         std::memcpy(host + k * ct_words, ct.data.data(), (ct.seeded ? ct_words / 2 : ct_words) * sizeof(u64));
         seeded[k] = ct.seeded ? 1 : 0;
         if (ct.seeded) std::memcpy(&seed_of[k * 8], ct.seed, 64);

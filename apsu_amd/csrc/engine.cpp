@@ -168,9 +168,6 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_TENSOR_LAZY")) tensor_lazy_ = std::atoi(v) != 0;   // =0: the tensor-on-load transform reduces its products to canonical residues
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
         if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
-        if (const char *v = std::getenv("APSU_HE_INPUTS_READY")) inputs_ready_ = std::atoi(v) != 0;   // default of apsu_he_set_query_overlap
-        if (const char *v = std::getenv("APSU_HE_PIPE_CP")) pipe_cp_ = std::atoi(v) != 0;
-        if (const char *v = std::getenv("APSU_HE_EARLY_HIGH")) early_high_ = std::atoi(v) != 0;    // =0: the second stream waits for everything queued on the main stream
         if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
         if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
         if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
@@ -1465,7 +1462,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     const size_t need_hext = s.high_powers.size() * nb * 2 * Eh_ * n * sizeof(u64);
     std::unique_ptr<Powers> pw;
     // (round 4) a pooled buffer whose last reader -- the evaluation of the query in front -- is still running would make this
-    // query's second stream wait for that evaluation's end; with early_high_ the engine rather keeps TWO buffers of a shape and
+    // query's second stream wait for that evaluation's end; with the caller's overlap promise the engine rather keeps TWO buffers of a shape and
     // takes the one whose reader is done (a caller that frees its powers right after queueing the evaluation, as the reference's
     // RunQuery does, then gets the alternation for free: 68 MB more at 16M-4096)
     {
@@ -1475,9 +1472,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             if (c.low.bytes() != need_low || c.high.bytes() != need_high || c.hext.bytes() != need_hext) continue;
             fits++;
             if (first == SIZE_MAX) first = i;
-            if (pick == SIZE_MAX && (!(early_high_ && inputs_ready_) || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
+            if (pick == SIZE_MAX && (!inputs_ready_ || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
         }
-        if (pick == SIZE_MAX && (fits >= 3 || !(early_high_ && inputs_ready_))) pick = first;   // three pooled ones, all busy: the oldest (else: a new buffer).
+        if (pick == SIZE_MAX && (fits >= 3 || !inputs_ready_)) pick = first;   // three pooled ones, all busy: the oldest (else: a new buffer).
         // (three: the host runs up to two queries ahead -- one buffer is being read, one is written or waits for its evaluation, the third takes the next query)
         if (pick != SIZE_MAX) {
             pw = std::move(powers_pool_[pick]);
@@ -1532,15 +1529,22 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         busy = hipEventQuery(inflight_[(inflight_head_ + inflight_count_ - 1) % inflight_.size()]) == hipErrorNotReady;
     // ... and only into a buffer nobody reads any more (fresh, or its last evaluation is over): waiting for that evaluation would
     // serialise the two streams, with the slower walk
-    const bool buffer_idle = !recycled || (pw->last_use_set && hipEventQuery(pw->last_use) == hipSuccess);
-    const bool pipe = pipe_cp_ && busy && buffer_idle && split && early_high_ && inputs_ready_ && on_device;
+    // A pooled buffer is ordered behind its LAST READER only when an evaluation has read it since it was last written: `last_use`
+    // is consumed here (had_last_use) and set again by eval_bundles alone.  A buffer that was computed and given back without an
+    // evaluation (an error path, a caller that drops a query) keeps no mark: its writers may still be queued on EITHER stream, so
+    // it takes the conservative order -- no pipelined walk, the second stream behind everything on the main stream (ev_main_), the
+    // main stream behind the second stream's last writer (high_ready, above).
+    const bool had_last_use = recycled && pw->last_use_set;
+    const bool buffer_known = !recycled || had_last_use;
+    const bool buffer_idle = !recycled || (had_last_use && hipEventQuery(pw->last_use) == hipSuccess);
+    const bool pipe = pipe_cp_ && (busy || force_pipe_) && (buffer_idle || (force_pipe_ && buffer_known)) && split && inputs_ready_ && on_device;
     pw->low_async = pipe;
     WITH_ARENA({
         for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
         if (pipe) {
             counters_[C_PIPELINED]++;
             switch_lane(1);
-            if (recycled && pw->last_use_set) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
+            if (had_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             DagRun r;
             run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
             for (int d = 1; d < (int)sched_.levels.size(); d++) run_dag(sched_, r, d, nb, src, on_device, rk, *pw, true, true);
@@ -1563,12 +1567,12 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             //  second stream waits for the LAST READER of this powers buffer -- the
             //  evaluation that used it before it went back to the pool -- not for everything the main stream has queued: the next
             //  query's high-power chain then runs next to the tail of the query in front of it, whose launches leave CUs idle)
-            const bool early = early_high_ && inputs_ready_ && on_device && (!recycled || pw->last_use_set);   // (a pooled buffer whose reader left no mark: wait for all)
+            const bool early = inputs_ready_ && on_device && buffer_known;   // (a pooled buffer whose reader left no mark: wait for all)
             if (!early) HIP_CHECK(hipEventRecord(ev_main_, st_));
             run_dag(sched_low_, rl, 0, nb, src, on_device, rk, *pw, true, false);
             switch_lane(1);
             if (!early) HIP_CHECK(hipStreamWaitEvent(st_, ev_main_, 0));
-            else if (recycled && pw->last_use_set) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
+            else if (had_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             run_dag(sched_high_, rh, 0, nb, src, on_device, rk, *pw, false, true);
             for (int d = 1; d < depth; d++) {
                 switch_lane(0);
@@ -1592,6 +1596,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         if (!on_device) sync();
     });
     if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
+    pw->last_use_set = false;                               // consumed above; only an evaluation of THESE powers sets it again
     return pw;
 }
 
@@ -2755,6 +2760,7 @@ std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indice
         sync();                                              // the workspace is reused by the next call; nothing here is latency-critical
     });
     if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
+    pw->last_use_set = false;                               // consumed above; only an evaluation of THESE powers sets it again
     return pw;
 }
 

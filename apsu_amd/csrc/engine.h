@@ -86,7 +86,7 @@ struct Powers {
     bool low_async = false;                      // pipelined queries (Engine::compute_powers): the low powers come from the second stream too
     // recorded on the main stream behind the last evaluation that read these powers: when the buffer comes back from the pool,
     // the second stream may start writing its high half as soon as THAT evaluation is over -- it does not have to wait for whatever
-    // else the main stream has queued since (Engine::compute_powers, early_high_)
+    // else the main stream has queued since (Engine::compute_powers, inputs_ready_)
     mutable hipEvent_t last_use = nullptr;
     mutable bool last_use_set = false;
     ~Powers() { if (high_ready) (void)hipEventDestroy(high_ready); if (last_use) (void)hipEventDestroy(last_use); }
@@ -201,7 +201,17 @@ public:
     void set_two_stream(int mode) { std::lock_guard<std::mutex> g(mu_); two_stream_mode_ = mode < 0 ? -1 : (mode ? 1 : 0); }
     // device-resident evaluation results without the closing stream synchronisation (see apsu_he_set_async_results)
     void set_async_results(bool on) { std::lock_guard<std::mutex> g(mu_); async_results_ = on; }
-    void set_inputs_ready(bool on) { std::lock_guard<std::mutex> g(mu_); inputs_ready_ = on; }   // apsu_he_set_query_overlap
+    // apsu_he_set_query_overlap.  0: off (the second stream waits for everything the main stream has queued).  1: the caller's inputs are
+    // complete at call time -- the second stream waits only for the last reader of the powers buffer it reuses, and a ComputePowers
+    // that finds an evaluation still running takes the pipelined walk.  2: as 1 without the pipelined walk.  3: as 1 with the
+    // pipelined walk taken whether or not the device is busy (tests: the walk's event chain is then exercised deterministically).
+    void set_query_overlap(int mode)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        inputs_ready_ = mode != 0;
+        pipe_cp_ = mode == 1 || mode == 3;
+        force_pipe_ = mode == 3;
+    }
     // tier 1 on device-resident operands: the per-method calls take device pointers and return with their work queued on the
     // engine's stream (no host round trip per Evaluator call); see apsu_he_set_tier1_on_device
     void set_tier1_on_device(bool on) { std::lock_guard<std::mutex> g(mu_); tier1_device_ = on; }
@@ -277,9 +287,9 @@ private:
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
     hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
-    bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap (APSU_HE_INPUTS_READY=1 for contexts that never call it)
-    bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (APSU_HE_PIPE_CP)
-    bool early_high_ = true;          // two-stream ComputePowers: the high-power chain waits for the last reader of its buffer only (APSU_HE_EARLY_HIGH)
+    bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap: the second stream then waits for the last reader of its powers buffer only
+    bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (set_query_overlap 1 / 3)
+    bool force_pipe_ = false;         // ... whether or not an evaluation is still running (set_query_overlap 3)
     int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded

@@ -410,11 +410,11 @@ class HeContext:
         """eval_bundles with device-resident masks and output returns once its work is queued; see sync() / stream"""
         _check(load_library().apsu_he_set_async_results(self.h, int(bool(on))))
 
-    def set_query_overlap(self, on):
+    def set_query_overlap(self, mode):
         """apsu_he_set_query_overlap: the device-resident inputs of compute_powers are complete when it is called (not produced by
-        work queued on the context's stream), so consecutive queued queries may overlap (the next query's high-power chain next to
-        this query's tail)"""
-        _check(load_library().apsu_he_set_query_overlap(self.h, int(bool(on))))
+        work queued on the context's stream), so consecutive queued queries may overlap.  False / 0 off, True / 1 on, 2 on without
+        the pipelined walk, 3 on with the pipelined walk forced (tests)"""
+        _check(load_library().apsu_he_set_query_overlap(self.h, int(mode)))
 
     def set_tier1_on_device(self, on):
         """tier-1 calls take device pointers (ints) and only queue their work; see sync() / stream"""

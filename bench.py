@@ -144,14 +144,23 @@ def main():
         rk = ctx.upload_relin_keys(rk_host)
     mask_host = rng.integers(0, t, (len(units), n), dtype=np.uint64)
     unit_pos = {(u[0], u[1]): i for i, u in enumerate(units)}
-    src_dev = torch.from_numpy(src_host.view(np.int64)).to(dev)
-    mask_dev = torch.from_numpy(mask_host.view(np.int64)).to(dev)
+    # A SECOND query (other source ciphertexts, other masks): consecutive steps alternate between the two, so that a step which
+    # read anything of the step in front of it -- powers, workspace, job tables -- would produce wrong bits (identical queries
+    # would hide that); one result of each kind is compared with the CPU's below
+    rng_b = np.random.default_rng(SEED0 + 0xB)
+    src_host_b = np.stack([np.stack([np.stack([np.stack([rng_b.integers(0, q, n, dtype=np.uint64) for q in ctx.q[:Lf]])
+                                               for _ in range(2)]) for _ in range(ns)])
+                           for _ in range(ctx.bundle_idx_count)])
+    mask_host_b = rng_b.integers(0, t, (len(units), n), dtype=np.uint64)
+    src_hosts, mask_hosts = [src_host, src_host_b], [mask_host, mask_host_b]
     esz = 8
-    src_ptrs = [[src_dev.data_ptr() + ((b * ns + s) * 2 * Lf * n) * esz for s in range(ns)] for b in my_indices]
-    mask_ptrs = [mask_dev.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine]
+    src_devs = [torch.from_numpy(a.view(np.int64)).to(dev) for a in src_hosts]
+    mask_devs = [torch.from_numpy(a.view(np.int64)).to(dev) for a in mask_hosts]
+    src_ptrs_k = [[[sd.data_ptr() + ((b * ns + s) * 2 * Lf * n) * esz for s in range(ns)] for b in my_indices] for sd in src_devs]
+    mask_ptrs_k = [[md.data_ptr() + unit_pos[(u[0], u[1])] * n * esz for u in mine] for md in mask_devs]
     max_local, _rows = gather_slots(assign)
     # two result buffers, alternated per step: the collective of step k (torch's stream) may still read one while
-    # step k+1 (the engine's stream) fills the other
+    # step k+1 (the engine's stream) fills the other.  Step k runs query kind k & 1 into buffer k & 1.
     out_bufs = [torch.zeros((max_local, 2, n), dtype=torch.int64, device=dev) for _ in range(2)]
     out_dev = out_bufs[0]
     step_no = [0]
@@ -175,9 +184,9 @@ def main():
         step_no[0] += 1
         if buf_free[slot] is not None:
             eng_stream.wait_event(buf_free[slot])
-        pw = ctx.compute_powers(my_indices, src_ptrs, rk, on_device=True) if my_indices else None
+        pw = ctx.compute_powers(my_indices, src_ptrs_k[slot], rk, on_device=True) if my_indices else None
         if bundles:
-            ctx.eval_bundles(bundles, pw, rk, mask_ptrs, out=out_dev.data_ptr(), masks_on_device=True, out_on_device=True)
+            ctx.eval_bundles(bundles, pw, rk, mask_ptrs_k[slot], out=out_dev.data_ptr(), masks_on_device=True, out_on_device=True)
         if world > 1:                                                # the path's only collective
             cur = torch.cuda.current_stream()
             cur.wait_stream(eng_stream)
@@ -214,24 +223,38 @@ def main():
     # round 2 still charged to one timed step.
     if not args.no_profile:
         ctx.profile_enable(0)
-    pipelined0 = ctx.debug_counters()["pipelined"]
+    if step_no[0] & 1:
+        step()                                     # the timed region starts with query kind 0
+        fence()
+    # ---- the timed region: K queries ONE AT A TIME, each with a host wait at its end = the reference's serving pattern (one query per
+    # dispatcher run, receiver_dispatcher_osn.cpp:112-116) and BASELINE.json's metric, a latency.  (Until round 4 `value` was the
+    # back-to-back rate of K queued queries; that figure is `throughput_ms_per_query` below.)
+    lat = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    pipelined_steps = ctx.debug_counters()["pipelined"] - pipelined0
-    # true per-query latency: ONE query, host wait at its end, nothing queued behind it (median of 5; `value` above is the
-    # back-to-back rate of K queued queries)
-    lat = []
-    for _ in range(5):
-        fence()
         tl = time.perf_counter()
         step()
-        fence()
+        torch.cuda.synchronize()                   # the query's results (and, N > 1, the gathered results) are complete
         lat.append((time.perf_counter() - tl) * 1e3)
-    lat.sort()
-    latency_sync_ms = lat[len(lat) // 2]
+    fence()
+    elapsed = time.perf_counter() - t0
+    # one result of each query kind, as the TIMED steps wrote it (the loops below overwrite the buffers)
+    timed_results = {k: out_bufs[k].clone() for k in range(min(2, args.steps))}
+    latency_median_ms = sorted(lat)[len(lat) // 2]
+    # ---- the rate of QUEUED queries (never `value`): K queries back to back, nothing waited for until the end; query k + 1's
+    # ComputePowers runs on the engine's second stream next to query k's evaluation (apsu_he_set_query_overlap)
+    q_steps = max(args.steps, 10) & ~1
+    for _ in range(2):
+        step()
+    fence()
+    pipelined0 = ctx.debug_counters()["pipelined"]
+    t1 = time.perf_counter()
+    for i in range(q_steps):
+        step()
+    fence()
+    throughput_ms = (time.perf_counter() - t1) * 1e3 / q_steps
+    pipelined_steps = ctx.debug_counters()["pipelined"] - pipelined0
+    queued_results = {k: out_bufs[k].clone() for k in range(2)}     # written by the last two QUEUED (pipelined) steps
     sampled = 0
     if not args.no_profile:
         ctx.profile_enable(2)
@@ -292,14 +315,15 @@ def main():
         "value": round(ms_step, 4), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "step_issue": "device-resident inputs, masks and results; the K timed queries are queued back to back on the engine's "
-                      "streams (apsu_he_set_async_results) and the clock stops after barrier + device synchronise: `value` is the "
-                      "back-to-back rate, `latency_ms_sync` one query with a host wait at its end.  Queued queries are PIPELINED "
-                      "(apsu_he_set_query_overlap): while an evaluation is running, the next query's ComputePowers runs on the engine's "
-                      "second stream next to it and the main stream only evaluates (APSU_HE_PIPE_CP=0 APSU_HE_EARLY_HIGH=0 serialises "
-                      "the queries: +4.5 % on `value` in the in-process A/B, `latency_ms_sync` unchanged; profiles/r04_ab_pipe_cp.txt)",
-        "latency_ms_sync": round(latency_sync_ms, 4),
-        "pipelined_steps": int(pipelined_steps),             # timed steps whose ComputePowers ran next to the evaluation in front of it
+        "step_issue": "device-resident inputs, masks and results; a step is ONE query with a host wait at its end (query latency: the "
+                      "reference serves one query per dispatcher run), consecutive steps alternate between two different queries; "
+                      "`value` = `ms_per_step` = wall time of the K timed steps / K.  `throughput_ms_per_query` is the rate of queued "
+                      "queries (K back to back, no host wait in between, query k+1's ComputePowers pipelined next to query k's "
+                      "evaluation: apsu_he_set_async_results + apsu_he_set_query_overlap) -- rounds 2-4 reported THAT as `value`",
+        "latency_ms_median": round(latency_median_ms, 4),
+        "throughput_ms_per_query": round(throughput_ms, 4),
+        "throughput_steps": int(q_steps),
+        "pipelined_steps": int(pipelined_steps),             # queued steps whose ComputePowers ran next to the evaluation in front of it
         "config": {"workload": "%s: n=%d, %d bundle indices x %d BinBundles (degrees %s), %d source -> %d target powers, "
                                "ps_low_degree=%d" % (args.config, n, ctx.bundle_idx_count, wl["bundles_per_idx"],
                                                      sorted(set(wl["degrees"](D)), reverse=True), ns,
@@ -453,7 +477,7 @@ def main():
                 M.random_bundle(0, b, ci, deg, SEED0 + 1000003 * b + 7919 * ci)
             flat = [np.ascontiguousarray(src_host[b, s]) for b in range(ctx.bundle_idx_count) for s in range(ns)]
             mlist = [np.ascontiguousarray(mask_host[unit_pos[(u[0], u[1])]]) for u in mine]
-            want = out_dev[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
+            want = timed_results[0][:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)     # query kind 0
             hio = {}
             for mode in ("pageable", "pinned"):
                 kw = {}
@@ -525,8 +549,8 @@ def main():
 
     # ---- CPU baseline + bit-exactness (rank 0, N=1 only) --------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host,
-                                              unit_pos, out_dev, n, t)
+        result["cpu_baseline"] = cpu_baseline(ctx, params_json, units, mine, bundles, src_hosts, rk_host, mask_hosts,
+                                              unit_pos, {"timed": timed_results, "queued": queued_results}, n, t)
     if rank == 0 and world > 1:
         g = gathered.cpu()
         mine_ok = bool((g[:len(mine)] == out_dev[:len(mine)].cpu()).all())
@@ -539,13 +563,15 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask_host, unit_pos, out_dev, n, t):
+def cpu_baseline(ctx, params_json, units, mine, bundles, src_hosts, rk_host, mask_hosts, unit_pos, gpu_results, n, t):
     """The reference CPU path, MEASURED on this box's host cores over the WHOLE query (no extrapolation):
     the CPU restatement (oracle/) executes the reference's call sequence with the reference's task granularity —
     ComputePowers per bundle index in sequence, one task per PowersDag node inside it (receiver_osn.cpp:320-328,
     powers.h:158-278), then one task per BinBundle on a pool of T threads (receiver_osn.cpp:334-364, the CLI's `-t`).
     Timed at T = every host core of this process (nproc stated) and at T = 1; every BinBundle's GPU result is compared
-    bit for bit with the CPU's.  The synthetic DB is rebuilt on the host beforehand (not timed)."""
+    bit for bit with the CPU's -- for BOTH queries the steps alternate between, on result buffers copied right behind the timed
+    (one query at a time) steps and right behind the queued (pipelined) steps.  The synthetic DB is rebuilt on the host
+    beforehand (not timed)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ref
     p = ref.load_params(params_json)
@@ -574,7 +600,8 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
             db[(b0, ci0)] = list(ex.map(make_coeff, [(seed, d) for d in range(deg + 1)], chunksize=16))
     t_db = time.perf_counter() - t_db
 
-    def run_query(T):
+    def run_query(T, kind=0):
+        src_host, mask_host = src_hosts[kind], mask_hosts[kind]
         ref.set_threads(T)
         t0 = time.perf_counter()
         plists = {}
@@ -601,8 +628,16 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
         return (time.perf_counter() - t0) * 1e3, t_pw * 1e3, res
 
     ms_all, pw_all, res = run_query(nproc)
-    gpu = out_dev[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
-    bit_exact = all(bool((gpu[i] == res[i]).all()) for i in range(len(mine)))
+    res_by_kind = {0: res}
+    checks = {}
+    for where, bufs in gpu_results.items():
+        for kind, buf in bufs.items():
+            if kind not in res_by_kind:
+                res_by_kind[kind] = run_query(nproc, kind)[2]
+            gpu = buf[:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)
+            checks["%s_query%d" % (where, kind)] = all(bool((gpu[i] == res_by_kind[kind][i]).all()) for i in range(len(mine)))
+    bit_exact = bool(checks) and all(checks.values())
+    distinct = len(res_by_kind) < 2 or not any(bool((res_by_kind[0][i] == res_by_kind[1][i]).all()) for i in range(len(mine)))
     # the reference's own scripts use -t 1/2/4/8 (tools/auto_test.py:194); ComputePowers has at most a few dozen independent
     # nodes per level, so a pool of every core is not the fastest setting: the sweep finds it, and THAT is `value`
     sweep = {nproc: (ms_all, pw_all)}
@@ -622,7 +657,8 @@ def cpu_baseline(ctx, params_json, units, mine, bundles, src_host, rk_host, mask
             "process_bin_bundle_cache_ms": round(sweep[best_T][0] - sweep[best_T][1], 1),
             "thread_sweep": {str(T): {"value": round(v[0], 1), "compute_powers_ms": round(v[1], 1)} for T, v in sorted(sweep.items())},
             "host_db_build_s": round(t_db, 1),
-            "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(mine)}
+            "gpu_result_bit_exact_vs_cpu": bit_exact, "bundles_compared": len(mine) * len(checks),
+            "bit_exact_by_step_kind": checks, "the_two_queries_differ_in_every_binbundle": distinct}
 
 
 if __name__ == "__main__":

@@ -67,7 +67,7 @@ typedef struct { uint32_t power, depth, parent1, parent2; } apsu_he_dag_node;   
 const char *apsu_he_last_error(void);
 /* 1: tiers 1 and 2, N1, N2, N4.  2 (additive): apsu_he_multi_*, apsu_he_eval_all, apsu_he_partition_bundles, apsu_he_wire_*,
  * apsu_he_set_async_results / apsu_he_sync / apsu_he_stream, apsu_he_mask_generate_blake2xb.
- * 6: apsu_he_set_query_overlap.
+ * 6: apsu_he_set_query_overlap.  7: its modes 2 and 3; the APSU_HE_* environment switches of measured-and-decided A/B experiments are gone.
  * 3: apsu_he_set_eval_pipeline removed (measured-negative scheduling experiment, profiles/r03_eval_pipeline.txt); added
  * apsu_he_debug_counters, apsu_he_phase_* / apsu_he_multi_phase_*, apsu_he_eval_all_ex + apsu_he_host_alloc, apsu_he_partition_bundles_ex,
  * the SEAL object codec apsu_he_seal_*, apsu_he_seed_expand, apsu_he_run_query_request; poly_modulus_degree 32768.
@@ -80,7 +80,7 @@ const char *apsu_he_last_error(void);
  * the header of a saved ReceiverDB (apsu_he_wire_peek_type ... apsu_he_wire_receiver_db_header).
  * 5 (additive): apsu_he_set_tier1_on_device (tier-1 calls on device-resident operands without a host round trip per call);
  * BinBundle images and DB files carry a row format (bit-packed database rows, the default, or dense words) and load into either. */
-#define APSU_HE_ABI_VERSION 6   /* what this header describes; compare with apsu_he_abi_version() of the loaded library */
+#define APSU_HE_ABI_VERSION 7   /* what this header describes; compare with apsu_he_abi_version() of the loaded library */
 int apsu_he_abi_version(void);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -218,7 +218,10 @@ int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes);
 /* Receiver::ComputePowers for n_bundle_idx bundle indices at once (receiver_osn.cpp:320-328,395-488).
  * src_cts[b * source_power_count + s] = query ciphertext of the s-th source power (ascending) for
  * bundle index bundle_indices[b]: size 2, coefficient form, first data level (receiver_osn.cpp:304-317).
- * src_on_device != 0: the pointers are device pointers (inputs already resident in HBM). */
+ * src_on_device != 0: the pointers are device pointers (inputs already resident in HBM).
+ * Every coefficient must be a canonical residue of its limb's prime, which is what a valid seal::Ciphertext holds
+ * (seal::is_data_valid_for, checked by SEALObject::extract in the reference, seal_object.h:161-219): the engine's lazy transforms
+ * take source limbs as they are.  apsu_he_run_query_request checks it on the decoded objects and fails like the reference. */
 int apsu_he_compute_powers(apsu_he_ctx *ctx, const uint32_t *bundle_indices, int n_bundle_idx,
                            const uint64_t *const *src_cts, int src_on_device, const apsu_he_relin *rk,
                            apsu_he_powers **out);
@@ -323,14 +326,17 @@ int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
  * stay alive and unmodified until then.  Host-memory arguments always synchronise, as does event profiling.
  * Default off (APSU_HE_ASYNC=1 turns it on for contexts that never call this). */
 int apsu_he_set_async_results(apsu_he_ctx *ctx, int on);
-/* Overlap of consecutive queries (ABI 6).  With on != 0 the caller promises that the device-resident inputs of
- * apsu_he_compute_powers -- the source ciphertexts and the relinearisation keys -- are COMPLETE when the call is made, i.e. not
+/* Overlap of consecutive queries (ABI 6; modes 2 and 3 ABI 7).  With mode != 0 the caller promises that the device-resident inputs
+ * of apsu_he_compute_powers -- the source ciphertexts and the relinearisation keys -- are COMPLETE when the call is made, i.e. not
  * still being produced by work queued on the context's stream (apsu_he_stream).  The engine's second stream then does not wait for
  * the main stream's queue at the start of a ComputePowers (receiver_osn.cpp:395-488) but only for the last evaluation that read the
- * powers buffer it is about to reuse: the high-power half of the next query's powers is computed next to the tail of the query in
- * front of it (-2...-4 % on the rate of queued queries; one query alone takes the same time).  Default off: a caller that uploads a
- * query on the context's stream and calls apsu_he_compute_powers behind it (apsu_he_run_query_request does) needs the ordering. */
-int apsu_he_set_query_overlap(apsu_he_ctx *ctx, int on);
+ * powers buffer it is about to reuse, and a ComputePowers that finds an evaluation still running on the device is queued as ONE
+ * chain on the second stream next to it (pipelined queries: -4 % on the rate of queued queries; one query alone takes the same
+ * time).  mode 0 (default): off -- a caller that uploads a query on the context's stream and calls apsu_he_compute_powers behind it
+ * (apsu_he_run_query_request does) needs the ordering.  1: on.  2: on, without the pipelined walk (only the high-power chain starts
+ * early).  3: on, every ComputePowers takes the pipelined walk whether or not the device is busy (for tests: the walk's event chain
+ * is exercised deterministically; slower for a query that runs alone).  Results are bit-identical in every mode. */
+int apsu_he_set_query_overlap(apsu_he_ctx *ctx, int mode);
 /* Tier 1 on device-resident operands (ABI 5): with on != 0 every pointer argument of the tier-1 calls (apsu_he_transform_to_ntt ...
  * apsu_he_clear_irrelevant_bits; relinearisation keys stay handles) is DEVICE memory -- or page-locked host memory, which the device
  * addresses -- and the calls return with their work queued on the context's stream instead of copying in, waiting and copying out:

@@ -187,9 +187,9 @@ def test_device_resident_io_and_profile_hooks():
     G.close()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [0, 1, 2, 3])
 def test_async_device_results(overlap):
-    """apsu_he_set_query_overlap (second case): the next query's high-power chain may start before the query in front has finished --
+    """apsu_he_set_query_overlap (modes 1-3): the next query's high-power chain / whole ComputePowers may start before the query in front has finished --
     the inputs below are complete when compute_powers is called (torch's blocking uploads), as that mode requires.
     apsu_he_set_async_results: with device-resident sources, masks and results the calls return with their work queued;
     back-to-back queries without a host synchronisation give the bits of the synchronous path, results are complete
@@ -220,10 +220,10 @@ def test_async_device_results(overlap):
         pw = G.compute_powers(S.bundle_indices, ptrs, rk, on_device=True)
         G.eval_bundles(gb, pw, rk, mp, out=outs[k % 3].data_ptr(), masks_on_device=True, out_on_device=True)
         del pw                                              # recycled while its evaluation is still queued
-    if overlap:                                             # the queued queries really were pipelined (three short queries may finish before
-        assert G.debug_counters()["pipelined"] >= 0         # the host queues the next: the count itself is timing-dependent)
-    else:
-        assert G.debug_counters()["pipelined"] == 0
+    # mode 3 takes the pipelined walk for every query; mode 1 only for a query that finds the device busy, which these short queries
+    # (0.6 ms) leave to timing -- tests/test_gpu_pipelined.py pins that mode down at 16M-4096 size
+    piped = G.debug_counters()["pipelined"]
+    assert piped == (6 if overlap == 3 else piped if overlap == 1 else 0)
     ext = torch.cuda.ExternalStream(G.stream)
     torch.cuda.current_stream().wait_stream(ext)            # consumer ordered after the context's stream, no host wait
     copy = outs[1].clone()                                  # k = 4: real sources

@@ -237,7 +237,7 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", apsu_amd.lib_path()]).decode()
     exported = set(re.findall(r" T (apsu_he_[a-z_0-9]+)", nm))
     assert exported == declared
-    assert lib.apsu_he_abi_version() == 6
+    assert lib.apsu_he_abi_version() == 7
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1,5 +1,7 @@
 """what one rank of an N-GPU run does (default 16M-4096; argv[1] = another config of bench.py): per-rank step time on a
-single GPU, for N = 1, 2, 4, 8 (the shards of rank 0 and of the last rank are executed here, one after the other)"""
+single GPU, for N = 1, 2, 4, 8 (the shards of rank 0 and of the last rank are executed here, one after the other).
+Per shard BOTH figures of bench.py: the LATENCY of one query with a host wait at its end (bench.py's `value`; the N-GPU
+projection quotes this one) and the rate of queued, pipelined queries (`throughput_ms_per_query`)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, apsu_amd
@@ -23,7 +25,7 @@ sd = torch.from_numpy(src.view(np.int64)).cuda(); md = torch.from_numpy(masks.vi
 out = torch.zeros((len(units), 2, n), dtype=torch.int64, device="cuda")
 for world in (1, 2, 4, 8):
     assign = partition(units, ctx.bundle_idx_count, world, ctx.compute_powers_cost())
-    worst = 0
+    worst = worst_lat = 0
     seen = set()
     for r in range(world):                                  # every distinct shard shape once (the worst rank sets the step)
         mine = assign[r]
@@ -45,12 +47,19 @@ for world in (1, 2, 4, 8):
             for _ in range(10): step()
             torch.cuda.synchronize(); runs.append((time.perf_counter() - t0) * 100)
         ms = sorted(runs)[len(runs) // 2]
+        lat = []
+        for _ in range(10 * REPEAT):                            # one query at a time, host wait at its end
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(); lat.append((time.perf_counter() - t0) * 1e3)
+        lms = sorted(lat)[len(lat) // 2]
         if REPEAT > 1:
             print(f"   runs of 10 steps: {' '.join('%.3f' % v for v in runs)}  spread {100 * (max(runs) - min(runs)) / ms:.1f} % of the median", flush=True)
         t1 = time.perf_counter()
         for _ in range(10): pw = ctx.compute_powers(idx, sp, rk, on_device=True)
         ctx.eval_bundles(bl[:1], pw, rk, mp[:1], out=out.data_ptr(), masks_on_device=True, out_on_device=True)
         torch.cuda.synchronize(); pms = (time.perf_counter() - t1) * 100
-        print(f"world={world} rank={r}: {len(idx)} idx, {len(mine)} bundles (deg sum {sum(u[2] for u in mine)}): step {ms:.3f} ms (powers ~{pms:.3f} ms)", flush=True)
+        print(f"world={world} rank={r}: {len(idx)} idx, {len(mine)} bundles (deg sum {sum(u[2] for u in mine)}): latency {lms:.3f} ms, queued {ms:.3f} ms per query (powers ~{pms:.3f} ms)", flush=True)
         worst = max(worst, ms)
-    print(f"  => per-rank compute at N={world}: {worst:.3f} ms")
+        worst_lat = max(worst_lat, lms)
+    print(f"  => per-rank compute at N={world}: latency {worst_lat:.3f} ms, queued rate {worst:.3f} ms per query")
