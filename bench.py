@@ -504,6 +504,56 @@ def main():
         except Exception as e:                                          # never lose the main line
             result["host_io"] = {"error": str(e)}
 
+    # ---- the same query through the REFERENCE-SIDE ADAPTER's call patterns (rank 0, N=1 only; never `value`) -----------------
+    # integration/receiver_hot_path.cpp keeps the reference's call structure: Receiver::ComputePowers once per bundle index
+    # (receiver_osn.cpp:320-328) and one evaluation per ProcessBinBundleCache task on a pool of T host threads (:334-364, :490-540), every
+    # call from host memory into host memory with its own wait.  integration/receiver_run_query.cpp is the batched form: the sources of all
+    # bundle indices in ONE apsu_he_compute_powers, all BinBundles in ONE apsu_he_eval_bundles into one host buffer.  Both are issued here
+    # exactly as those files issue them (incl. the per-query upload of the relinearisation keys, HeGpu::relin_keys), host wall clock.
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_host_io:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            srcs_h = [[np.ascontiguousarray(src_host[b, s]) for s in range(ns)] for b in range(ctx.bundle_idx_count)]
+            masks_h = [np.ascontiguousarray(mask_host[unit_pos[(u[0], u[1])]]) for u in mine]
+            want = timed_results[0][:len(mine)].cpu().numpy().view(np.uint64).reshape(len(mine), 2, 1, n)     # query kind 0
+            ctx.set_async_results(False)
+            T = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
+
+            def incremental(pool):
+                rk_q = ctx.upload_relin_keys(rk_host) if rk_host is not None else None
+                pws = {b: ctx.compute_powers([b], [srcs_h[b]], rk_q) for b in my_indices}               # sequential, as :320-328
+                outs = list(pool.map(lambda i: ctx.eval_bundles([bundles[i]], pws[mine[i][0]], rk_q, [masks_h[i]])[0], range(len(mine))))
+                return np.stack(outs)
+
+            def batched(_pool):
+                rk_q = ctx.upload_relin_keys(rk_host) if rk_host is not None else None
+                pw = ctx.compute_powers(my_indices, [srcs_h[b] for b in my_indices], rk_q)
+                return ctx.eval_bundles(bundles, pw, rk_q, masks_h)
+
+            ac = {}
+            with ThreadPoolExecutor(T) as pool:
+                for name, fn in (("incremental", incremental), ("batched", batched)):
+                    for _ in range(2):
+                        got = fn(pool)
+                    ts = []
+                    for _ in range(5):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        got = fn(pool)
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                    ac[name + "_ms"] = round(sorted(ts)[2], 3)
+                    ac[name + "_same_bits"] = bool((np.asarray(got).reshape(want.shape) == want).all())
+            ac["calls"] = {"incremental": "%d x apsu_he_compute_powers (one bundle index) + %d x apsu_he_eval_bundles (one BinBundle) from %d host threads"
+                                          % (len(my_indices), len(mine), T),
+                           "batched": "1 x apsu_he_compute_powers (%d bundle indices) + 1 x apsu_he_eval_bundles (%d BinBundles)" % (len(my_indices), len(mine))}
+            ac["incremental_over_batched"] = round(ac["incremental_ms"] / max(1e-9, ac["batched_ms"]), 2)
+            ac["note"] = ("host wall clock incl. the Python binding, pageable host memory in and out, relinearisation keys uploaded per query; "
+                          "integration/receiver_hot_path.cpp issues the incremental pattern, integration/receiver_run_query.cpp the batched one")
+            result["adapter_calls"] = ac
+            ctx.set_async_results(os.environ.get("APSU_BENCH_ASYNC", "1") != "0")
+        except Exception as e:                                          # never lose the main line
+            result["adapter_calls"] = {"error": str(e)}
+
     # ---- the same query from the WIRE (rank 0, N=1 only; never `value`) ------------------------
     # apsu_he_run_query_request: the framed QueryRequest as the reference's querier sends it (SEAL objects: seeded ciphertexts + seeded
     # RelinKeys; query.cpp:44-80) in, one framed ResultPackage per BinBundle out; parse, inflate, seed expansion on the device, the query,
