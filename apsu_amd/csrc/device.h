@@ -182,9 +182,9 @@ struct TensorSumJob { const u64 *a, *b; u64 *dq, *bs; int terms; int pad; };
 void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size_t n, int njobs, int e0, hipStream_t st);
 // tensor product + inverse NTT in one launch: njobs products x 3 polys x `limbs` limbs (operand polys src_ps words apart,
 // output job.d[3][limbs][n], coefficient form), followed by n_plain limbs at `plain` transformed in place; modmap covers both
-// xcd: grid order that puts the three workgroups of one (product, limb) pair on one XCD (they read the same operand limbs)
+// (grid order: the three workgroups of one (product, limb) pair -- they read the same operand limbs -- on one XCD)
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd = false, bool lazy_in = false);
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st);
 struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
 void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)
@@ -198,7 +198,7 @@ void launch_ks_moddown(const DevKey *key, int L, const u64 *acc, u64 *ct, size_t
                        hipStream_t st, const DevLevel *lv = nullptr, u64 *ext = nullptr, int n_ext = 0, bool raw = false);
 // kara: the three-product accumulation (k_mac<.., true>, lv->mac_chunk_k)
 // packed: every job of the launch reads bit-packed plaintexts (MacJob::packed)
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false, bool packed = false, int limb_slow = 0);
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara = false, bool packed = false);
 // single products on one limb: out[0][k] = a[k] * pw[limb][k], out[out_poly_stride + k] = a[k] * pw[pw_poly_stride + limb n + k]  (mod q_limb);
 // pt: the plaintext's slot as k_mac takes it (dense: [L][n] words; packed: the bit-packed slot, rows per DevLevel::mac_row_off)
 struct TermJob { const u64 *pt; const u64 *pw; u64 *out; };

@@ -146,38 +146,32 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         }
         d_tabs_.alloc(tabs.size() * sizeof(NttTable));
         HIP_CHECK(hipMemcpy(d_tabs_.p(), tabs.data(), tabs.size() * sizeof(NttTable), hipMemcpyHostToDevice));
-        // BEHZ step 4 (the dyadic tensor product) is formed by the load of the inverse transform that follows it (k_intt_tensor)
-        // instead of by its own kernel: same bits, and measured in one process against the separate kernels with
-        // tools/ab_test.py (profiles/r03_ab_fuse_tensor.txt): -0.059 +- 0.026 ms on the whole 16M-4096 query, -0.017 +- 0.0014 ms
-        // (-2.1 %) on the N = 8 shard.  APSU_HE_FUSE_TENSOR=0 restores the separate kernels.
-        if (const char *v = std::getenv("APSU_HE_ASYNC")) async_results_ = std::atoi(v) != 0;     // default of apsu_he_set_async_results
-        if (const char *v = std::getenv("APSU_HE_MAX_INFLIGHT")) max_inflight_ = std::max(1, std::atoi(v));   // queued evaluations the host may run ahead
-        if (const char *v = std::getenv("APSU_HE_FUSE_EXT")) fuse_ext_ = std::atoi(v) != 0;       // =0: separate extension kernel per DAG level
-        fuse_tensor_ = true;
-        if (const char *v = std::getenv("APSU_HE_FUSE_TENSOR")) fuse_tensor_ = std::atoi(v) != 0;
+        // Environment switches (read once per context).  Round 5 retired the switches of A/B experiments that were decided in earlier
+        // rounds together with their losing code paths (separate tensor / extension kernels where the fused forms apply, inverse
+        // transforms with their own twist in front of drop / mod-down kernels, the tensor transform in launch order, canonical products
+        // in the tensor-on-load transform, k_mac's other grid orders, the i = 0 block's per-term products as k_mac chains, the gathered
+        // transforms' unconditional reduce-on-load; the records are in profiles/r03_ab_*.txt and profiles/r04_ab_*.txt).  What is left
+        // either selects a data format, sizes a buffer, or forces a correctness fallback that the engine otherwise takes by itself:
+        //   APSU_HE_SPLIT=0/1          default of apsu_he_set_two_stream (profiling scripts: one-stream kernel traces)
+        //   APSU_HE_EVAL_SIDE=0        the evaluation's side work (coefficient-form sums, i = 0 finish) stays on the main stream
+        //   APSU_HE_PACKED_ROWS=0      BinBundle rows as dense 64-bit words instead of bit-packed (images of either format load anywhere)
+        //   APSU_HE_EVAL_WS_BYTES=n    evaluation workspace -> BinBundles per chunk (default 6 GiB)
+        //   APSU_HE_ARENA_BYTES=n      initial workspace arena (grows on demand)
+        //   APSU_HE_EVAL_PER_TERM=1    eval_patstock's products finished one by one (the fallback of the summed finish)
+        //   APSU_HE_MAC_KARA=0/1       three-product k_mac forced off / on (default: by chain length)
+        //   APSU_HE_SEED_EXPAND_HOST=1 seeded objects expanded by the host codec (the fallback of the device sampler)
+        if (const char *v = std::getenv("APSU_HE_SPLIT")) two_stream_default_ = std::atoi(v) != 0 ? 1 : 0;
         if (split_ntt) fuse_tensor_ = false;                     // the fused load belongs to a whole-limb workgroup
-        // the inverse transforms in front of the drop-last-limb / mod-down kernels leave their twist to those kernels' constants
-        // (the way the unrolled BEHZ finish has taken it since round 2): -0.035 +- 0.020 ms (-1.0 %) on the whole query,
-        // profiles/r03_ab_fusions.txt; APSU_HE_RAW_TWIST=0 restores the transforms' own twist
-        if (const char *v = std::getenv("APSU_HE_RAW_TWIST")) raw_twist_ = std::atoi(v) != 0;
-        // ... in a grid order that puts the three workgroups of one (product, limb) pair -- which read the same operand limbs -- on one
-        // XCD (workgroups b and b + 8 share an XCD, hence its L2): -0.031 +- 0.007 ms (-0.9 %) on the whole query over three
-        // in-process A/B runs, level on the N = 8 shard; profiles/r03_ab_xcd.txt.  APSU_HE_TENSOR_XCD=0 restores launch order.
-        // (The same placement for the key switch's gather transforms -- L + 1 readers per digit -- measured level to +0.6 %: not kept.)
-        if (const char *v = std::getenv("APSU_HE_TENSOR_XCD")) tensor_xcd_ = std::atoi(v) != 0;
-        if (const char *v = std::getenv("APSU_HE_TENSOR_LAZY")) tensor_lazy_ = std::atoi(v) != 0;   // =0: the tensor-on-load transform reduces its products to canonical residues
-        if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;   // three-product k_mac: force off / on (default: by chain length)
-        if (const char *v = std::getenv("APSU_HE_MAC_LIMB_SLOW")) mac_limb_slow_ = std::atoi(v);   // k_mac grid order, see kernels.hip k_mac: 0 (block, limb, job), 1 (block, job, limb), 2 (block mod 8, job, block / 8, limb)
-        if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v);            // 0: the cf sums and the i = 0 finish stay on the main stream; 1 / 2: where the side lane starts (ps_run)
-        if (const char *v = std::getenv("APSU_HE_TERM_KERNEL")) term_kernel_ = std::atoi(v) != 0;   // =0: the i = 0 block's per-term products as k_mac chains of length one
-        if (const char *v = std::getenv("APSU_HE_GATHER_NORED")) gather_nored_ = std::atoi(v) != 0;  // =0: the gathered transforms always reduce on load
+        if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;
+        if (const char *v = std::getenv("APSU_HE_EVAL_SIDE")) eval_side_ = std::atoi(v) != 0;
         // BinBundle plaintexts bit-packed in HBM (12.5 % fewer bytes for 56-bit primes, 22 % for 50-bit ones; k_mac<.., PACKED>): in-process
         // A/B on 16M-4096 -0.146 +- 0.017 ms (-4.2 %) on the whole query, -2.4 % on the N = 8 shard, same bits
-        // (profiles/r04_ab_packed_rows.txt).  Default since round 4; APSU_HE_PACKED_ROWS=0 keeps dense 64-bit words.
-        // Only with key switching (the single-prime paths keep dense rows).
+        // (profiles/r04_ab_packed_rows.txt).  Only with key switching (the single-prime paths keep dense rows).
         if (const char *v = std::getenv("APSU_HE_PACKED_ROWS")) packed_rows_ = std::atoi(v) != 0;
         if (!hp_.using_keyswitching) packed_rows_ = false;
-        if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);   // evaluation workspace -> BinBundles per chunk
+        if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);
+        if (const char *v = std::getenv("APSU_HE_EVAL_PER_TERM")) force_per_term_ = std::atoi(v) != 0;
+        if (const char *v = std::getenv("APSU_HE_SEED_EXPAND_HOST")) seed_expand_host_ = std::atoi(v) != 0;
     }
     // level constants
     {
@@ -840,20 +834,20 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
         // the lazy transform takes them as they are (16M-4096: 56-bit sources into 56- and 50-bit targets)
         u64 max_src = 0;
         for (int J = 0; J < L; J++) max_src = std::max(max_src, hp_.key_q[J]);
-        bool nored = gather_nored_ && hp_.logn <= 14;
+        bool nored = hp_.logn <= 14;
         for (int I = 0; I <= L && nored; I++) nored = ntt_gather_nored_ok(hp_.key_q[I < L ? I : hp_.K - 1], max_src, hp_.logn);
         PROF(P_NTT_FWD, src.size());
         launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_, nored);
     }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
     // the inverse transform leaves its twist to the mod-down kernel, whose own constants absorb it (unrolled sizes)
-    const bool raw = raw_twist_ && L <= 4;
+    const bool raw = L <= 4;
     const int *amap = raw ? map_ksacc_raw(chain_idx) : map_ksacc(chain_idx);
     // (the inner product formed by the inverse transform's load, the way the BEHZ tensor product is, was measured in round 3:
     //  2 % SLOWER on the whole query -- six operand streams per output and tdec read twice; tools/microbench/intt_ks_experiment.hip)
     { PROFW(P_KEYSWITCH, (size_t)batch * n * ((size_t)L * (L + 1) + 2 * (L + 1))); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), amap, L + 1, true);
-    const bool fuse_ext = ext_out && n_ext > 0 && fuse_ext_ && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
+    const bool fuse_ext = ext_out && n_ext > 0 && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
     { PROFW(P_KEYSWITCH, (size_t)batch * n * (2 * (L + 1) + 4 * L) + (fuse_ext ? (size_t)n_ext * 2 * (hlevel(chain_idx).L + hlevel(chain_idx).nB + 1) * n : 0));
       launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0, raw); }
     return fuse_ext;
@@ -1369,7 +1363,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 }
                 if (fuse_tensor_) {                                                                                              // :422/:424
                     PROF(P_NTT_FUSED, tj.size() * 3 * Ef);
-                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_, tensor_xcd_, tensor_lazy_);
+                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_);
                 } else {
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
@@ -1423,7 +1417,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                     for (size_t pl = 0; pl < 2 * Lf; pl++)
                         srcp[(((size_t)b * np + i) * 2 * Lf) + pl] = slot_ptr(s.slot_of[s.low_powers[i]], b) + pl * n;
             // (limb j of a slot is already a canonical residue of q_j: nothing to reduce)
-            bool nored = gather_nored_ && hp_.logn <= 14;
+            bool nored = hp_.logn <= 14;
             for (size_t j = 0; j < Lf && nored; j++) nored = ntt_gather_nored_ok(hp_.key_q[j], hp_.key_q[j], hp_.logn);
             PROF(P_NTT_FWD, srcp.size());
             launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_, nored);
@@ -1512,10 +1506,9 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // Two-stream walk: the high-power half of the DAG runs on the second stream next to the low-power half and to the
     // BinBundle inner products.  Measured on 16M-4096 (tools/pipe_sweep.py, tools/rank_cost.py): 3.84 ->
     // 3.65 ms for the whole query (four bundle indices), 0.95 -> 0.86 ms per rank with one bundle index.  Default: on
-    // whenever the PowersDag splits; APSU_HE_SPLIT=0/1 or apsu_he_set_two_stream force it.  Event profiling always takes
+    // whenever the PowersDag splits; APSU_HE_SPLIT=0/1 (read at apsu_he_create) or apsu_he_set_two_stream force it.  Event profiling always takes
     // the one-stream walk: a launch bracketed by events next to another stream's kernels measures the sharing, not the kernel.
-    static const int split_env = [] { const char *v = std::getenv("APSU_HE_SPLIT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
-    const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : split_env;                  // API override, then environment
+    const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : two_stream_default_;       // API override, then environment
     const bool split = split_ok_ && !prof_on_ && (split_mode < 0 || split_mode == 1);   // (host inputs are uploaded per lane and end with a sync)
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
@@ -1542,7 +1535,6 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     WITH_ARENA({
         for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
         if (pipe) {
-            counters_[C_PIPELINED]++;
             switch_lane(1);
             if (had_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             DagRun r;
@@ -1596,6 +1588,7 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
         if (!on_device) sync();
     });
     if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
+    if (pipe) counters_[C_PIPELINED]++;                      // (once per call: the walk above is queued again after an arena growth)
     pw->last_use_set = false;                               // consumed above; only an evaluation of THESE powers sets it again
     return pw;
 }
@@ -1918,8 +1911,7 @@ void Engine::seed_expand(int chain_idx, int count, const u64 *seeds, u64 *const 
             sync();                                              // buf is reused
         }
     };
-    static const bool force_host = [] { const char *v = std::getenv("APSU_HE_SEED_EXPAND_HOST"); return v && std::atoi(v) != 0; }();
-    if (L > DMAXL || force_host) { host_expand(); return; }
+    if (L > DMAXL || seed_expand_host_) { host_expand(); return; }
     const DevLevel *lv = nullptr;
     if (key_level && hp_.K - 1 > hp_.first_chain_idx) {
         // the key level is not a data level: a DevLevel-shaped view that carries its moduli only
@@ -2120,7 +2112,7 @@ void Engine::eval_plain(EvalCall &c, const std::vector<int> &pl_ids)
         else HIP_CHECK(hipMemsetAsync(o, 0, 2 * Lv * n * sizeof(u64), st_));
         ej.push_back(EpiJob{ o, nullptr, nullptr, b.a0.u(), mask_ptr(pl_ids[x]), res_ptr(pl_ids[x]) });
     }
-    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
+    { auto mj = group_mac(ms); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(lvl), (int)Lv, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(lvl, mac_mean_cnt(mj)), mac_packed(mj)); }
     d_ntt_ct(acc, (size_t)Bp * 2, lvl, true);                                                 // :154
     // :159 add_plain(a_0), :162 add_plain(mask), :168-170 mod switch to the last level, :171 clear bits
     { PROFW(P_MODSWITCH, (size_t)Bp * n * (2 * Lv + 4)); launch_eval_epilogue(dlevel(0), lvl, upload_jobs(ej), Lv * n, hp_.irrelevant_bit_count, n, Bp, st_); }
@@ -2160,8 +2152,8 @@ void Engine::eval_patstock(EvalCall &c, const std::vector<int> &ps_ids)
     const bool need_vlast = i0_fast && low > high;
     // RAW inverse transforms (no twist, no final reduction) where the consumer's own constants absorb the twist:
     // the inner polynomials when the fused drop + extension kernel takes them, the i = 0 block's sums and last limbs
-    const bool raw_drop = raw_twist_ && low == high + 1 && hlevel(high).L == hlevel(high).nB && hlevel(high).L <= 3;
-    const bool raw_i0 = raw_twist_ && need_vlast;
+    const bool raw_drop = low == high + 1 && hlevel(high).L == hlevel(high).nB && hlevel(high).L <= 3;
+    const bool raw_i0 = need_vlast;
     PsBatch g;
     g.ids = ps_ids;
     std::stable_sort(g.ids.begin(), g.ids.end(), [&](int a, int b) { return bslot[c0 + a] < bslot[c0 + b]; });
@@ -2240,17 +2232,13 @@ void Engine::ps_tables(EvalCall &c, const PsPlan &plan, PsBatch &g)
         for (int x = 0; x < Bs; x++) {
             const Bundle &b = *bundles[c0 + g.ids[x]];
             const int bs = bslot[c0 + g.ids[x]];
-            if (i0_fast && term_kernel_) {
+            if (i0_fast) {
                 if (x == 0) g.term_packed = b.packed;
                 else if (g.term_packed != (bool)b.packed) throw std::logic_error("BinBundles of one evaluation differ in their row format");
             }
             for (u32 j = 1; j <= l; j++) {
-                if (i0_fast && term_kernel_)
+                if (i0_fast)                                 // the dropped limb of every term by itself: k_term_product (not k_mac chains of length one)
                     tj.push_back(TermJob{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs), g.vlast + ((size_t)x * l + j - 1) * 2 * n });
-                else if (i0_fast)
-                    ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
-                                            g.vlast + ((size_t)x * l + j - 1) * 2 * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
-                                            (u32)(Ll * n), (u32)n, (u32)(Ll - 1), 1, (u32)b.packed });
                 else
                     ms.push_back(MacStream{ bundle_slot(b, false, j - 1, Ll * n), low_ptr(j, bs),
                                             g.term + ((size_t)x * l + j - 1) * 2 * Ll * n, 1, bundle_stride(b, false, Ll * n), low_term_stride,
@@ -2292,7 +2280,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     const int Bs = (int)g.ids.size(), NI = g.NI;
     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
-    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed, mac_limb_slow_); }
+    { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
     if (g.n_term) { PROF(P_MAC, (uint64_t)g.n_term * (g.term_packed ? packed_row_bits(hp_.key_q[Ll - 1]) : 64)); launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_); }
     d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
 
@@ -2326,14 +2314,14 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         struct Back { Engine *e; ~Back() { e->switch_lane(0); } } back{ this };
         HIP_CHECK(hipStreamWaitEvent(st_, ev_fork_, 0));
         if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // the cf sums read the high powers (second stream)
-        { auto mj = group_mac(cs); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
+        { auto mj = group_mac(cs); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
         d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
         if (side_i0) launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0);
         HIP_CHECK(hipEventRecord(ev_side_, st_));
     };
-    // where the side lane starts: 1 = behind the inverse transforms above (next to the drop / extension / transform launches),
-    // 2 = behind the tensor-on-load transform (next to the finish and the key switch of the sums: launches that leave most of the chip idle)
-    if (side && eval_side_ == 1) run_side();
+    // the side lane starts behind the inverse transforms above, next to the drop / extension / transform launches (starting it behind the
+    // tensor-on-load transform instead, next to the finish and the key switch of the sums, measured level: profiles/r04_ab_eval_side.txt)
+    if (side) run_side();
     const bool late_cf = late_high && !side;                 // the cf sums on the main stream, behind the wait for the high powers
 
     // mod switch to the high level (:269,298), then ct x ct with the high powers (:272,301): extend, NTT,
@@ -2362,11 +2350,10 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     // inverse transforms per term at L = 2.
     int max_terms = 0;
     for (int x = 0; x < Bs; x++) max_terms = std::max(max_terms, nin[x]);
-    static const bool force_per_term = std::getenv("APSU_HE_EVAL_PER_TERM") != nullptr;
     // the summed finish adds per-term canonical residues of EVERY q limb as plain integers: the widest limb bounds it
     u64 q_widest = 0;
     for (size_t j = 0; j < Lh; j++) q_widest = std::max(q_widest, hlevel(high).q[j]);
-    const bool summed = !force_per_term && Lh <= 4 &&
+    const bool summed = !force_per_term_ && Lh <= 4 &&
                         (unsigned __int128)max_terms * q_widest < ((unsigned __int128)1 << 63);
     const size_t w_cf = (size_t)Bs * 2 * Lh * n;
     if (summed) {
@@ -2377,7 +2364,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             g.cf = bsum + (size_t)Bs * 3 * nBskh * n;
             std::vector<MacStream> cs;
             cf_streams(g, cs);
-            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_);
+            auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj));
         }
         std::vector<TensorSumJob> tj;
         std::vector<FinishSumJob> fj;
@@ -2406,8 +2393,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
             PROF(P_NTT_FUSED, dmap.size());
             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
-                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, tensor_xcd_, tensor_lazy_);
-            if (side && eval_side_ == 2) run_side();
+                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_);
         } else {
             { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
             d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
@@ -2418,7 +2404,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             g.cf = ws(w_cf);
             std::vector<MacStream> cs;
             cf_streams(g, cs);
-            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj), mac_limb_slow_); }
+            { auto mj = group_mac(cs); PROF(P_MAC, mac_units(mj)); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
             d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
         }
         u64 *dbuf = ws((size_t)NI * 3 * Eh * n);
@@ -2439,7 +2425,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         }
         if (fuse_tensor_ && tj.size() == (size_t)NI) {
             PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
-            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, tensor_xcd_, tensor_lazy_);
+            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_);
         } else {
             if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
             d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
@@ -2760,7 +2746,7 @@ std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indice
         sync();                                              // the workspace is reused by the next call; nothing here is latency-critical
     });
     if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
-    pw->last_use_set = false;                               // consumed above; only an evaluation of THESE powers sets it again
+    pw->last_use_set = false;                               // (the path synchronises; kept for the pool's bookkeeping)
     return pw;
 }
 

@@ -290,7 +290,7 @@ private:
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap: the second stream then waits for the last reader of its powers buffer only
     bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (set_query_overlap 1 / 3)
     bool force_pipe_ = false;         // ... whether or not an evaluation is still running (set_query_overlap 3)
-    int eval_side_ = 1;               // cf sums + i = 0 finish of eval_patstock on the second stream (APSU_HE_EVAL_SIDE)
+    bool eval_side_ = true;           // cf sums + i = 0 finish of eval_patstock on a side stream (APSU_HE_EVAL_SIDE=0: on the main stream)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded
     // run-ahead (20 queued queries = 1300 launches + 200 stream events) makes the HIP runtime block the host inside a
@@ -333,26 +333,21 @@ private:
         std::vector<uint32_t> low_powers, high_powers;    // target powers by final form
     } sched_, sched_low_, sched_high_;
     void mask_generate_impl(uint32_t count, u64 *masks_dev, u64 *values_host, u64 *blocks_host, const std::function<void(u64 *, size_t)> &fill);
-    bool fuse_ext_ = true;            // ComputePowers: a parent's BEHZ extension is written by the key switch's mod-down kernel
-    bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor)
-    bool tensor_xcd_ = true;          // ... with the three workgroups of one (product, limb) pair placed on one XCD
-    bool tensor_lazy_ = true;         // tensor-on-load inverse transforms take the fold's last word (< 4q) instead of a canonical residue (ntt_core.h, ntt_lazy_input_ok; APSU_HE_TENSOR_LAZY)
+    bool fuse_tensor_ = true;         // BEHZ step 4 is formed by the inverse transform's load (k_intt_tensor); off only for n = 32768, whose limb does not fit one workgroup
+    bool force_per_term_ = false;     // APSU_HE_EVAL_PER_TERM: eval_patstock's products finished one by one (the fallback of the summed finish)
+    bool seed_expand_host_ = false;   // APSU_HE_SEED_EXPAND_HOST: seeded objects expanded by the host codec (the fallback of the device sampler)
     bool tier1_device_ = false;       // tier-1 operands are device memory and calls do not synchronise
     void tier1_done() { if (!tier1_device_ || prof_on_) sync(); }
     bool packed_rows_ = true;         // BinBundle plaintexts are kept bit-packed in HBM (APSU_HE_PACKED_ROWS=0: dense 64-bit words; Bundle::packed)
     size_t slot_bytes(int chain_idx, bool packed) const;          // bytes of one NTT-form plaintext at a level, either format
     void pack_bundle(Bundle &b);      // dense -> packed when this context keeps packed rows (no-op otherwise)
     void unpack_bundle(Bundle &b);    // packed -> dense (images of the other format)
-    bool term_kernel_ = true;         // the i = 0 block's per-term products on the dropped limb by k_term_product instead of k_mac chains of length one
-    int mac_limb_slow_ = 1;           // k_mac grid order 0 / 1 / 2: what is resident behind one L2 together (1: -2.5 ... -2.9 % on the 256M-4096 query, level at 16M-4096) (APSU_HE_MAC_LIMB_SLOW; kernels.hip, launch_mac)
     int mac_kara_ = -1;               // k_mac with three products per term instead of four: -1 by chain length, 0 / 1 forced (APSU_HE_MAC_KARA)
     bool mac_kara(int lvl, uint32_t mean_cnt) const;
     uint64_t mac_units(const std::vector<MacJob> &mj) const;      // bits of database rows per coefficient index (profile unit of P_MAC)
-    bool gather_nored_ = true;        // gathered forward transforms skip the reduce-on-load where the lazy range allows (ntt_gather_nored_ok)
     size_t eval_ws_budget_ = (size_t)6 << 30;
-    bool raw_twist_ = true;           // inverse transforms in front of drop / mod-down kernels leave their twist to those kernels
     bool split_ok_ = false;           // the low-power and high-power halves of the PowersDag share no node
-    int two_stream_mode_ = -1;
+    int two_stream_mode_ = -1, two_stream_default_ = -1;   // apsu_he_set_two_stream ; APSU_HE_SPLIT
     void build_schedule();
     void build_schedule_for(Sched &s, const std::vector<char> &member);
     struct DagRun;                    // per-call state of one walk over a schedule

@@ -144,13 +144,13 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
 template <int LOGN, int T>
 __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
                                                    u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
-                                                   const int *__restrict__ modmap, int period, int xcd, int lazy_in)
+                                                   const int *__restrict__ modmap, int period)
 {
     constexpr int N = 1 << LOGN;
     __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
     const int tid = threadIdx.x;
     size_t g = blockIdx.x;
-    if (xcd) {
+    {
         // XCD-aware order: the three workgroups of one (product, limb) pair -- which read the same operand limbs -- sit 8 apart in
         // the grid (workgroups b and b + 8 share an XCD, hence an L2): pair u = 8 blk + lane, polynomial pl at 24 blk + 8 pl + lane.
         // (One product per block with lane = limb, so that all workgroups of limb e share an XCD and products with a common parent
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     const int r = (int)(g - jb * per), pl = r / limbs, e = r - pl * limbs;
     const TensorJob job = jobs[jb];
     const u64 *a0 = job.a + (size_t)e * N, *a1 = a0 + src_ps, *b0 = job.b + (size_t)e * N, *b1 = b0 + src_ps;
-    const bool lazy = lazy_in && ntt_lazy_input_ok(tab, LOGN);
+    // the fold's last word (< 4q) enters the transform as it is where the range discipline takes that (-1.05 % query, profiles/r04_ab_tensor_lazy.txt)
+    const bool lazy = ntt_lazy_input_ok(tab, LOGN);
     SrcTensor ops;
     if (pl == 0) ops = SrcTensor{ a0, b0, nullptr, nullptr, lazy };
     else if (pl == 1) ops = SrcTensor{ a0, b1, a1, b0, lazy };
@@ -202,13 +203,12 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
 }
 
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, bool xcd, bool lazy_in)
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st)
 {
     const size_t n_tensor = (size_t)njobs * 3 * limbs;
-    const size_t count = (xcd ? (n_tensor / 3 + 7) / 8 * 24 : n_tensor) + n_plain;
+    const size_t count = (n_tensor / 3 + 7) / 8 * 24 + n_plain;                 // the XCD-aware order pads the pairs to blocks of eight
     if (!(n_tensor + n_plain)) return;
-    const int xm = xcd ? 1 : 0;
-#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period, xm, lazy_in ? 1 : 0); break;
+#define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period); break;
     switch (logn) {
     T_CASE(14, 1024) T_CASE(13, 512) T_CASE(12, 256) T_CASE(11, 128) T_CASE(10, 64) T_CASE(8, 64) T_CASE(6, 64)
     default: throw_hip(hipErrorInvalidValue, __FILE__, __LINE__);
@@ -1505,15 +1505,11 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
     MAC_STAMP(0);
     // grid order (launch_mac).  Workgroups go to the XCDs round-robin in launch order, so what is FAST in the grid decides which
     // workgroups are resident behind one L2 together, i.e. how much of the shared powers that L2 has to hold:
-    //   0: (block, limb, job)        -- an XCD holds blocks x, x + 8 of every limb of ~10 jobs: 2 * limbs * terms * 8 KiB
-    //   1: (block, job, limb)        -- ... of ONE limb of ~32 jobs: 2 * terms * 8 KiB
-    //   2: (block mod 8, job, block / 8, limb) -- ONE block of one limb of 64 jobs: terms * 8 KiB (2.5 MiB for 310 terms)
+    //   limb_slow 0: (block, limb, job)  -- an XCD holds blocks x, x + 8 of every limb of ~10 jobs: 2 * limbs * terms * 8 KiB
+    //   limb_slow 1: (block, job, limb)  -- ... of ONE limb of ~32 jobs: 2 * terms * 8 KiB  (-2.5 ... -2.9 % on the 256M-4096 query,
+    //                level at 16M-4096; one block per XCD measured level with it: profiles/r04_ab_mac_grid_order.txt)
     unsigned b_x = blockIdx.x, b_limb = blockIdx.y, b_job = blockIdx.z;
-    if (limb_slow == 1) { b_limb = blockIdx.z; b_job = blockIdx.y; }
-    else if (limb_slow == 2) {
-        const unsigned xb = (unsigned)((n / C + EW_T - 1) / EW_T) >> 3;          // blocks per XCD lane (launch_mac: a multiple of 8 blocks)
-        b_x = blockIdx.x + 8 * (blockIdx.z % xb); b_limb = blockIdx.z / xb; b_job = blockIdx.y;
-    }
+    if (limb_slow) { b_limb = blockIdx.z; b_job = blockIdx.y; }
     const size_t k = ((size_t)b_x * EW_T + threadIdx.x) * C;
     if (k >= n) return;
     constexpr int SPLIT = MAC_G / G;                            // a job's streams are covered by SPLIT blocks
@@ -1713,7 +1709,7 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
 #ifndef APSU_MAC_C
 #define APSU_MAC_C 2
 #endif
-void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara, bool packed, int limb_slow)
+void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, int njobs, hipStream_t st, bool kara, bool packed)
 {
     if (!njobs || !nlimbs) return;
     constexpr int G = APSU_MAC_G, C = APSU_MAC_C;
@@ -1721,9 +1717,8 @@ void launch_mac(const DevLevel *lv, int nlimbs, const MacJob *jobs, size_t n, in
     //  costs ~0.26 ms more than its chains' length explains, i.e. ~14 us per workgroup; long-lived workgroups that keep the load
     //  pipeline running across chains were 4-9 % SLOWER, starting the first resident generation in phases changed nothing)
     const unsigned gx = (unsigned)((n / C + EW_T - 1) / EW_T), gl = (unsigned)nlimbs, gj = (unsigned)(njobs * (MAC_G / G));
-    int ls = gj <= 65535u ? limb_slow : 0;
-    if (ls == 2 && (gx % 8 != 0 || (size_t)gl * (gx / 8) > 65535u)) ls = 1;
-    const dim3 grid = ls == 2 ? dim3(8, gj, gl * (gx / 8)) : ls == 1 ? dim3(gx, gj, gl) : dim3(gx, gl, gj);
+    const int ls = gj <= 65535u ? 1 : 0;                          // limb slowest (k_mac) unless the jobs do not fit grid dimension y
+    const dim3 grid = ls ? dim3(gx, gj, gl) : dim3(gx, gl, gj);
     if (packed) {
         if constexpr (C == 2) {
             if (kara) hipLaunchKernelGGL((k_mac<G, C, true, true>), grid, dim3(EW_T), 0, st, lv, jobs, n, ls);

@@ -315,8 +315,8 @@ int apsu_he_multi_phase_read(apsu_he_multi *m, uint64_t *count, double *avg_ms, 
 
 /* Scheduling option: ComputePowers may walk the high-power half of the PowersDag on a second HIP stream, next to the
  * low-power half and to the BinBundle inner products (bit-identical results).  mode -1 = default policy (on
- * whenever the PowersDag splits into independent halves and the inputs are device resident), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1 sets the default for
- * contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
+ * whenever the PowersDag splits into independent halves and the inputs are device resident), 0 = off, 1 = on; the environment variable APSU_HE_SPLIT=0/1
+ * (read at apsu_he_create) sets the default for contexts that never call this.  Event profiling (apsu_he_profile_enable) always uses one stream. */
 int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
 
 /* Device-resident pipelines: with on != 0, an apsu_he_eval_bundles call whose masks AND results live in device memory
@@ -324,7 +324,7 @@ int apsu_he_set_two_stream(apsu_he_ctx *ctx, int mode);
  * are complete after apsu_he_sync(ctx), or for work ordered after the context's main HIP stream (apsu_he_stream: a
  * hipStream_t; e.g. hipEventRecord on it + hipStreamWaitEvent on the consumer's stream).  The caller's device buffers must
  * stay alive and unmodified until then.  Host-memory arguments always synchronise, as does event profiling.
- * Default off (APSU_HE_ASYNC=1 turns it on for contexts that never call this). */
+ * Default off. */
 int apsu_he_set_async_results(apsu_he_ctx *ctx, int on);
 /* Overlap of consecutive queries (ABI 6; modes 2 and 3 ABI 7).  With mode != 0 the caller promises that the device-resident inputs
  * of apsu_he_compute_powers -- the source ciphertexts and the relinearisation keys -- are COMPLETE when the call is made, i.e. not

@@ -141,12 +141,16 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
     sc.close()
 
 
-@pytest.mark.parametrize("bits", [(40, 40, 40, 36), (60, 60, 60, 50), (56, 56, 56, 50)])
-def test_seed_expansion_on_the_device_equals_the_host_codec(bits):
+@pytest.mark.parametrize("bits,force_host", [((40, 40, 40, 36), False), ((60, 60, 60, 50), False), ((56, 56, 56, 50), False), ((60, 60, 60, 50), True)])
+def test_seed_expansion_on_the_device_equals_the_host_codec(monkeypatch, bits, force_host):
     """apsu_he_seed_expand (k_seed_bulk + k_seed_fix: SEAL's sample_poly_uniform with its in-stream rejection sampling) against
     the host codec's expansion (itself held against the Python model in tests/test_seal_codec.py): data levels and the key
-    level, several ciphertexts per call, 60-bit primes for hundreds of rejections per limb"""
+    level, several ciphertexts per call, 60-bit primes for hundreds of rejections per limb.  Last case: the engine's own fallback
+    for objects whose rejections overflow the device list -- expansion by the host codec, uploaded -- forced for every object
+    (APSU_HE_SEED_EXPAND_HOST=1, read at apsu_he_create)"""
     import torch
+    if force_host:
+        monkeypatch.setenv("APSU_HE_SEED_EXPAND_HOST", "1")
     n = 1024 if bits[0] == 60 else (8192 if bits[0] == 56 else 64)
     js = common.toy_json(n=n, coeff_bits=bits, plain_bits=17 if n < 8192 else 22)
     G = apsu_amd.HeContext(js)

@@ -124,25 +124,8 @@ int main(int argc, char** argv) {
         printf("  starts per 20 us:"); for (size_t b = 0; b < hist.size() && b < 80; b++) printf(" %d", hist[b]); printf("\n");
     }
 #endif
-    if (getenv("ORDER")) {
-        // grid orders of k_mac (what is resident behind one L2 together) and the price of the shared power loads: the same jobs with
-        // pw_stride = 0 read ONE term's powers over and over (L1 / L2 hits only; wrong sums, timing only)
-        std::vector<MacJob> jobs0 = jobs;
-        for (auto &j : jobs0) j.pw_stride = 0;
-        MacJob *dj0; CHECK(hipMalloc(&dj0, jobs0.size() * sizeof(MacJob))); CHECK(hipMemcpy(dj0, jobs0.data(), jobs0.size() * sizeof(MacJob), hipMemcpyHostToDevice));
-        for (int pass = 0; pass < 2; pass++)
-            for (int pw0 = 0; pw0 < 2; pw0++)
-                for (int order = 0; order < 3; order++) {
-                    std::vector<float> t;
-                    for (int rep = 0; rep < 10; rep++) {
-                        CHECK(hipEventRecord(e0)); launch_mac(lv, 3, pw0 ? dj0 : dj, n, (int)jobs.size(), 0, false, false, order); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
-                        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms);
-                    }
-                    std::sort(t.begin(), t.end());
-                    printf("terms %d  order %d  %s: median %.3f ms (%.0f GB/s)\n", terms, order, pw0 ? "one term's powers (cache hits)" : "real powers                  ", t[t.size() / 2],
-                           words * 8 / (t[t.size() / 2] * 1e-3) / 1e9);
-                }
-    }
+    // (the grid-order comparison that lived here -- ORDER=1: orders 0 / 1 / 2 with real powers and with one term's powers -- is recorded in
+    //  profiles/r04_mac_grid_order.txt; the library keeps order 1 and launch_mac no longer takes an order)
     if (getenv("TILED")) {
         // Is the scan bound by bytes or by the NUMBER of separate pieces it reads?  Row layout (the engine's): a workgroup's G streams
         // are G pieces of 4 KiB (dense) / 3.5 KiB (56-bit packed) per term, each in another stream's slot.  Tiled layout: the G pieces
@@ -168,7 +151,7 @@ int main(int argc, char** argv) {
                 const bool packed = v >= 2; MacJob *dv = v == 0 ? d_jd : v == 1 ? d_jdt : v == 2 ? d_jp : d_jpt;
                 std::vector<float> t;
                 for (int rep = 0; rep < 10; rep++) {
-                    CHECK(hipEventRecord(e0)); launch_mac(packed ? lvp : lv, 3, dv, n, (int)jobs.size(), 0, false, packed, 1); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                    CHECK(hipEventRecord(e0)); launch_mac(packed ? lvp : lv, 3, dv, n, (int)jobs.size(), 0, false, packed); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms);
                 }
                 std::sort(t.begin(), t.end());
