@@ -308,6 +308,12 @@ def _self_made(tmp_path):
     C = ref.RefContext(path["n"], path["coeff_bits"], 0, path["plain_bits"])
     path["coeff_modulus"] = ["%x" % v for v in C.q]
     path["plain_modulus"] = "%x" % C.t
+    path["seal_version"] = "4.0.0"
+    # the generator writes the secret key as SEAL holds it (NTT form at the key level); the repository's golden files carry the
+    # ternary coefficients: convert, so that the self-made file has the generator's field names and no others
+    sk_ntt = _secret_ntt(C, path)
+    del path["secret"]
+    path["secret_ntt"] = [["%x" % int(v) for v in row] for row in sk_ntt]
     q, t, n = C.q, C.t, C.n
     K = len(q)
     sc = seal.SealContext(n=n, coeff_modulus=q, plain_modulus=t)
@@ -365,3 +371,53 @@ def test_gpu_consumers_on_self_made_fixtures(tmp_path):
     finally:
         B.close()
     check_path_gpu(json.loads(json.dumps(path)))
+
+
+# ------------------------------------------------------------------------------------------------ generator <-> consumer schema
+def _json_keys(o, acc):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if not k.lstrip("-").isdigit():                      # "sources" / "powers" are maps keyed by the exponent
+                acc.add(k)
+            _json_keys(v, acc)
+    elif isinstance(o, list):
+        for v in o:
+            _json_keys(v, acc)
+    return acc
+
+
+def _generator_keys():
+    """the field names integration/seal_fixtures.cpp writes, per output file kind (its J.num / J.str / J.hexv / J.raw / J.key calls)"""
+    import re
+    with open(os.path.join(ROOT, "integration", "seal_fixtures.cpp")) as f:
+        src = f.read()
+    cut = {"ops": ("void emit_ops(", "std::map<uint32_t, Node> powers_dag("), "path": ("void emit_path(", "template <class T> string saved("),
+           "objects": ("void emit_objects(", "int main(")}
+    out = {}
+    for kind, (a, b) in cut.items():
+        body = src[src.index(a):src.index(b)]
+        out[kind] = set(re.findall(r"\.(?:num|str|hexv|raw|key)\(\"([A-Za-z_0-9]+)\"", body))
+        assert len(out[kind]) > 8, kind
+    return out
+
+
+def test_generator_and_consumers_agree_on_every_field_name(tmp_path):
+    """A schema drift between the SEAL-side generator (never run here) and the consumers above would only show on the day somebody
+    runs the generator.  Caught here instead: (1) the self-made fixtures that test_consumers_on_self_made_fixtures feeds through
+    the checkers carry EXACTLY the field names the generator's source writes, per file kind; (2) every one of those names is read
+    somewhere in this file's checkers (a field the generator writes and nobody reads is dead weight; a field a checker reads and
+    the generator does not write fails in (1))."""
+    gen = _generator_keys()
+    ops, path, obj = _self_made(tmp_path)
+    mine = {"ops": _json_keys(ops, set()), "path": _json_keys(path, set()), "objects": _json_keys(obj, set())}
+    for kind in ("ops", "path", "objects"):
+        assert gen[kind] == mine[kind], (kind, "only the generator writes: %s" % sorted(gen[kind] - mine[kind]),
+                                        "only the self-made fixture has: %s" % sorted(mine[kind] - gen[kind]))
+    with open(os.path.abspath(__file__)) as f:
+        me = f.read()
+    consumers = me[me.index("def _primes(g):"):
+                   me.index("# ------------------------------------------------------------------------------------------------ the consumers themselves")]
+    informational = {"seal_version", "x", "noise_budget", "plain_bits", "coeff_bits", "n", "seeded", "compr"}   # read below or descriptive
+    for kind in ("ops", "path", "objects"):
+        for k in sorted(gen[kind]):
+            assert ('"%s"' % k) in consumers or k in informational, "field %r of seal_%s_*.json is never read by a checker" % (k, kind)
