@@ -126,6 +126,32 @@ int main(int argc, char** argv) {
 #endif
     // (the grid-order comparison that lived here -- ORDER=1: orders 0 / 1 / 2 with real powers and with one term's powers -- is recorded in
     //  profiles/r04_mac_grid_order.txt; the library keeps order 1 and launch_mac no longer takes an order)
+    if (getenv("PLACEMENT")) {
+        // Does the scan's speed depend on WHERE the database lies?  (Identical binaries run one after the other alternate between 1.12 and
+        // 1.26 ms, profiles/r05_mac_ring3.txt.)  Several copies of the same database in ONE process, the same kernel on each in turn;
+        // SKEW_LIST: the same with the streams of one copy moved apart by extra words (relative alignment of the concurrently read rows).
+        const int copies = atoi(getenv("PLACEMENT"));
+        std::vector<u64 *> dbs{ db };
+        for (int c = 1; c < copies; c++) { u64 *d2; CHECK(hipMalloc(&d2, (words + (size_t)streams * 8192) * 8)); k_fillrand<<<4096, 256>>>(d2, words + (size_t)streams * 8192, ((u64)1 << 55) - 1); dbs.push_back(d2); }
+        std::vector<size_t> skews{ 0 };
+        if (getenv("SKEW_LIST")) { skews.clear(); char *t = strdup(getenv("SKEW_LIST")); for (char *q2 = strtok(t, ","); q2; q2 = strtok(nullptr, ",")) skews.push_back((size_t)atoll(q2)); }
+        for (int pass = 0; pass < 3; pass++)
+            for (size_t c = 0; c < dbs.size(); c++)
+                for (size_t sk : skews) {
+                    if (c == 0 && sk > skew) continue;              // the first copy was allocated without room for a skew
+                    std::vector<MacJob> jc = jobs;
+                    for (size_t x = 0; x < jc.size(); x++) for (int g = 0; g < MAC_G; g++) jc[x].pt[g] = dbs[c] + (x * MAC_G + g) * (terms * ptw + sk);
+                    MacJob *djc; CHECK(hipMalloc(&djc, jc.size() * sizeof(MacJob))); CHECK(hipMemcpy(djc, jc.data(), jc.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+                    std::vector<float> t;
+                    for (int rep = 0; rep < 8; rep++) {
+                        CHECK(hipEventRecord(e0)); launch_mac(lv, 3, djc, n, (int)jc.size(), 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms);
+                    }
+                    std::sort(t.begin(), t.end());
+                    printf("pass %d  copy %zu at %p  skew %5zu words: median %.3f ms (%.0f GB/s)\n", pass, c, (void *)dbs[c], sk, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9);
+                    CHECK(hipFree(djc));
+                }
+    }
     if (getenv("TILED")) {
         // Is the scan bound by bytes or by the NUMBER of separate pieces it reads?  Row layout (the engine's): a workgroup's G streams
         // are G pieces of 4 KiB (dense) / 3.5 KiB (56-bit packed) per term, each in another stream's slot.  Tiled layout: the G pieces
