@@ -208,7 +208,17 @@ struct MultiEngine::Rccl {
     InitAll init_all = nullptr; AllGather all_gather = nullptr; Destroy destroy = nullptr, abort = nullptr; ErrStr err = nullptr;
     std::vector<void *> comms;
     std::atomic<bool> broken{ false };                           // a collective failed: communicators were aborted, fall back to peer copies
-    void abort_all() { broken = true; if (abort) for (void *&c : comms) if (c) { (void)abort(c); c = nullptr; } }
+    std::mutex abort_mu;
+    // Called from worker threads whose all-gather failed.  Exactly ONE thread aborts: several workers may fail in the same collective,
+    // and ncclCommAbort must not run twice on a communicator nor next to a worker that is still reading its entry of `comms` --
+    // every worker copies its communicator before the rendezvous (comm_of), the entries are cleared under the lock.
+    void abort_all()
+    {
+        std::lock_guard<std::mutex> g(abort_mu);
+        if (broken.exchange(true)) return;
+        if (abort) for (void *&c : comms) if (c) { (void)abort(c); c = nullptr; }
+    }
+    void *comm_of(int slot) { std::lock_guard<std::mutex> g(abort_mu); return broken ? nullptr : comms[(size_t)slot]; }
     ~Rccl() { if (destroy) for (void *c : comms) if (c) (void)destroy(c); if (lib) dlclose(lib); }
 };
 
@@ -465,16 +475,18 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
         }
         } catch (...) { compute_error = std::current_exception(); }
         if (use_rccl) {
-            const bool all_ok = meet.arrive(!compute_error);
+            int my_slot = 0;
+            for (size_t i = 0; i < devs_.size(); i++) if (devs_[i].get() == &d) my_slot = (int)i;
+            void *const my_comm = rccl_->comm_of(my_slot);        // taken before the rendezvous: a failing peer clears the table
+            const bool all_ok = meet.arrive(!compute_error && my_comm != nullptr);
             if (compute_error) std::rethrow_exception(compute_error);
             if (!all_ok) { (void)hipStreamSynchronize(st); throw std::runtime_error("another device failed before the RCCL gather; nothing was gathered"); }
             // ONE all-gather of max_rows fixed-size rows per device, then the output device places them by id
-            int slot = 0;
-            for (size_t i = 0; i < devs_.size(); i++) if (devs_[i].get() == &d) slot = (int)i;
+            const int slot = my_slot;
             const size_t need = devs_.size() * max_rows * row * sizeof(u64);
             if (d.gath.bytes() < need) { E.wait(); d.gath.alloc(need); }
             if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.wait(); d.out.alloc(max_rows * row * sizeof(u64)); }
-            const int rc = rccl_->all_gather(d.out.u(), d.gath.u(), max_rows * row, /* ncclUint64 */ 5, rccl_->comms[slot], st);
+            const int rc = rccl_->all_gather(d.out.u(), d.gath.u(), max_rows * row, /* ncclUint64 */ 5, my_comm, st);
             if (rc != 0) {                                        // the peers may already sit in the collective: abort every communicator so they return
                 const std::string why = rccl_->err ? rccl_->err(rc) : "?";
                 rccl_->abort_all();
