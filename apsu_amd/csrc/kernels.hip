@@ -1654,27 +1654,6 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
     };
 
     const u32 cnt = job.cnt;
-#ifdef APSU_MAC_RING3
-    // experiment (tools/microbench/macbench.hip, -DAPSU_MAC_RING3): THREE register sets, the loads of term i + 2 leave -- all six at once,
-    // behind a scheduling barrier -- before term i is consumed: two whole terms in flight at every wait (the two-set loop below has
-    // one, issued one multiply-accumulate period ahead: 0.28 - 0.56 us against ~0.7 us of loaded memory latency, profiles/r05_mac_pmc.txt)
-    {
-        Term R0, R1, R2;
-        auto ld = [&](u32 i, Term &t) { load_term(i < cnt ? i : cnt - 1, t); __builtin_amdgcn_sched_barrier(0); };
-        ld(0, R0); ld(1, R1);
-        u32 in_chunk3 = 0, i = 0;
-        for (; i + 3 <= cnt; i += 3) {
-            ld(i + 2, R2); mac_term(R0); __builtin_amdgcn_sched_barrier(0);
-            ld(i + 3, R0); mac_term(R1); __builtin_amdgcn_sched_barrier(0);
-            ld(i + 4, R1); mac_term(R2); __builtin_amdgcn_sched_barrier(0);
-            in_chunk3 += 3;
-            if (in_chunk3 + 4 > chunk) { fold(false); in_chunk3 = 1; }
-        }
-        if (i < cnt) { mac_term(R0); i++; }                      // R0 / R1 hold terms i, i + 1 (clamped reloads of the last term otherwise)
-        if (i < cnt) { mac_term(R1); i++; }
-        fold(true);
-    }
-#else
     Term A, B;                                                   // ping-pong register sets: no copies
     MAC_STAMP(1);
     load_term(0, A);
@@ -1696,7 +1675,6 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
     MAC_STAMP(3);
     fold(true);
     MAC_STAMP(4);
-#endif
 #pragma unroll
     for (int g = 0; g < G; g++) {
         if (g0 + g < (int)job.ng) {
