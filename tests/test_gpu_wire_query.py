@@ -126,6 +126,21 @@ def test_framed_seeded_query_runs_through_the_engine(compr):
     bad_parts = [(e, ([forged] + list(c[1:])) if e == S.sources[0] else c) for e, c in plain_parts]
     with pytest.raises((ValueError, apsu_amd.ApsuHeError), match="coeff_modulus_size|first data level"):
         seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, bad_parts), gb, [b["mask"] for b in S.bundles], compr=compr)
+    # a coefficient that is not a residue of its prime (SEALObject::extract -> is_valid_for -> is_data_valid_for in the reference): refused --
+    # the engine's lazy transforms take source limbs as they are, an out-of-range word must not reach them
+    for poly, limb in ((0, 0), (1, first)):
+        wrong = expanded[(0, S.sources[0])].copy()
+        wrong[poly, limb, 5] = int(C.q[limb])                        # == q: the smallest value outside [0, q)
+        bad_ct = sc.ct_save(first, False, wrong, compr=compr)
+        bad_parts = [(e, ([bad_ct] + list(c[1:])) if e == S.sources[0] else c) for e, c in plain_parts]
+        with pytest.raises((ValueError, apsu_amd.ApsuHeError), match="outside"):
+            seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, bad_parts), gb, [b["mask"] for b in S.bundles], compr=compr)
+    wrong_rk = S.rk.copy()
+    wrong_rk[0, 1, K - 1, 7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with pytest.raises((ValueError, apsu_amd.ApsuHeError), match="outside"):
+        seal.run_query_request(G, sc, wire.build_query_request(compr, sc.relin_keys_save(wrong_rk, compr=compr), plain_parts), gb,
+                               [b["mask"] for b in S.bundles], compr=compr)
+    assert seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, plain_parts), gb, [b["mask"] for b in S.bundles], compr=compr) == pkgs
     with pytest.raises(ValueError, match="query powers"):            # a part with a foreign exponent (query.cpp:63-68)
         seal.run_query_request(G, sc, wire.build_query_request(compr, rk_blob, [(e + 1, c) for e, c in parts]), gb, [b["mask"] for b in S.bundles])
     with pytest.raises(ValueError, match="relinearization"):
