@@ -4,8 +4,9 @@ bench.py's queued rate and every multi-query caller run ComputePowers of query k
 (apsu_he_set_async_results + apsu_he_set_query_overlap: three streams, up to three pooled powers buffers, event-chained).
 The reference gets per-query isolation for free -- a fresh `all_powers` per Receiver::RunQuery
 (receiver/apsu/receiver_osn.cpp:286-364) -- so the engine must give the bits of the one-query-at-a-time path whatever it
-overlaps.  What these tests pin down, at BASELINE.json's 16M-4096 size (an evaluation of five full-degree BinBundles
-and a short one lasts ~0.6 ms, longer than the host needs to queue the next query):
+overlaps.  What these tests pin down, at BASELINE.json's sizes -- 16M-4096 (five full-degree BinBundles and a short one: an
+evaluation lasts ~0.6 ms, longer than the host needs to queue the next query) and 256M-4096 (a BinBundle of degree 3999 and one
+of degree 1000; its powers change level on their way out of the DAG, on the second stream when pipelined):
 
 * K queued queries that ALTERNATE IRREGULARLY between two source sets and two mask sets (every lag 1, 2, 3 holds both an
   equal and a different pair of kinds, so a query that reads the powers, the workspace or the job tables of query k-1,
@@ -30,9 +31,11 @@ from oracle import ref
 
 pytestmark = pytest.mark.gpu
 
-CFG = "16M-4096"
-IDX = 1                                           # the bundle index every BinBundle of these tests belongs to
-SHORT = 170
+# (parameter set, bundle index of every BinBundle of the test, degrees: full-degree BinBundles of max_items_per_bin - 1 plus a short one).
+# 16M-4096: the low powers stay at the first data level (gathered forward transform straight out of the DAG's slots); 256M-4096: four
+# data primes, the low powers are switched down one level and the high ones two on the way out (modulus-switch kernels on the second
+# stream), 322 target powers per bundle index
+WORLDS = [("16M-4096", 1, lambda D: [D] * 5 + [170]), ("256M-4096", 2, lambda D: [D, 1000])]
 KINDS = [0, 1, 1, 0, 0, 0, 1, 0, 1, 1, 0, 1]      # source set of query k   (lags 1, 2, 3: equal and different pairs)
 MASKS = [0, 0, 1, 0, 1, 1, 0, 1, 1, 0, 0, 1]      # mask set of query k
 K = len(KINDS)
@@ -43,17 +46,18 @@ def _bundle_seed(ci):
     return SEED + 7919 * ci
 
 
-@pytest.fixture(scope="module")
-def world():
+@pytest.fixture(scope="module", params=WORLDS, ids=[w[0] for w in WORLDS])
+def world(request):
     """sources A / B, masks M0 / M1, relin keys, and the ORACLE's results for every (sources, masks) pair and BinBundle"""
     from bench import splitmix_values
+    CFG, IDX, degrees_of = request.param
     js = common.param_json(CFG)
     p = ref.load_params(js)
     C = ref.RefContext.from_params(p)
     n, t = C.n, C.t
     ps = p["ps_low_degree"]
     D = p["max_items_per_bin"] - 1
-    degrees = [D] * 5 + [SHORT]
+    degrees = degrees_of(D)
     targets = ref.create_powers_set(ps, p["max_items_per_bin"])
     _, nodes = ref.powers_dag(p["query_powers"], targets)
     sources = sorted(p["query_powers"])
@@ -104,7 +108,7 @@ def world():
     class W:
         pass
     w = W()
-    w.js, w.n, w.t, w.ns, w.Lf, w.degrees, w.targets = js, n, t, ns, Lf, degrees, targets
+    w.js, w.n, w.t, w.ns, w.Lf, w.degrees, w.targets, w.idx, w.cfg = js, n, t, ns, Lf, degrees, targets, IDX, CFG
     w.src, w.rkh, w.masks, w.want, w.opw = src, rkh, masks, want, opw
     # the two kinds must not agree by accident anywhere a hazard could hide
     assert (want[(0, 0, 0)] != want[(1, 0, 0)]).mean() > 0.99 and (want[(0, 0, 0)][0] != want[(0, 1, 0)][0]).mean() > 0.99    # (a mask changes c0 only)
@@ -119,7 +123,7 @@ class Rig:
         self.torch, self.w = torch, w
         G = self.G = apsu_amd.HeContext(w.js)
         self.rk = G.upload_relin_keys(w.rkh)
-        self.bundles = [G.random_bundle(IDX, ci, deg, _bundle_seed(ci)) for ci, deg in enumerate(w.degrees)]
+        self.bundles = [G.random_bundle(w.idx, ci, deg, _bundle_seed(ci)) for ci, deg in enumerate(w.degrees)]
         self.src_d = [torch.from_numpy(s.view(np.int64)).cuda() for s in w.src]
         words = 2 * w.Lf * w.n
         self.src_ptrs = [[[sd.data_ptr() + s * words * 8 for s in range(w.ns)]] for sd in self.src_d]
@@ -132,7 +136,7 @@ class Rig:
         return [self.torch.full((len(self.w.degrees), 2, self.w.n), -1, dtype=self.torch.int64, device="cuda") for _ in range(count)]
 
     def query(self, kind, mk, out, hold=None):
-        pw = self.G.compute_powers([IDX], self.src_ptrs[kind], self.rk, on_device=True)
+        pw = self.G.compute_powers([self.w.idx], self.src_ptrs[kind], self.rk, on_device=True)
         self.G.eval_bundles(self.bundles, pw, self.rk, self.mask_ptrs[mk], out=out.data_ptr(), masks_on_device=True, out_on_device=True)
         return pw
 
@@ -185,7 +189,7 @@ def test_queued_queries_are_isolated(world, monkeypatch, mode, side, two_stream,
     if mode == 3:
         assert piped == K, "forced mode: every ComputePowers takes the pipelined walk"
     elif mode == 1 and two_stream != 0:
-        assert piped >= 1, "an evaluation of 1.3 GB of BinBundles outlasts the host's queueing of the next query"
+        assert piped >= 1, "an evaluation of a gigabyte of BinBundles outlasts the host's queueing of the next query"
     else:
         assert piped == 0
     for k in range(K):
@@ -216,10 +220,10 @@ def test_dropped_powers_do_not_leak_into_the_next_query(world, mode):
         pw = rig.query(1, 1, outs[1 + 2 * r])              # a long evaluation in front ...
         del pw
         kind_drop, kind_keep = (0, 1) if r % 2 == 0 else (1, 0)
-        dropped = G.compute_powers([IDX], rig.src_ptrs[kind_drop], rig.rk, on_device=True)
+        dropped = G.compute_powers([world.idx], rig.src_ptrs[kind_drop], rig.rk, on_device=True)
         del dropped                                         # ... a query that is dropped before its evaluation ...
         if r == 1:                                          # (twice in a row)
-            dropped = G.compute_powers([IDX], rig.src_ptrs[kind_drop], rig.rk, on_device=True)
+            dropped = G.compute_powers([world.idx], rig.src_ptrs[kind_drop], rig.rk, on_device=True)
             del dropped
         pw = rig.query(kind_keep, r % 2, outs[2 + 2 * r])   # ... and the query whose result is checked
         del pw
@@ -242,7 +246,7 @@ def test_powers_of_a_pipelined_query_match_the_oracle(world):
     pw = rig.query(1, 1, outs[1]); del pw
     pw = rig.query(0, 1, outs[2])
     for power in world.targets:
-        ct, _, _ = pw.download(IDX, power)
+        ct, _, _ = pw.download(world.idx, power)
         assert (ct == world.opw[0][power]).all(), "power %d" % power
     rig.check(outs[2], 0, 1, "third query")
     rig.check(outs[1], 1, 1, "second query")
