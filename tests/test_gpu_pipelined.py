@@ -252,3 +252,83 @@ def test_powers_of_a_pipelined_query_match_the_oracle(world):
     rig.check(outs[1], 1, 1, "second query")
     del pw
     rig.close()
+
+
+@pytest.mark.parametrize("walk_seed", [2026, 7, 99])
+def test_scheduler_fuzz_with_changing_policies(walk_seed):
+    """150 queued queries at 1M-1024-com (two bundle indices) under a seeded random walk over everything a caller can change between
+    queries: overlap mode 0-3, one / two streams, phase timers on / off, synchronous or queued results, powers freed / held / dropped
+    without an evaluation, subsets of the BinBundles (job tables and workspace change shape), an occasional host wait.  Every output
+    is compared with the oracle's result for its (sources, masks) pair."""
+    import torch
+    js = common.param_json("1M-1024-com")
+    SA = common.make_scenario(js, {0: [124, 17, 60], 1: [99, 3, 124]}, seed=common.SEED0)
+    SB = common.make_scenario(js, {0: [124, 17, 60], 1: [99, 3, 124]}, seed=common.SEED0 + 77)     # other query, other keys are NOT used: see below
+    # one key set for both queries: query B is re-encrypted under A's secret (make_scenario derives x and the sources from the seed)
+    C = SA.C
+    SB.sk, SB.rk = SA.sk, SA.rk
+    for b in SB.bundle_indices:
+        for e in SB.sources:
+            xe = np.array([pow(int(v), e, C.t) for v in SB.x[b]], dtype=np.uint64)
+            SB.src[b][e] = C.encrypt(SA.sk, C.encode(xe), common.SEED0 + 5000 * (b + 1) + e)
+    S = [SA, SB]
+    opw = [common.oracle_powers(s) for s in S]
+    bundles = SA.bundles                                           # the database is SA's; masks: SA's and SB's
+    masks = [np.stack([b["mask"] for b in SA.bundles]), np.stack([b["mask"] for b in SB.bundles])]
+    want = {}
+    for kind in range(2):
+        for mk in range(2):
+            for i, b in enumerate(bundles):
+                bb = dict(b, mask=masks[mk][i])
+                want[(kind, mk, i)] = common.oracle_eval(S[kind], opw[kind], bb)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(SA.rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in bundles]
+    ns = len(SA.sources)
+    src_d, ptrs = [], []
+    for s in S:
+        a = np.stack([np.stack([s.src[b][e] for e in s.sources]) for b in s.bundle_indices])
+        d = torch.from_numpy(a.view(np.int64)).cuda()
+        w = a[0, 0].size
+        src_d.append(d)
+        ptrs.append({b: [d.data_ptr() + ((bi * ns + i) * w) * 8 for i in range(ns)] for bi, b in enumerate(s.bundle_indices)})
+    mask_d = [torch.from_numpy(m.view(np.int64)).cuda() for m in masks]
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(walk_seed)
+    pending, held = [], []
+    G.set_async_results(True)
+    for q in range(150):
+        r = rng.random()
+        if r < 0.25:
+            G.set_query_overlap(int(rng.integers(0, 4)))
+        elif r < 0.35:
+            G.set_two_stream(int(rng.integers(-1, 2)))
+        elif r < 0.40:
+            G.phase_enable(bool(rng.integers(0, 2)))
+        elif r < 0.45:
+            G.set_async_results(bool(rng.integers(0, 2)))
+        elif r < 0.50:
+            G.sync()
+        kind, mk = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        sub = sorted(int(v) for v in rng.choice(len(gb), size=int(rng.integers(1, len(gb) + 1)), replace=False))
+        idx = sorted({bundles[i]["bundle_idx"] for i in sub})
+        if rng.random() < 0.15:                                    # a query that is dropped before its evaluation
+            dropped = G.compute_powers(idx, [ptrs[1 - kind][b] for b in idx], rk, on_device=True)
+            del dropped
+        pw = G.compute_powers(idx, [ptrs[kind][b] for b in idx], rk, on_device=True)
+        out = torch.full((len(sub), 2, G.n), -1, dtype=torch.int64, device="cuda")
+        G.eval_bundles([gb[i] for i in sub], pw, rk, [mask_d[mk].data_ptr() + i * G.n * 8 for i in sub], out=out.data_ptr(),
+                       masks_on_device=True, out_on_device=True)
+        pending.append((q, kind, mk, sub, out))
+        if rng.random() < 0.3:
+            held.append(pw)                                        # the caller keeps some powers alive for a while
+            if len(held) > 3:
+                held.pop(0)
+        del pw
+    G.sync()
+    G.phase_enable(False)
+    for q, kind, mk, sub, out in pending:
+        got = out.cpu().numpy().view(np.uint64)
+        for row, i in enumerate(sub):
+            assert (got[row] == want[(kind, mk, i)].reshape(2, G.n)).all(), "query %d (sources %d, masks %d), BinBundle %d" % (q, kind, mk, i)
+    G.close()
