@@ -140,6 +140,8 @@ void launch_modswitch(const DevLevel *lv, const u64 *in, size_t in_stride, int p
 void launch_clear_bits(u64 *ct, size_t words, int bits, hipStream_t st);
 struct CtJob { const u64 *src; u64 *dst; };
 void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st);
+// copy of query source ciphertexts ([2][L][n] words each) that flags words outside [0, q_limb) in *bad (device-visible host memory)
+void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, hipStream_t st);
 // drop last limb of `polys` polynomials per job: src [polys][L][n] -> dst [polys][L-1][n]
 void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);

@@ -398,6 +398,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     lanes_[2].arena.alloc((size_t)1 << 20);
     stage_bytes_ = 4u << 20;
     HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&bad_source_), 64));
+    *bad_source_ = 0;
 }
 
 Engine::~Engine()
@@ -419,6 +421,7 @@ Engine::~Engine()
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_side_) (void)hipEventDestroy(ev_side_);
     if (stage_) (void)hipHostFree(stage_);
+    if (bad_source_) (void)hipHostFree(bad_source_);
     if (wire_pinned_) (void)hipHostFree(wire_pinned_);
 }
 
@@ -445,10 +448,23 @@ void Engine::sync()
     if (prof_on_) prof_collect();
 }
 
+// Called where a PUBLIC entry point has just waited for the device (apsu_he_sync, a synchronous apsu_he_eval_bundles, apsu_he_powers_download):
+// k_copy_sources of a query whose work has completed by now may have found a source coefficient outside [0, q).  (Not inside sync():
+// the engine also waits in the middle of its own bookkeeping -- arena growth, job-table reallocation -- where nothing may be thrown.)
+void Engine::check_sources()
+{
+    if (bad_source_ && *bad_source_) {
+        *bad_source_ = 0;
+        throw std::invalid_argument("a source ciphertext of apsu_he_compute_powers holds a coefficient outside [0, q): the results computed from it "
+                                    "are not valid (seal::is_data_valid_for)");
+    }
+}
+
 void Engine::wait()
 {
     Enter g(this);
     sync();
+    check_sources();
 }
 
 void Engine::switch_lane(int lane)
@@ -1324,7 +1340,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 }
                 si++;
             }
-            if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_jobs(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), st_); }
+            if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_sources(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), dlevel(first), (int)Lf, n, bad_source_, st_); }
             if (s.levels.size() > 1) {
                 run.ext = ws(P * nb * 2 * Ef * n);
                 size_t max_nodes = 0;
@@ -1615,6 +1631,7 @@ void Engine::download_power(const Powers &pw, uint32_t bundle_idx, uint32_t powe
     const size_t words = (size_t)power_size(power) * (lvl + 1) * hp_.n;               // the stored slot may be zero-padded beyond that
     if (capacity_words < words) throw std::invalid_argument("output buffer too small");
     sync();
+    check_sources();
     const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * pw.polys * (lvl + 1) * hp_.n;
     HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
     if (chain_idx) *chain_idx = lvl;
@@ -2544,6 +2561,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     int chunk = (int)std::max<size_t>(1, budget / (per_bundle_words * sizeof(u64)));
     chunk = std::min(chunk, count);
 
+    bool synced = false;
     for (int c0 = 0; c0 < count; c0 += chunk) {
         const int B = std::min(chunk, count - c0);
         WITH_ARENA({
@@ -2572,10 +2590,11 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
                 phase_spans_.push_back(ev_span);
                 if (query_start_) { if (query_end_) phase_pool_.push_back(query_end_); query_end_ = phase_event(st_); }
             }
-            if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) { sync(); inflight_count_ = 0; }
+            if (!(async_results_ && out_on_device && masks_on_device && !prof_on_)) { sync(); inflight_count_ = 0; synced = true; }
             else mark_inflight();
         });
     }
+    if (synced) check_sources();
 }
 
 // ============================================================================ no key switching: ciphertexts of any size

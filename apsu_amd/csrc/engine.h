@@ -215,7 +215,7 @@ public:
     // tier 1 on device-resident operands: the per-method calls take device pointers and return with their work queued on the
     // engine's stream (no host round trip per Evaluator call); see apsu_he_set_tier1_on_device
     void set_tier1_on_device(bool on) { std::lock_guard<std::mutex> g(mu_); tier1_device_ = on; }
-    void wait();                                                  // locked sync()
+    void wait();                                                  // locked sync() + check_sources()
     // test hook: copy one computed power to the host (serialised with the other calls on this context)
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
                         int *is_ntt);
@@ -300,6 +300,10 @@ private:
     int max_inflight_ = 2;
     void throttle_inflight();
     void mark_inflight();
+    // device-resident source ciphertexts are checked while they are gathered (k_copy_sources: every word below its limb's prime, SEAL's
+    // is_data_valid_for); the kernel raises this word of page-locked host memory, sync() looks at it and throws std::invalid_argument
+    unsigned *bad_source_ = nullptr;
+    void check_sources();
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
     // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the

@@ -486,6 +486,31 @@ __global__ __launch_bounds__(EW_T) void k_copy_jobs(const CtJob *__restrict__ jo
         *reinterpret_cast<u64x2 *>(job.dst + k) = *reinterpret_cast<const u64x2 *>(job.src + k);
 }
 
+// The same for the source ciphertexts of a query ([2][L][n] each): while it copies, every word is held against the prime of its limb
+// (seal::is_data_valid_for); a word outside [0, q) raises *bad -- a word of page-locked host memory the engine looks at when it next
+// waits for the device.  The lazy transforms take source limbs as they are, so such a word must not pass silently.
+__global__ __launch_bounds__(EW_T) void k_copy_sources(const CtJob *__restrict__ jobs, size_t words, const DevLevel *__restrict__ lv, int L, size_t n,
+                                                       unsigned *__restrict__ bad)
+{
+    const CtJob job = jobs[blockIdx.y];
+    bool wrong = false;
+    for (size_t k = ((size_t)blockIdx.x * EW_T + threadIdx.x) * 2; k < words; k += (size_t)gridDim.x * EW_T * 2) {
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(job.src + k);
+        const u64 q = lv->q[(k / n) % (size_t)L].q;                 // (n is even: both words lie in the same limb)
+        wrong |= v[0] >= q || v[1] >= q;
+        *reinterpret_cast<u64x2 *>(job.dst + k) = v;
+    }
+    if (wrong) atomicOr(bad, 1u);
+}
+
+void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, hipStream_t st)
+{
+    if (!njobs) return;
+    unsigned gx = (unsigned)std::min<size_t>((words / 2 + EW_T - 1) / EW_T, 64);
+    hipLaunchKernelGGL(k_copy_sources, dim3(gx, (unsigned)njobs), dim3(EW_T), 0, st, jobs, words, lv, L, n, bad);
+    KERNEL_CHECK();
+}
+
 void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st)
 {
     if (!njobs) return;

@@ -221,7 +221,9 @@ int apsu_he_bundle_bytes(const apsu_he_bundle *b, uint64_t *db_bytes);
  * src_on_device != 0: the pointers are device pointers (inputs already resident in HBM).
  * Every coefficient must be a canonical residue of its limb's prime, which is what a valid seal::Ciphertext holds
  * (seal::is_data_valid_for, checked by SEALObject::extract in the reference, seal_object.h:161-219): the engine's lazy transforms
- * take source limbs as they are.  apsu_he_run_query_request checks it on the decoded objects and fails like the reference. */
+ * take source limbs as they are.  apsu_he_run_query_request checks it on the decoded objects and fails like the reference; device-resident
+ * sources are checked by the kernel that gathers them, and a violation is reported (APSU_HE_INVALID_ARGUMENT) by the call that next
+ * waits for that work: a synchronous apsu_he_eval_bundles, apsu_he_powers_download or apsu_he_sync. */
 int apsu_he_compute_powers(apsu_he_ctx *ctx, const uint32_t *bundle_indices, int n_bundle_idx,
                            const uint64_t *const *src_cts, int src_on_device, const apsu_he_relin *rk,
                            apsu_he_powers **out);

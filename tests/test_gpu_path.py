@@ -187,6 +187,46 @@ def test_device_resident_io_and_profile_hooks():
     G.close()
 
 
+def test_device_resident_sources_outside_their_prime_are_reported():
+    """seal::is_data_valid_for for sources handed over as device pointers (tier 2, `src_on_device`): the engine's lazy transforms take source limbs
+    as they are, so a word >= q_limb must not pass silently.  The kernel that gathers the sources checks every word; the violation is
+    reported by the call that next waits for that work -- a synchronous eval_bundles, or apsu_he_sync in the queued mode -- and the context
+    stays usable"""
+    import torch
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 17]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    src = np.stack([S.src[0][e] for e in S.sources])
+    w = src[0].size
+    good = torch.from_numpy(src.view(np.int64)).cuda()
+    wrong = src.copy()
+    wrong[3, 1, 1, 77] = np.uint64(int(S.C.q[1]))                    # source 3, polynomial 1, limb 1: == q, the smallest invalid value
+    bad = torch.from_numpy(wrong.view(np.int64)).cuda()
+    ptrs = lambda d: [[d.data_ptr() + i * w * 8 for i in range(len(S.sources))]]
+    want = np.stack([common.oracle_eval(S, opw, b) for b in S.bundles])
+    with pytest.raises(ValueError, match="outside"):                 # synchronous evaluation: reported right there
+        G.eval_bundles(gb, G.compute_powers([0], ptrs(bad), rk, on_device=True), rk, masks)
+    assert (G.eval_bundles(gb, G.compute_powers([0], ptrs(good), rk, on_device=True), rk, masks) == want).all()
+    # queued mode: nothing waits inside the calls, apsu_he_sync reports it
+    G.set_async_results(True)
+    md = torch.from_numpy(np.stack(masks).view(np.int64)).cuda()
+    od = torch.zeros((len(gb), 2, G.n), dtype=torch.int64, device="cuda")
+    mp = [md.data_ptr() + i * G.n * 8 for i in range(len(gb))]
+    pw = G.compute_powers([0], ptrs(bad), rk, on_device=True)
+    G.eval_bundles(gb, pw, rk, mp, out=od.data_ptr(), masks_on_device=True, out_on_device=True)
+    with pytest.raises(ValueError, match="outside"):
+        G.sync()
+    pw = G.compute_powers([0], ptrs(good), rk, on_device=True)
+    G.eval_bundles(gb, pw, rk, mp, out=od.data_ptr(), masks_on_device=True, out_on_device=True)
+    G.sync()
+    assert (od.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all()
+    G.close()
+
+
 @pytest.mark.parametrize("overlap", [0, 1, 2, 3])
 def test_async_device_results(overlap):
     """apsu_he_set_query_overlap (modes 1-3): the next query's high-power chain / whole ComputePowers may start before the query in front has finished --
