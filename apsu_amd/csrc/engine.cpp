@@ -91,6 +91,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     HIP_CHECK(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_intt_, hipEventDisableTiming));
 
     const size_t n = hp_.n;
     const int nmod = (int)hp_.ntt.size();
@@ -420,6 +421,7 @@ Engine::~Engine()
     if (ev_main_) (void)hipEventDestroy(ev_main_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_side_) (void)hipEventDestroy(ev_side_);
+    if (ev_intt_) (void)hipEventDestroy(ev_intt_);
     if (stage_) (void)hipHostFree(stage_);
     if (bad_source_) (void)hipHostFree(bad_source_);
     if (wire_pinned_) (void)hipHostFree(wire_pinned_);
@@ -2298,8 +2300,18 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     const std::vector<int> &nin = g.nin, &in_off = g.in_off;
     u64 *inner = g.inner, *ssum = g.ssum, *vlast = g.vlast, *term = g.term;
     { PROF(P_MAC, g.units); launch_mac(dlevel(low), (int)Ll, g.mac_jobs, n, g.n_mac, st_, mac_kara(low, g.mean_cnt), g.mac_is_packed); }
-    if (g.n_term) { PROF(P_MAC, (uint64_t)g.n_term * (g.term_packed ? packed_row_bits(hp_.key_q[Ll - 1]) : 64)); launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_); }
-    d_ntt(inner, g.imap.size(), upload_jobs(g.imap), (int)g.imap.size(), true);               // :268,297,320,333
+    // Side lane (rounds 4, 5): see below.  side_tp (round 5): the i = 0 block's per-term products and THEIR inverse transforms leave the main
+    // stream too -- they feed only the i = 0 finish, which runs on the side lane anyway -- so the main chain behind k_mac starts with the
+    // inner polynomials alone: -0.017 ms (-0.5 %) on the latency of the 16M-4096 query over four order-balanced A/B runs, -1.7 % on the
+    // N = 8 shard, same bits (profiles/r05_ab_side_term_product.txt)
+    const bool side_tp = eval_side_ && plan.late_high && !prof_on_ && i0_fast && low != high && lanes_[2].st && cur_lane_ == 0 &&
+                         (size_t)Bs * l <= 4096 && g.n_term && plan.need_vlast;
+    const size_t n_vlast = side_tp ? (size_t)Bs * l * 2 : 0;
+    const int *imap_dev = upload_jobs(g.imap);
+    if (side_tp) HIP_CHECK(hipEventRecord(ev_fork_, st_));    // behind k_mac (the powers and the database are read-only from here on)
+    else if (g.n_term) { PROF(P_MAC, (uint64_t)g.n_term * (g.term_packed ? packed_row_bits(hp_.key_q[Ll - 1]) : 64)); launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_); }
+    d_ntt(inner, g.imap.size() - n_vlast, imap_dev, (int)g.imap.size(), true);               // :268,297,320,333
+    if (side_tp) HIP_CHECK(hipEventRecord(ev_intt_, st_));
 
     // Side lane (round 4).  Two pieces of the evaluation hang off nothing that follows on the main stream: the sums of the
     // coefficient-form products (they read the high powers and the database, :328-337) and the i = 0 block's finish (it reads the
@@ -2326,13 +2338,18 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         if (side_i0)
             for (int x = 0; x < Bs; x++)
                 ij.push_back(I0Job{ ssum + (size_t)x * 2 * Lh * n, vlast + (size_t)x * l * 2 * n, i0_side + (size_t)x * 2 * Lh * n, (int)l, 1 });
-        HIP_CHECK(hipEventRecord(ev_fork_, st_));
+        if (!side_tp) HIP_CHECK(hipEventRecord(ev_fork_, st_));
         switch_lane(2);
         struct Back { Engine *e; ~Back() { e->switch_lane(0); } } back{ this };
         HIP_CHECK(hipStreamWaitEvent(st_, ev_fork_, 0));
+        if (side_tp) {
+            launch_term_product(dlevel(low), g.term_jobs, g.n_term, n, (int)Ll - 1, (u32)(Ll * n), (u32)n, g.term_packed, st_);
+            d_ntt(vlast, n_vlast, imap_dev + (g.imap.size() - n_vlast), (int)n_vlast, true);
+        }
         if (async_high) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // the cf sums read the high powers (second stream)
         { auto mj = group_mac(cs); launch_mac(dlevel(high), (int)Lh, upload_jobs(mj), n, (int)mj.size(), st_, mac_kara(high, mac_mean_cnt(mj)), mac_packed(mj)); }
         d_ntt_ct(g.cf, (size_t)Bs * 2, high, true);
+        if (side_tp) HIP_CHECK(hipStreamWaitEvent(st_, ev_intt_, 0));            // the i = 0 finish also reads the sums the main stream transforms back
         if (side_i0) launch_i0_finish(dlevel(low), upload_jobs(ij), n, Bs, st_, raw_i0);
         HIP_CHECK(hipEventRecord(ev_side_, st_));
     };

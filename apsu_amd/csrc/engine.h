@@ -286,7 +286,7 @@ private:
     int cur_lane_ = 0, overflow_lane_ = 0;
     void switch_lane(int lane);
     hipEvent_t ev_main_ = nullptr;    // main-stream progress marker the second stream waits on
-    hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the second
+    hipEvent_t ev_fork_ = nullptr, ev_side_ = nullptr, ev_intt_ = nullptr;   // eval_patstock's side lane: start marker on the main stream, end marker on the side stream, main-stream inverse transforms done
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap: the second stream then waits for the last reader of its powers buffer only
     bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (set_query_overlap 1 / 3)
     bool force_pipe_ = false;         // ... whether or not an evaluation is still running (set_query_overlap 3)
