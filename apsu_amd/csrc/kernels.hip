@@ -1562,6 +1562,12 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
 #pragma unroll
             for (int g = 0; g < G; g++)
                 ptw[g] = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(jp->pt[0]) + ((size_t)(j * nblk + b_x) * G + g) * tile) + (bitoff >> 5);
+        } else if (jp->pad == 2) {                              // macbench: BLOCK-MAJOR rows -- the terms of one (stream, limb, block) contiguous, a tile per term
+            const u32 bitoff = threadIdx.x * 2 * kb, tile = EW_T * C * kb / 8, nblk = (u32)(n / (EW_T * C));
+            psh = bitoff & 31;
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                ptw[g] = reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(jp->pt[g0 + g < (int)job.ng ? g0 + g : g0]) + ((size_t)(j * nblk + b_x) * job.cnt) * tile) + (bitoff >> 5);
         } else
 #endif
         {

@@ -161,20 +161,21 @@ int main(int argc, char** argv) {
         for (int j = 0; j < 3; j++) { hp.mac_bits[j] = kbits; hp.mac_mask_hi[j] = (1u << (kbits - 28)) - 1; hp.mac_row_off[j] = (u32)(j * n * kbits / 8); }
         DevLevel *lvp; CHECK(hipMalloc(&lvp, sizeof(hp))); CHECK(hipMemcpy(lvp, &hp, sizeof(hp), hipMemcpyHostToDevice));
         const size_t slot_b = 3 * n * kbits / 8;
-        std::vector<MacJob> jd = jobs, jdt = jobs, jp = jobs, jpt = jobs;
+        std::vector<MacJob> jd = jobs, jdt = jobs, jp = jobs, jpt = jobs, jpb = jobs;
         for (size_t x = 0; x < jobs.size(); x++) {
             const size_t s0 = x * MAC_G;
             jdt[x].pad = 1; jdt[x].pt_stride = (u32)(ptw * MAC_G); jdt[x].pt[0] = db + s0 * terms * ptw;
             for (int g = 0; g < MAC_G; g++) jp[x].pt[g] = reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(db) + (s0 + g) * terms * slot_b);
             jp[x].packed = 1; jp[x].pt_stride = (u32)slot_b;
+            jpb[x] = jp[x]; jpb[x].pad = 2; jpb[x].pt_stride = (u32)(256 * 2 * kbits / 8);      // block-major: a term = the next 3.5 KiB tile
             jpt[x] = jp[x]; jpt[x].pad = 1; jpt[x].pt_stride = (u32)(slot_b * MAC_G); jpt[x].pt[0] = reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(db) + s0 * terms * slot_b);
         }
         auto upj = [&](const std::vector<MacJob> &v) { MacJob *d; if (hipMalloc(&d, v.size() * sizeof(MacJob)) != hipSuccess) abort(); if (hipMemcpy(d, v.data(), v.size() * sizeof(MacJob), hipMemcpyHostToDevice) != hipSuccess) abort(); return d; };
-        MacJob *d_jd = upj(jd), *d_jdt = upj(jdt), *d_jp = upj(jp), *d_jpt = upj(jpt);
+        MacJob *d_jd = upj(jd), *d_jdt = upj(jdt), *d_jp = upj(jp), *d_jpt = upj(jpt), *d_jpb = upj(jpb);
         const double coefs = (double)streams * terms * ptw;
         for (int pass = 0; pass < 2; pass++)
-            for (int v = 0; v < 4; v++) {
-                const bool packed = v >= 2; MacJob *dv = v == 0 ? d_jd : v == 1 ? d_jdt : v == 2 ? d_jp : d_jpt;
+            for (int v = 0; v < 5; v++) {
+                const bool packed = v >= 2; MacJob *dv = v == 0 ? d_jd : v == 1 ? d_jdt : v == 2 ? d_jp : v == 3 ? d_jpt : d_jpb;
                 std::vector<float> t;
                 for (int rep = 0; rep < 10; rep++) {
                     CHECK(hipEventRecord(e0)); launch_mac(packed ? lvp : lv, 3, dv, n, (int)jobs.size(), 0, false, packed); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
@@ -182,7 +183,7 @@ int main(int argc, char** argv) {
                 }
                 std::sort(t.begin(), t.end());
                 const double by = coefs * (packed ? kbits / 8.0 : 8.0), med = t[t.size() / 2];
-                printf("terms %d  %-22s %s: median %.3f ms  %.0f GB/s  %.3f Tcoef/s\n", terms, packed ? (kbits == 56 ? "packed 56 bits" : "packed") : "dense", (v & 1) ? "tiled" : "rows ", med,
+                printf("terms %d  %-22s %s: median %.3f ms  %.0f GB/s  %.3f Tcoef/s\n", terms, packed ? (kbits == 56 ? "packed 56 bits" : "packed") : "dense", v == 4 ? "block-major" : (v & 1) ? "tiled" : "rows ", med,
                        by / (med * 1e-3) / 1e9, coefs / (med * 1e-3) / 1e12);
             }
     }

@@ -33,6 +33,22 @@ __global__ void k_rows(const char *__restrict__ base, size_t stream_bytes, int t
         }
     if (acc == 0x1234567) out[0] = acc;
 }
+// block-major layout: the `terms` rows of one (stream, block of 512 coefficients) CONTIGUOUS (terms x 3.5 KiB = 154 KiB per stream and
+// workgroup read front to back) instead of 168 KiB apart
+__global__ void k_rows_blockmajor(const char *__restrict__ base, size_t stream_bytes, int terms, u64 *out)
+{
+    u64 acc = 0;
+    const char *p[4];
+    for (int g = 0; g < 4; g++) p[g] = base + ((size_t)blockIdx.y * 4 + g) * stream_bytes + (size_t)blockIdx.x * terms * 3584 + (size_t)threadIdx.x * 14;
+    for (int i = 0; i < terms; i++)
+        for (int g = 0; g < 4; g++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(p[g] + (size_t)i * 3584) & ~(uintptr_t)3);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(q));
+            acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+    if (acc == 0x1234567) out[0] = acc;
+}
 int main(int argc, char **argv)
 {
     const int slabs = argc > 1 ? atoi(argv[1]) : 16;
@@ -45,16 +61,21 @@ int main(int argc, char **argv)
     const int terms = 44; const size_t stream_bytes = (size_t)terms * 172032; const int streams4 = (int)(bytes / stream_bytes / 4);
     for (int pass = 0; pass < 3; pass++)
         for (int i = 0; i < slabs; i++) {
-            float best_a = 1e9f, best_b = 1e9f;
+            float best_a = 1e9f, best_b = 1e9f, best_c = 1e9f;
             for (int rep = 0; rep < 4; rep++) {
                 float ms;
                 CHECK(hipEventRecord(e0)); k_flat<<<256 * 16, 256>>>(reinterpret_cast<const u64x2 *>(s[i]), bytes / 16, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                 CHECK(hipEventElapsedTime(&ms, e0, e1)); best_a = std::min(best_a, ms);
                 CHECK(hipEventRecord(e0)); k_rows<<<dim3(16, streams4), 256>>>(reinterpret_cast<const char *>(s[i]), stream_bytes, terms, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                 CHECK(hipEventElapsedTime(&ms, e0, e1)); best_b = std::min(best_b, ms);
+                // (a stream covers 16 blocks x terms x 3.5 KiB = the same bytes as one limb of `terms` rows: stream_bytes / 3 per limb)
+                CHECK(hipEventRecord(e0)); k_rows_blockmajor<<<dim3(16, streams4 * 3), 256>>>(reinterpret_cast<const char *>(s[i]), stream_bytes / 3, terms, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                CHECK(hipEventElapsedTime(&ms, e0, e1)); best_c = std::min(best_c, ms);
             }
             const double rows_bytes = (double)streams4 * 4 * terms * 16 * 256 * 14;
-            printf("pass %d slab %2d at %p: flat read %.0f GB/s   k_mac-shaped rows %.0f GB/s\n", pass, i, (void *)s[i], bytes / (best_a * 1e-3) / 1e9, rows_bytes / (best_b * 1e-3) / 1e9);
+            const double bm_bytes = (double)streams4 * 3 * 4 * terms * 16 * 256 * 14;
+            printf("pass %d slab %2d at %p: flat read %.0f GB/s   k_mac-shaped rows %.0f GB/s   block-major rows %.0f GB/s\n", pass, i, (void *)s[i], bytes / (best_a * 1e-3) / 1e9,
+                   rows_bytes / (best_b * 1e-3) / 1e9, bm_bytes / (best_c * 1e-3) / 1e9);
         }
     return 0;
 }
