@@ -44,7 +44,13 @@ template <int LOGN, bool INV, int MODE, int PASS> static void emu_pass(u64 *lds,
     if constexpr (PASS < plan_passes(LOGN)) {
         // in-place global reads/writes of a pass touch disjoint 16-coefficient sets per work item, so
         // stepping the threads sequentially is equivalent to the barrier-separated parallel execution
-        for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, MODE, PASS>(lds, glob, tid, T, tab);
+        if constexpr (INV && PASS == 0) {
+            // as in k_ntt since round 5 (SrcStaged): the inverse stages its limb into the LDS image with coalesced loads and runs its first pass from there
+            for (int tid = 0; tid < T; tid++)
+                for (int e = 2 * tid; e < (1 << LOGN); e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(SrcStaged(), glob, e, tab);
+            for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, true, MODE, 0, false, false, SrcPlain, true>(lds, glob, tid, T, tab);
+        } else
+            for (int tid = 0; tid < T; tid++) ntt_pass<LOGN, INV, MODE, PASS>(lds, glob, tid, T, tab);
         emu_pass<LOGN, INV, MODE, PASS + 1>(lds, glob, T, tab);
     }
 }

@@ -36,15 +36,17 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     const int mv = modmap[(split ? g >> 1 : g) % (size_t)period];
     const NttTable tab = tabs[split ? (((mv & NTT_MAP_MASK) << 1) | (int)(g & 1)) : (mv & NTT_MAP_MASK)];
     u64 *p = data + g * N;
+    // (the inverse transform stages its limb into LDS with coalesced loads: SrcStaged, ntt_core.h)
+    using SRC = std::conditional_t<INV, SrcStaged, SrcPlain>;
     if (INV && ((mv & NTT_MAP_RAW) || split)) {                                 // wave-uniform branches
-        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, INV>(lds, p, tab, tid);
-        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, INV>(lds, p, tab, tid);
-        else ntt_body<LOGN, INV, NTT_WIDE, T, 0, INV>(lds, p, tab, tid);
+        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
+        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
+        else ntt_body<LOGN, INV, NTT_WIDE, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
         return;
     }
-    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T>(lds, p, tab, tid);
-    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
-    else ntt_body<LOGN, INV, NTT_WIDE, T>(lds, p, tab, tid);
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
+    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
+    else ntt_body<LOGN, INV, NTT_WIDE, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
 }
 
 constexpr int EW_T = 256;                                         // threads per workgroup of the coefficient-parallel kernels
@@ -170,13 +172,13 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     if (g >= n_tensor) {                                                        // wave-uniform
         u64 *p = plain + (g - n_tensor) * N;
         if (mv & NTT_MAP_RAW) {
-            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true>(lds, p, tab, tid);
-            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true>(lds, p, tab, tid);
-            else ntt_body<LOGN, true, NTT_WIDE, T, 0, true>(lds, p, tab, tid);
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
         } else {
-            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T>(lds, p, tab, tid);
-            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T>(lds, p, tab, tid);
-            else ntt_body<LOGN, true, NTT_WIDE, T>(lds, p, tab, tid);
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
         }
         return;
     }

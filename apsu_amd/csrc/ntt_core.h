@@ -145,11 +145,20 @@ HD u64 ntt_reduce128_lazy(u64 hi, u64 lo, const NttTable &tab)
 
 // Where a pass that reads global memory takes its coefficients from.
 struct SrcPlain {};                                               // the limb itself
+// The limb itself, STAGED (round 5): the inverse transform's first pass would read 16 contiguous coefficients per lane straight from
+// global memory -- 128 bytes per lane, 64 different lines per load instruction, every line touched by eight consecutive instructions of
+// the wave (512 vector-L1 look-ups per wave instead of 64; with 16 waves per CU the 8 KiB a wave keeps live do not fit the L1).  With
+// this source type the workgroup body takes the path of the tensor-on-load transform: coalesced 16-byte loads into the LDS image, the
+// first pass from there.  Same bits; -3.5 ... -6 % on launches of 6 840 limbs and more, level below 700 (tools/microbench/ntt_variants.hip,
+// profiles/r05_ntt_staged_inverse.txt).
+struct SrcStaged {};
 // The dyadic tensor product of two NTT-form ciphertexts, computed on load in front of the inverse transform
 // (BEHZ step 4, d0 = a0*b0, d1 = a0*b1 + a1*b0, d2 = a1*b1): value(e) = x0[e]*y0[e] (+ x1[e]*y1[e]) mod q.
 struct SrcTensor { const u64 *x0, *y0, *x1, *y1; bool lazy; };   // x1 == nullptr: one product; lazy: ntt_lazy_input_ok for this limb
 HD u64x2 src_load2(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return *reinterpret_cast<const u64x2 *>(glob + e); }
 HD u64 src_load1(const SrcPlain &, const u64 *glob, int e, const NttTable &) { return glob[e]; }
+HD u64x2 src_load2(const SrcStaged &, const u64 *glob, int e, const NttTable &) { return *reinterpret_cast<const u64x2 *>(glob + e); }
+HD u64 src_load1(const SrcStaged &, const u64 *glob, int e, const NttTable &) { return glob[e]; }
 HD u64x2 src_load2(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
 {
     const u64x2 x = ldg16(s.x0 + e), y = ldg16(s.y0 + e);

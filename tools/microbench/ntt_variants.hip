@@ -33,6 +33,22 @@ __global__ __launch_bounds__(T, 4) void k_plain(u64 *__restrict__ data, const Nt
     else ntt_body<LOGN, INV, NTT_WIDE, T, 0, RAW, SrcPlain, (WS > 0), false, (WS == 2 ? 12 : WS == 3 ? 40 : 0)>(lds, p, tab, threadIdx.x);
 }
 
+// round 5: the plain INVERSE transform with its limb STAGED into the LDS image by coalesced 16-byte loads (the path the tensor-on-load transform takes)
+// instead of the first pass reading 16 contiguous coefficients per lane straight from global memory (128 bytes per lane: 64 different lines per load
+// instruction, every line touched by eight consecutive instructions -- 512 L1 look-ups per wave instead of 64)
+// (SrcStaged is the library's since the variant was adopted: ntt_core.h)
+template <bool RAW>
+__global__ __launch_bounds__(T, 4) void k_inv_staged(u64 *__restrict__ data, const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[lds_slots(N)];
+    const size_t g = blockIdx.x;
+    const NttTable tab = tabs[modmap[g % (size_t)period]];
+    u64 *p = data + g * N;
+    if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, RAW, SrcStaged>(lds, p, tab, threadIdx.x, nullptr, SrcStaged());
+    else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, RAW, SrcStaged>(lds, p, tab, threadIdx.x, nullptr, SrcStaged());
+    else ntt_body<LOGN, true, NTT_WIDE, T, 0, RAW, SrcStaged>(lds, p, tab, threadIdx.x, nullptr, SrcStaged());
+}
+
 template <int RED, int WS>
 __global__ __launch_bounds__(T, 4) void k_gather(const u64 *const *__restrict__ src, u64 *__restrict__ data, const NttTable *__restrict__ tabs,
                                                  const int *__restrict__ modmap, int period)
@@ -175,6 +191,17 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((k_plain<true, 2, true>), dim3(big), dim3(T), 0, 0, d_b, d_tabs, map, period);
         same("  ... with stagger");
     }
+    for (int which = 0; which < 2; which++) {                     // staged inverse == the library's inverse
+        const int *map = which ? d_map_ext : d_map_q; const int period = which ? 7 : 3;
+        copy_in(d_a); copy_in(d_b);
+        hipLaunchKernelGGL((k_plain<true, 1, true>), dim3(big), dim3(T), 0, 0, d_a, d_tabs, map, period);
+        hipLaunchKernelGGL((k_inv_staged<true>), dim3(big), dim3(T), 0, 0, d_b, d_tabs, map, period);
+        same(which ? "inverse RAW staged, extended base" : "inverse RAW staged, data primes");
+        copy_in(d_a); copy_in(d_b);
+        hipLaunchKernelGGL((k_plain<true, 1, false>), dim3(big), dim3(T), 0, 0, d_a, d_tabs, map, period);
+        hipLaunchKernelGGL((k_inv_staged<false>), dim3(big), dim3(T), 0, 0, d_b, d_tabs, map, period);
+        same(which ? "inverse staged, extended base" : "inverse staged, data primes");
+    }
     hipLaunchKernelGGL((k_gather<1, 0>), dim3(big), dim3(T), 0, 0, d_src, d_a, d_tabs, d_map_ks, 12);
     hipLaunchKernelGGL((k_gather<1, 2>), dim3(big), dim3(T), 0, 0, d_src, d_b, d_tabs, d_map_ks, 12);
     same("gathered forward, reduce on load (stagger)");
@@ -219,6 +246,19 @@ int main(int argc, char **argv)
         PLAIN3("inverse, data primes", true, false, d_map_q, 3);
         PLAIN3("inverse RAW, data primes", true, true, d_map_q, 3);
         PLAIN3("inverse, extended base", true, false, d_map_ext, 7);
+        if (getenv("STAGED")) {
+            auto st = [&](const char *name, bool raw, const int *map, int per) {
+                const double a = raw ? tm.us([&] { hipLaunchKernelGGL((k_plain<true, 1, true>), g, dim3(T), 0, 0, d_a, d_tabs, map, per); }, reps)
+                                     : tm.us([&] { hipLaunchKernelGGL((k_plain<true, 1, false>), g, dim3(T), 0, 0, d_a, d_tabs, map, per); }, reps);
+                const double b = raw ? tm.us([&] { hipLaunchKernelGGL((k_inv_staged<true>), g, dim3(T), 0, 0, d_a, d_tabs, map, per); }, reps)
+                                     : tm.us([&] { hipLaunchKernelGGL((k_inv_staged<false>), g, dim3(T), 0, 0, d_a, d_tabs, map, per); }, reps);
+                const double by = (double)count * 16 * N;
+                printf("STAGED %-34s %6zu limbs  library %7.1f us %5.0f GB/s | staged %7.1f us %5.0f GB/s %+5.1f %%\n", name, count, a, by / a / 1e3, b, by / b / 1e3, (b / a - 1) * 100);
+            };
+            st("inverse RAW, data primes", true, d_map_q, 3);
+            st("inverse, data primes", false, d_map_q, 3);
+            st("inverse RAW, extended base", true, d_map_ext, 7);
+        }
         line("gather, reduce on load", count, tm.us([&] { hipLaunchKernelGGL((k_gather<1, 0>), g, dim3(T), 0, 0, d_src, d_a, d_tabs, d_map_ks, 12); }, reps),
              tm.us([&] { hipLaunchKernelGGL((k_gather<1, 1>), g, dim3(T), 0, 0, d_src, d_a, d_tabs, d_map_ks, 12); }, reps),
              tm.us([&] { hipLaunchKernelGGL((k_gather<1, 2>), g, dim3(T), 0, 0, d_src, d_a, d_tabs, d_map_ks, 12); }, reps),
