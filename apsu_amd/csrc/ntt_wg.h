@@ -70,9 +70,11 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
     unsigned sink = 0;
     if constexpr (NEXTPASS == 0) { if (next) ntt_touch_line(next, sink); }
     if constexpr (STAGGER > 0 && INV) { if (tid & 256) __builtin_amdgcn_s_sleep(STAGGER); }
-    // (the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
-    //  line is consumed by the wave's eight consecutive loads.  Staging the limb through LDS with coalesced loads first was
-    //  measured again in round 2 for small launches: no gain, profiles/r02_ntt_latency.txt)
+    // (with SRC = SrcPlain the first inverse pass reads its 16 contiguous coefficients per lane from global memory: 128 B per lane, every
+    //  line is consumed by the wave's eight consecutive loads.  Round 2 measured staging the limb through LDS with coalesced loads for
+    //  SMALL launches only -- no gain, profiles/r02_ntt_latency.txt -- and left it; on launches of thousands of limbs the direct reads
+    //  thrash the vector L1, and since round 5 the library's inverse transforms pass SrcStaged and take the staged path below:
+    //  -3.5 ... -6 %, profiles/r05_ntt_staged_inverse.txt)
     if constexpr (PF && P > 1) {
         constexpr bool COMPUTED = !std::is_same<SRC, SrcPlain>::value;
         // (the pass that leaves a non-RAW inverse transform also loads its 16 twist constants: with a prefetched set on top the
