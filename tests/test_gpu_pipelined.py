@@ -189,7 +189,8 @@ def test_queued_queries_are_isolated(world, monkeypatch, mode, side, two_stream,
     if mode == 3:
         assert piped == K, "forced mode: every ComputePowers takes the pipelined walk"
     elif mode == 1 and two_stream != 0:
-        assert piped >= 1, "an evaluation of a gigabyte of BinBundles outlasts the host's queueing of the next query"
+        # (measured: 8 of 12 on a context's first, cold pass -- allocations, job-table uploads --, 11 of 12 from then on, at both sizes)
+        assert piped >= K // 2, "an evaluation of a gigabyte of BinBundles outlasts the host's queueing of the next query"
     else:
         assert piped == 0
     for k in range(K):
