@@ -115,12 +115,16 @@ struct MacJob {
 // tabs[modmap[g % period] & NTT_MAP_MASK].  An inverse transform of a limb whose map entry carries NTT_MAP_RAW writes its
 // result WITHOUT the final twist n^-1 psi^-k and without the final reduction (consumers: the unrolled BEHZ finish kernels).
 constexpr int NTT_MAP_RAW = 1 << 30, NTT_MAP_MASK = NTT_MAP_RAW - 1;
+// latency_limbs (round 6): a launch of at most that many limbs takes the LATENCY form of the transform (8 coefficients per lane, twice the
+// waves per limb; ntt_core.h plan_k) where the ring size has one (n = 8192, 4096); 0 = always the throughput form; NTT_FORM_AUTO = the
+// measured crossover per ring size and kind of launch (kernels.hip, ntt_use_latency_form).  Same bits.
+constexpr size_t NTT_FORM_AUTO = ~(size_t)0;
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
-                int period, hipStream_t st);
+                int period, hipStream_t st, size_t latency_limbs = 0);
 // forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n.
 // nored: the caller has checked ntt_gather_nored_ok for every (source, target) pair of the launch: no reduction on load
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                       hipStream_t st, bool nored = false);
+                       hipStream_t st, bool nored = false, size_t latency_limbs = 0);
 // out = a (.) b per limb; a:[batch][polys][L][n], b:[batch][L][n] (b_batch_stride may be 0)
 void launch_dyadic_plain(const DevLevel *lv, const u64 *ct, const u64 *pt, u64 *out, int polys, size_t n, int batch,
                          size_t pt_batch_stride, hipStream_t st);
@@ -141,7 +145,7 @@ void launch_clear_bits(u64 *ct, size_t words, int bits, hipStream_t st);
 struct CtJob { const u64 *src; u64 *dst; };
 void launch_copy_jobs(const CtJob *jobs, size_t words, int njobs, hipStream_t st);
 // copy of query source ciphertexts ([2][L][n] words each) that flags words outside [0, q_limb) in *bad (device-visible host memory)
-void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, hipStream_t st);
+void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, unsigned seq, hipStream_t st);
 // drop last limb of `polys` polynomials per job: src [polys][L][n] -> dst [polys][L-1][n]
 void launch_modswitch_jobs(const DevLevel *lv, const CtJob *jobs, int polys, size_t n, int njobs, hipStream_t st);
 void launch_fill_random(u64 *out, size_t words, u64 seed, u64 bound, hipStream_t st);
@@ -186,7 +190,7 @@ void launch_tensor_sum(const DevLevel *lv, int E, const TensorSumJob *jobs, size
 // output job.d[3][limbs][n], coefficient form), followed by n_plain limbs at `plain` transformed in place; modmap covers both
 // (grid order: the three workgroups of one (product, limb) pair -- they read the same operand limbs -- on one XCD)
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st);
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, size_t latency_limbs = 0);
 struct FinishSumJob { const u64 *dq, *bs; u64 *out; int terms; int pad; };   // out: [3][L][n] = sum of the finished terms
 void launch_behz_finish_sum(const DevLevel *lv, int L, int nB, const FinishSumJob *jobs, size_t n, int njobs, hipStream_t st);
 // finish: out[3][L][n] (+)= sum over `terms` consecutive products d[term][3][E][n] (coeff form)

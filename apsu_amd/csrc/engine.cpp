@@ -6,6 +6,7 @@
 // (drop-limb, BEHZ floor, key-switch mod-down) is applied per term exactly where the reference
 // applies it (SURVEY.md §2.4 note N1), so results are bit-identical to the CPU path.
 #include "engine.h"
+#include "sched_policy.h"
 #include "seal_codec.h"
 
 #include <algorithm>
@@ -161,6 +162,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         //   APSU_HE_EVAL_PER_TERM=1    eval_patstock's products finished one by one (the fallback of the summed finish)
         //   APSU_HE_MAC_KARA=0/1       three-product k_mac forced off / on (default: by chain length)
         //   APSU_HE_SEED_EXPAND_HOST=1 seeded objects expanded by the host codec (the fallback of the device sampler)
+        //   APSU_HE_NTT_LATENCY_LIMBS=n transform launches of at most n limbs take the latency form (8 coefficients per lane; round 6);
+        //                              0 = always the throughput form.  Default: the measured crossover per ring size and kind of launch.
         if (const char *v = std::getenv("APSU_HE_SPLIT")) two_stream_default_ = std::atoi(v) != 0 ? 1 : 0;
         if (split_ntt) fuse_tensor_ = false;                     // the fused load belongs to a whole-limb workgroup
         if (const char *v = std::getenv("APSU_HE_MAC_KARA")) mac_kara_ = std::atoi(v) != 0 ? 1 : 0;
@@ -173,6 +176,11 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         if (const char *v = std::getenv("APSU_HE_EVAL_WS_BYTES")) eval_ws_budget_ = std::strtoull(v, nullptr, 10);
         if (const char *v = std::getenv("APSU_HE_EVAL_PER_TERM")) force_per_term_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_SEED_EXPAND_HOST")) seed_expand_host_ = std::atoi(v) != 0;
+        // The latency form of the LDS-resident transform (ntt_core.h plan_k, c = 8): a limb's workgroup has twice the waves, so a launch
+        // that gives a CU at most one limb hides that limb's LDS turnarounds and table loads behind three other waves per SIMD.
+        // Crossovers: kernels.hip, ntt_use_latency_form (tools/microbench/ntt_forms.hip, profiles/r06_ntt_forms_n8192.txt / _n4096.txt).
+        ntt_latency_limbs_ = NTT_FORM_AUTO;
+        if (const char *v = std::getenv("APSU_HE_NTT_LATENCY_LIMBS")) ntt_latency_limbs_ = std::strtoull(v, nullptr, 10);
     }
     // level constants
     {
@@ -399,8 +407,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
     lanes_[2].arena.alloc((size_t)1 << 20);
     stage_bytes_ = 4u << 20;
     HIP_CHECK(hipHostMalloc(&stage_, stage_bytes_));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&bad_source_), 64));
-    *bad_source_ = 0;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&bad_source_), BAD_SLOTS * sizeof(unsigned)));
+    for (int i = 0; i < BAD_SLOTS; i++) bad_source_[i] = 0;
 }
 
 Engine::~Engine()
@@ -453,13 +461,44 @@ void Engine::sync()
 // Called where a PUBLIC entry point has just waited for the device (apsu_he_sync, a synchronous apsu_he_eval_bundles, apsu_he_powers_download):
 // k_copy_sources of a query whose work has completed by now may have found a source coefficient outside [0, q).  (Not inside sync():
 // the engine also waits in the middle of its own bookkeeping -- arena growth, job-table reallocation -- where nothing may be thrown.)
+bool Engine::bad_source_pending(int slot, bool take)
+{
+    if (!bad_source_) return false;
+    const unsigned v = *const_cast<volatile unsigned *>(bad_source_ + slot);
+    if (v == bad_reported_[slot]) return false;
+    if (take) bad_reported_[slot] = v;
+    return true;
+}
+
+static const char *const BAD_SOURCE_TEXT = "a source ciphertext of apsu_he_compute_powers holds a coefficient outside [0, q): the results computed from it "
+                                           "are not valid (seal::is_data_valid_for)";
+
 void Engine::check_sources()
 {
-    if (bad_source_ && *bad_source_) {
-        *bad_source_ = 0;
-        throw std::invalid_argument("a source ciphertext of apsu_he_compute_powers holds a coefficient outside [0, q): the results computed from it "
-                                    "are not valid (seal::is_data_valid_for)");
+    bool any = false;
+    for (int i = 0; i < BAD_SLOTS; i++) any |= bad_source_pending(i, true);
+    if (any) throw std::invalid_argument(BAD_SOURCE_TEXT);
+}
+
+// the report of ONE query: only the word its ComputePowers writes, and only that call's sequence number in it (an older or a newer
+// query's report stays where it is for the call that waits for that query, or for apsu_he_sync)
+void Engine::check_sources(const Powers &pw)
+{
+    const int slot = (int)(pw.seq % BAD_SLOTS);
+    if (!bad_source_ || !pw.seq) return;
+    const unsigned v = *const_cast<volatile unsigned *>(bad_source_ + slot);
+    if (v == pw.seq && bad_reported_[slot] != v) {
+        bad_reported_[slot] = v;
+        throw std::invalid_argument(BAD_SOURCE_TEXT);
     }
+}
+
+bool Engine::take_bad_source()
+{
+    Enter g(this);
+    bool any = false;
+    for (int i = 0; i < BAD_SLOTS; i++) any |= bad_source_pending(i, true);
+    return any;
 }
 
 void Engine::wait()
@@ -467,6 +506,12 @@ void Engine::wait()
     Enter g(this);
     sync();
     check_sources();
+}
+
+void Engine::drain()
+{
+    Enter g(this);
+    sync();
 }
 
 void Engine::switch_lane(int lane)
@@ -835,7 +880,7 @@ bool Engine::mac_kara(int lvl, uint32_t mean_cnt) const
 void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
 {
     PROF(inverse ? P_NTT_INV : P_NTT_FWD, count);
-    launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_);
+    launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_, ntt_latency_limbs_);
 }
 
 bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out, int n_ext)
@@ -855,7 +900,7 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
         bool nored = hp_.logn <= 14;
         for (int I = 0; I <= L && nored; I++) nored = ntt_gather_nored_ok(hp_.key_q[I < L ? I : hp_.K - 1], max_src, hp_.logn);
         PROF(P_NTT_FWD, src.size());
-        launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_, nored);
+        launch_ntt_gather(hp_.logn, upload_jobs(src), tdec, src.size(), tabs(), map_ks(chain_idx), (L + 1) * L, st_, nored, ntt_latency_limbs_);
     }
     u64 *acc = ws((size_t)batch * 2 * (L + 1) * n);
     // the inverse transform leaves its twist to the mod-down kernel, whose own constants absorb it (unrolled sizes)
@@ -1338,11 +1383,14 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 for (int b = 0; b < nb; b++) {
                     const u64 *sp = src[(size_t)b * dag_.source_count() + si];
                     if (on_device) cj.push_back(CtJob{ sp, slot_ptr(s.slot_of[kv.first], b) });
-                    else H2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
+                    else {                                       // host sources: a plain copy, then the same check in place (round 6)
+                        H2D(slot_ptr(s.slot_of[kv.first], b), sp, 2 * Lf * n);
+                        cj.push_back(CtJob{ slot_ptr(s.slot_of[kv.first], b), slot_ptr(s.slot_of[kv.first], b) });
+                    }
                 }
                 si++;
             }
-            if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_sources(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), dlevel(first), (int)Lf, n, bad_source_, st_); }
+            if (!cj.empty()) { PROF(P_OTHER, 0); launch_copy_sources(upload_jobs(cj), 2 * Lf * n, (int)cj.size(), dlevel(first), (int)Lf, n, bad_source_ + query_seq_ % BAD_SLOTS, query_seq_, st_); }
             if (s.levels.size() > 1) {
                 run.ext = ws(P * nb * 2 * Ef * n);
                 size_t max_nodes = 0;
@@ -1381,7 +1429,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
                 }
                 if (fuse_tensor_) {                                                                                              // :422/:424
                     PROF(P_NTT_FUSED, tj.size() * 3 * Ef);
-                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_);
+                    launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Ef, Ef * n, nullptr, 0, tabs(), map_ext_fin(first), (int)Ef, st_, ntt_latency_limbs_);
                 } else {
                     { PROF(P_TENSOR, 0); launch_tensor(dlevel(first), upload_jobs(tj), n, (int)tj.size(), st_); }
                     d_ntt(dbuf, (size_t)nn * nb * 3 * Ef, map_ext_fin(first), (int)Ef, true);
@@ -1438,7 +1486,7 @@ void Engine::run_dag(const Sched &s, DagRun &run, int stage, int nb, const u64 *
             bool nored = hp_.logn <= 14;
             for (size_t j = 0; j < Lf && nored; j++) nored = ntt_gather_nored_ok(hp_.key_q[j], hp_.key_q[j], hp_.logn);
             PROF(P_NTT_FWD, srcp.size());
-            launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_, nored);
+            launch_ntt_gather(hp_.logn, upload_jobs(srcp), pw->low.u(), srcp.size(), tabs(), map_ct(), (int)Lf, st_, nored, ntt_latency_limbs_);
         } else if (do_low) {
             convert(s.low_powers, low_target, pw->low.u());
             d_ntt_ct(pw->low.u(), (size_t)pw->n_low * nb * 2, low_target, false);                      // :467,475
@@ -1478,26 +1526,46 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // takes the one whose reader is done (a caller that frees its powers right after queueing the evaluation, as the reference's
     // RunQuery does, then gets the alternation for free: 68 MB more at 16M-4096)
     {
-        size_t fits = 0, pick = SIZE_MAX, first = SIZE_MAX;
+        // (the rule itself: sched_policy.h, pick_pooled_buffer -- enumerated on the CPU tier)
+        std::vector<PoolEntryState> st(powers_pool_.size());
         for (size_t i = 0; i < powers_pool_.size(); i++) {
             Powers &c = *powers_pool_[i];
-            if (c.low.bytes() != need_low || c.high.bytes() != need_high || c.hext.bytes() != need_hext) continue;
-            fits++;
-            if (first == SIZE_MAX) first = i;
-            if (pick == SIZE_MAX && (!inputs_ready_ || !c.last_use_set || hipEventQuery(c.last_use) == hipSuccess)) pick = i;
+            st[i].fits = c.low.bytes() == need_low && c.high.bytes() == need_high && c.hext.bytes() == need_hext;
+            st[i].last_use_set = c.last_use_set;
+            st[i].last_use_done = st[i].fits && inputs_ready_ && c.last_use_set && hipEventQuery(c.last_use) == hipSuccess;
         }
-        if (pick == SIZE_MAX && (fits >= 3 || !inputs_ready_)) pick = first;   // three pooled ones, all busy: the oldest (else: a new buffer).
-        // (three: the host runs up to two queries ahead -- one buffer is being read, one is written or waits for its evaluation, the third takes the next query)
-        if (pick != SIZE_MAX) {
+        const int pick = pick_pooled_buffer(st.data(), st.size(), inputs_ready_);
+        if (pick >= 0) {
             pw = std::move(powers_pool_[pick]);
             powers_pool_.erase(powers_pool_.begin() + pick);
         }
     }
     const bool recycled = (bool)pw;
+    // The ordering rules -- which walk, behind which events -- are a pure function of this state (sched_policy.h, plan_walk; every
+    // state is enumerated against the no-unordered-writer invariant in tests/test_host_logic.py).
+    WalkState wst{};
+    wst.recycled = recycled;
+    wst.last_use_set = recycled && pw->last_use_set;
+    wst.last_use_done = wst.last_use_set && hipEventQuery(pw->last_use) == hipSuccess;
+    wst.high_async = recycled && pw->high_async && pw->high_ready;
+    wst.split_ok = split_ok_;
+    wst.prof_on = prof_on_;
+    wst.split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : two_stream_default_;       // API override, then environment
+    wst.pipe_cp = pipe_cp_;
+    wst.force_pipe = force_pipe_;
+    wst.inputs_ready = inputs_ready_;
+    wst.on_device = on_device;
+    // "busy": an evaluation queued earlier is still running (a query that finds the device idle takes the split walk: the merged
+    // chain is ~3 % slower for one query alone, profiles/r02_pipe_sweep.txt; a stream of queued queries takes the pipelined one)
+    if (pipe_cp_ && inflight_count_ > 0 && !inflight_.empty())
+        wst.device_busy = hipEventQuery(inflight_[(inflight_head_ + inflight_count_ - 1) % inflight_.size()]) == hipErrorNotReady;
+    const WalkPlan plan = plan_walk(wst);
     // a pooled buffer whose high half was produced on the second stream and never consumed: the main stream must not
     // overwrite it before those kernels have finished
-    if (recycled && pw->high_async && pw->high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw->high_ready, 0));
+    if (plan.main_waits_high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw->high_ready, 0));
     if (!pw) pw = std::make_unique<Powers>();
+    if (++query_seq_ == 0) query_seq_ = 1;                   // (0 = "never computed")
+    pw->seq = query_seq_;
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
     pw->low_level = low_target;
@@ -1526,35 +1594,21 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
     // 3.65 ms for the whole query (four bundle indices), 0.95 -> 0.86 ms per rank with one bundle index.  Default: on
     // whenever the PowersDag splits; APSU_HE_SPLIT=0/1 (read at apsu_he_create) or apsu_he_set_two_stream force it.  Event profiling always takes
     // the one-stream walk: a launch bracketed by events next to another stream's kernels measures the sharing, not the kernel.
-    const int split_mode = two_stream_mode_ >= 0 ? two_stream_mode_ : two_stream_default_;       // API override, then environment
-    const bool split = split_ok_ && !prof_on_ && (split_mode < 0 || split_mode == 1);   // (host inputs are uploaded per lane and end with a sync)
+    const bool split = plan.walk != WALK_ONE_STREAM;         // (host inputs are uploaded per lane and end with a sync)
     pw->high_async = split;
     if (split && !pw->high_ready) HIP_CHECK(hipEventCreateWithFlags(&pw->high_ready, hipEventDisableTiming));
-    // Pipelined queries (round 4; APSU_HE_PIPE_CP=0 turns it off): the WHOLE walk on the second stream -- one merged chain of
-    // launches -- next to the evaluation of the query in front, the main stream only evaluates: -2.5 % on the rate of queued
-    // 16M-4096 queries, -7.7 % on the N = 8 shard (profiles/r04_ab_pipe_cp.txt).  Needs the caller's apsu_he_set_query_overlap promise.
-    // Only while an evaluation queued earlier is still running: a query that finds the device idle takes the split walk (the merged
-    // chain is ~3 % slower for one query alone, profiles/r02_pipe_sweep.txt), a stream of queued queries takes this one.
-    bool busy = false;
-    if (pipe_cp_ && inflight_count_ > 0 && !inflight_.empty())
-        busy = hipEventQuery(inflight_[(inflight_head_ + inflight_count_ - 1) % inflight_.size()]) == hipErrorNotReady;
-    // ... and only into a buffer nobody reads any more (fresh, or its last evaluation is over): waiting for that evaluation would
-    // serialise the two streams, with the slower walk
-    // A pooled buffer is ordered behind its LAST READER only when an evaluation has read it since it was last written: `last_use`
-    // is consumed here (had_last_use) and set again by eval_bundles alone.  A buffer that was computed and given back without an
-    // evaluation (an error path, a caller that drops a query) keeps no mark: its writers may still be queued on EITHER stream, so
-    // it takes the conservative order -- no pipelined walk, the second stream behind everything on the main stream (ev_main_), the
-    // main stream behind the second stream's last writer (high_ready, above).
-    const bool had_last_use = recycled && pw->last_use_set;
-    const bool buffer_known = !recycled || had_last_use;
-    const bool buffer_idle = !recycled || (had_last_use && hipEventQuery(pw->last_use) == hipSuccess);
-    const bool pipe = pipe_cp_ && (busy || force_pipe_) && (buffer_idle || (force_pipe_ && buffer_known)) && split && inputs_ready_ && on_device;
+    // Pipelined queries (round 4): the WHOLE walk on the second stream -- one merged chain of launches -- next to the evaluation of
+    // the query in front, the main stream only evaluates: -2.5 % on the rate of queued 16M-4096 queries, -7.7 % on the N = 8 shard
+    // (profiles/r04_ab_pipe_cp.txt).  Needs the caller's apsu_he_set_query_overlap promise; only while an evaluation queued earlier is
+    // still running and only into a buffer nobody reads any more (plan_walk).  `last_use` is consumed here and set again by
+    // eval_bundles alone: a buffer that was computed and given back without an evaluation keeps no mark and takes the conservative order.
+    const bool pipe = plan.walk == WALK_PIPELINED;
     pw->low_async = pipe;
     WITH_ARENA({
         for (hipEvent_t *e : { &cp_span.b, &cp_span.b2 }) if (*e) { phase_pool_.push_back(*e); *e = nullptr; }   // a retry after arena growth
         if (pipe) {
             switch_lane(1);
-            if (had_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
+            if (plan.side_waits_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             DagRun r;
             run_dag(sched_, r, 0, nb, src, on_device, rk, *pw, true, true);
             for (int d = 1; d < (int)sched_.levels.size(); d++) run_dag(sched_, r, d, nb, src, on_device, rk, *pw, true, true);
@@ -1577,12 +1631,12 @@ std::unique_ptr<Powers> Engine::compute_powers(const uint32_t *bundle_indices, i
             //  second stream waits for the LAST READER of this powers buffer -- the
             //  evaluation that used it before it went back to the pool -- not for everything the main stream has queued: the next
             //  query's high-power chain then runs next to the tail of the query in front of it, whose launches leave CUs idle)
-            const bool early = inputs_ready_ && on_device && buffer_known;   // (a pooled buffer whose reader left no mark: wait for all)
-            if (!early) HIP_CHECK(hipEventRecord(ev_main_, st_));
+            //  (plan.side_waits_main / side_waits_last_use; a pooled buffer whose reader left no mark waits for all)
+            if (plan.side_waits_main) HIP_CHECK(hipEventRecord(ev_main_, st_));
             run_dag(sched_low_, rl, 0, nb, src, on_device, rk, *pw, true, false);
             switch_lane(1);
-            if (!early) HIP_CHECK(hipStreamWaitEvent(st_, ev_main_, 0));
-            else if (had_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
+            if (plan.side_waits_main) HIP_CHECK(hipStreamWaitEvent(st_, ev_main_, 0));
+            else if (plan.side_waits_last_use) HIP_CHECK(hipStreamWaitEvent(st_, pw->last_use, 0));
             run_dag(sched_high_, rh, 0, nb, src, on_device, rk, *pw, false, true);
             for (int d = 1; d < depth; d++) {
                 switch_lane(0);
@@ -1633,7 +1687,7 @@ void Engine::download_power(const Powers &pw, uint32_t bundle_idx, uint32_t powe
     const size_t words = (size_t)power_size(power) * (lvl + 1) * hp_.n;               // the stored slot may be zero-padded beyond that
     if (capacity_words < words) throw std::invalid_argument("output buffer too small");
     sync();
-    check_sources();
+    check_sources(pw);
     const u64 *src = (low ? pw.low.u() : pw.high.u()) + ((size_t)b * (low ? pw.n_low : pw.n_high) + idx) * pw.polys * (lvl + 1) * hp_.n;
     HIP_CHECK(hipMemcpy(out, src, words * sizeof(u64), hipMemcpyDeviceToHost));
     if (chain_idx) *chain_idx = lvl;
@@ -2427,7 +2481,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
             { PROFW(P_TENSOR, ((size_t)NI * 4 + (size_t)Bs * 3) * (Eh - Lh) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), (int)Lh, st_); }
             PROF(P_NTT_FUSED, dmap.size());
             launch_intt_tensor(hp_.logn, upload_jobs(pj), (int)pj.size(), (int)Lh, Eh * n, bsum, dmap.size() - pj.size() * 3 * Lh,
-                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_);
+                               tabs(), upload_jobs(dmap), (int)dmap.size(), st_, ntt_latency_limbs_);
         } else {
             { PROFW(P_TENSOR, ((size_t)NI * 4 * Eh + (size_t)NI * 3 * Lh + (size_t)Bs * 3 * (Eh - Lh)) * n); launch_tensor_sum(dlevel(high), (int)Eh, upload_jobs(tj), n, (int)tj.size(), 0, st_); }
             d_ntt(dq, dmap.size(), upload_jobs(dmap), (int)dmap.size(), true);
@@ -2459,7 +2513,7 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         }
         if (fuse_tensor_ && tj.size() == (size_t)NI) {
             PROF(P_NTT_FUSED, tj.size() * 3 * Eh);
-            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_);
+            launch_intt_tensor(hp_.logn, upload_jobs(tj), (int)tj.size(), (int)Eh, Eh * n, nullptr, 0, tabs(), map_ext_fin(high), (int)Eh, st_, ntt_latency_limbs_);
         } else {
             if (!tj.empty()) { PROF(P_TENSOR, 0); launch_tensor(dlevel(high), upload_jobs(tj), n, (int)tj.size(), st_); }
             d_ntt(dbuf, (size_t)NI * 3 * Eh, map_ext_fin(high), (int)Eh, true);
@@ -2611,7 +2665,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
             else mark_inflight();
         });
     }
-    if (synced) check_sources();
+    if (synced) check_sources(pw);
 }
 
 // ============================================================================ no key switching: ciphertexts of any size
@@ -2713,6 +2767,8 @@ std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indice
     const size_t E = hlevel(0).L + hlevel(0).nB + 1;
     job_seq_base_ = 0;
     auto pw = std::make_unique<Powers>();
+    if (++query_seq_ == 0) query_seq_ = 1;
+    pw->seq = query_seq_;
     pw->nb = nb;
     pw->bundle_indices.assign(bundle_indices, bundle_indices + nb);
     pw->low_level = pw->high_level = 0;
@@ -2740,15 +2796,19 @@ std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indice
         auto coef_ptr = [&](int slot, int b) { return coef + ((size_t)slot * nb + b) * S * n; };
         auto ext_ptr = [&](int slot, int b) { return ext + ((size_t)slot * nb + b) * S * E * n; };
         int si = 0;
+        std::vector<CtJob> chk;
         for (auto &kv : dag_.nodes()) {                                                            // receiver_osn.cpp:304-317
             if (!kv.second.is_source()) continue;
             for (int b = 0; b < nb; b++) {
                 const u64 *sp = src[(size_t)b * dag_.source_count() + si];
                 if (on_device) D2D(coef_ptr(s.slot_of[kv.first], b), sp, 2 * n);
                 else H2D(coef_ptr(s.slot_of[kv.first], b), sp, 2 * n);
+                chk.push_back(CtJob{ coef_ptr(s.slot_of[kv.first], b), coef_ptr(s.slot_of[kv.first], b) });
             }
             si++;
         }
+        // the sources against their (single) prime, in place: the same report as on the key-switching path (round 6)
+        launch_copy_sources(upload_jobs(chk), 2 * n, (int)chk.size(), dlevel(0), 1, n, bad_source_ + query_seq_ % BAD_SLOTS, query_seq_, st_);
         // BEHZ extension + NTT of every polynomial of the slots [s0, s1) (zero padding extends to zero)
         auto extend = [&](int s0, int s1) {
             if (s1 <= s0) return;
@@ -2783,6 +2843,7 @@ std::unique_ptr<Powers> Engine::compute_powers_nks(const uint32_t *bundle_indice
     });
     if (phase_on_ && cp_span.a && cp_span.b) phase_spans_.push_back(cp_span);
     pw->last_use_set = false;                               // (the path synchronises; kept for the pool's bookkeeping)
+    check_sources(*pw);                                      // this path has just waited: the report comes from the call that took the sources
     return pw;
 }
 

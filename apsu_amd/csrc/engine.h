@@ -89,6 +89,9 @@ struct Powers {
     // else the main stream has queued since (Engine::compute_powers, inputs_ready_)
     mutable hipEvent_t last_use = nullptr;
     mutable bool last_use_set = false;
+    // sequence number of the ComputePowers call that filled this buffer: the word a source coefficient outside [0, q) is reported in
+    // (Engine::check_sources) carries it, so the report attaches to THIS query's evaluation / download
+    uint32_t seq = 0;
     ~Powers() { if (high_ready) (void)hipEventDestroy(high_ready); if (last_use) (void)hipEventDestroy(last_use); }
     Powers() = default;
     Powers(const Powers &) = delete;
@@ -216,6 +219,10 @@ public:
     // engine's stream (no host round trip per Evaluator call); see apsu_he_set_tier1_on_device
     void set_tier1_on_device(bool on) { std::lock_guard<std::mutex> g(mu_); tier1_device_ = on; }
     void wait();                                                  // locked sync() + check_sources()
+    void drain();                                                 // locked sync() alone: never throws for a query's data (buffer growth in callers)
+    // Has any ComputePowers whose work is complete found a source coefficient outside [0, q) that no call has reported yet?  Clears it.
+    // Never throws: for callers that must finish their own protocol first (MultiEngine::eval_all, in front of a collective).
+    bool take_bad_source();
     // test hook: copy one computed power to the host (serialised with the other calls on this context)
     void download_power(const Powers &pw, uint32_t bundle_idx, uint32_t power, u64 *out, size_t capacity_words, int *chain_idx,
                         int *is_ntt);
@@ -290,6 +297,7 @@ private:
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap: the second stream then waits for the last reader of its powers buffer only
     bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (set_query_overlap 1 / 3)
     bool force_pipe_ = false;         // ... whether or not an evaluation is still running (set_query_overlap 3)
+    size_t ntt_latency_limbs_ = 0;    // transform launches of at most this many limbs take the 8-coefficient-per-lane form (APSU_HE_NTT_LATENCY_LIMBS)
     bool eval_side_ = true;           // cf sums + i = 0 finish of eval_patstock on a side stream (APSU_HE_EVAL_SIDE=0: on the main stream)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued
     // Asynchronous evaluations in flight: the host may run at most max_inflight_ queries ahead of the device.  Unbounded
@@ -302,8 +310,15 @@ private:
     void mark_inflight();
     // device-resident source ciphertexts are checked while they are gathered (k_copy_sources: every word below its limb's prime, SEAL's
     // is_data_valid_for); the kernel raises this word of page-locked host memory, sync() looks at it and throws std::invalid_argument
+    // page-locked words written by k_copy_sources: slot (seq % BAD_SLOTS) holds the sequence number of the last ComputePowers that found
+    // a source coefficient outside [0, q) there; bad_reported_ = what has been thrown already
+    static constexpr int BAD_SLOTS = 16;
     unsigned *bad_source_ = nullptr;
-    void check_sources();
+    unsigned bad_reported_[BAD_SLOTS] = {};
+    uint32_t query_seq_ = 0;
+    void check_sources();                                         // any query
+    void check_sources(const Powers &pw);                         // this query
+    bool bad_source_pending(int slot, bool take);
     void *stage_ = nullptr;           // pinned host staging for job arrays
     size_t stage_bytes_ = 0, stage_off_ = 0;
     // job-array cache: the n-th upload of a top-level call usually carries the same bytes as in the

@@ -25,7 +25,9 @@ void throw_hip(hipError_t e, const char *file, int line);
 // does not fit a workgroup's LDS).  Block g is half g & 1 of limb g >> 1 and takes table 2 * modulus + half, whose forward
 // twiddles are the big transform's for that half (W_h[2^s + b] = W[2^(s+1) + h 2^s + b]); the first Cooley-Tukey stage runs in
 // front (k_ntt_first_stage), the inverse's last stage and twist behind (k_ntt_last_stage), so the inverse halves are always RAW.
-template <int LOGN, bool INV, int T>
+// C: coefficients per lane -- 16 (T = n / 16 threads per limb: the throughput form) or 8 (T = n / 8: the latency form of round 6 for
+// launches that leave CUs idle, ntt_core.h plan_k; chosen by the launch wrappers from the number of limbs, same bits).
+template <int LOGN, bool INV, int T, int C = 16>
 __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
                                            const int *__restrict__ modmap, int period, int split)
 {
@@ -39,14 +41,14 @@ __global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttT
     // (the inverse transform stages its limb into LDS with coalesced loads: SrcStaged, ntt_core.h)
     using SRC = std::conditional_t<INV, SrcStaged, SrcPlain>;
     if (INV && ((mv & NTT_MAP_RAW) || split)) {                                 // wave-uniform branches
-        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
-        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
-        else ntt_body<LOGN, INV, NTT_WIDE, T, 0, INV, SRC>(lds, p, tab, tid, nullptr, SRC());
+        if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, INV, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
+        else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, INV, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
+        else ntt_body<LOGN, INV, NTT_WIDE, T, 0, INV, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
         return;
     }
-    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
-    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
-    else ntt_body<LOGN, INV, NTT_WIDE, T, 0, false, SRC>(lds, p, tab, tid, nullptr, SRC());
+    if (tab.narrow) ntt_body<LOGN, INV, NTT_NARROW, T, 0, false, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
+    else if (tab.wide_d4) ntt_body<LOGN, INV, NTT_WIDE_NEAR, T, 0, false, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
+    else ntt_body<LOGN, INV, NTT_WIDE, T, 0, false, SRC, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SRC());
 }
 
 constexpr int EW_T = 256;                                         // threads per workgroup of the coefficient-parallel kernels
@@ -98,8 +100,10 @@ __global__ __launch_bounds__(EW_T) void k_ntt_last_stage(u64 *__restrict__ data,
 
 // Forward NTT of gathered limbs: limb g is read from src[g] (residues of another modulus, reduced on load) and written
 // to data + g*N.  Replaces the decompose kernel of the key switch (App. B10): out[I][J] = NTT_I(c2_J mod m_I).
-template <int LOGN, int T>
-__global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restrict__ src, u64 *__restrict__ data,
+// MINW: waves per SIMD the register budget must admit (8: <= 64 VGPRs, two 1024-thread workgroups per CU at n = 8192 -- the form large
+// gathered launches take since round 6: -1 ... -5 %, tools/microbench/ntt_forms.hip)
+template <int LOGN, int T, int C = 16, int MINW = 4>
+__global__ __launch_bounds__(T, MINW) void k_ntt_gather(const u64 *const *__restrict__ src, u64 *__restrict__ data,
                                                   const NttTable *__restrict__ tabs, const int *__restrict__ modmap, int period, int nored)
 {
     constexpr int N = 1 << LOGN;
@@ -111,17 +115,42 @@ __global__ __launch_bounds__(T, 4) void k_ntt_gather(const u64 *const *__restric
     // nored: every source residue fits the lazy range of every (narrow) target as it stands (checked by the host, ntt_gather_nored_ok):
     // the transform is linear and its closing reduction takes any 64-bit value, so the reduction on load is left out
     if (tab.narrow) {
-        if (nored) ntt_body<LOGN, false, NTT_NARROW, T, 2>(lds, p, tab, tid, src[g]);
-        else ntt_body<LOGN, false, NTT_NARROW, T, 1>(lds, p, tab, tid, src[g]);
-    } else if (tab.wide_d4) ntt_body<LOGN, false, NTT_WIDE_NEAR, T, 1>(lds, p, tab, tid, src[g]);
-    else ntt_body<LOGN, false, NTT_WIDE, T, 1>(lds, p, tab, tid, src[g]);
+        if (nored) ntt_body<LOGN, false, NTT_NARROW, T, 2, false, SrcPlain, true, false, 0, -1, C>(lds, p, tab, tid, src[g]);
+        else ntt_body<LOGN, false, NTT_NARROW, T, 1, false, SrcPlain, true, false, 0, -1, C>(lds, p, tab, tid, src[g]);
+    } else if (tab.wide_d4) ntt_body<LOGN, false, NTT_WIDE_NEAR, T, 1, false, SrcPlain, true, false, 0, -1, C>(lds, p, tab, tid, src[g]);
+    else ntt_body<LOGN, false, NTT_WIDE, T, 1, false, SrcPlain, true, false, 0, -1, C>(lds, p, tab, tid, src[g]);
+}
+
+// Which form of the workgroup does a launch of `count` limbs take?  latency_limbs: 0 = always 16 coefficients per lane; NTT_FORM_AUTO = the
+// crossovers measured with tools/microbench/ntt_forms.hip (profiles/r06_ntt_forms_n8192.txt, _n4096.txt): at n = 8192 a limb's
+// 1024-thread workgroup wins while a CU gets at most one limb (<= 256 limbs: -3 ... -16 %) and loses above (+2 ... +20 %); at n = 4096
+// (512 threads, registers for 7-8 waves per SIMD) the forward, gathered and tensor-on-load transforms win at every size (-2 ... -24 %), the
+// plain inverse up to 1 024 limbs; any other value = that threshold for every kind (tests force either form with it).
+enum NttKind { NTT_KIND_FORWARD, NTT_KIND_INVERSE, NTT_KIND_GATHER, NTT_KIND_TENSOR };
+static bool ntt_use_latency_form(int logn, NttKind kind, size_t count, size_t latency_limbs)
+{
+    if (!plan_has_latency_form(logn) || latency_limbs == 0) return false;
+    if (latency_limbs != NTT_FORM_AUTO) return count <= latency_limbs;
+    if (logn == 13) return count <= 256;
+    return kind != NTT_KIND_INVERSE || count <= 1024;
 }
 
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                       hipStream_t st, bool nored)
+                       hipStream_t st, bool nored, size_t latency_limbs)
 {
     const int nr = nored ? 1 : 0;
     if (!count) return;
+    if (ntt_use_latency_form(logn, NTT_KIND_GATHER, count, latency_limbs)) {
+        if (logn == 13) hipLaunchKernelGGL((k_ntt_gather<13, 1024, 8>), dim3((unsigned)count), dim3(1024), 0, st, src, data, tabs, modmap, period, nr);
+        else hipLaunchKernelGGL((k_ntt_gather<12, 512, 8>), dim3((unsigned)count), dim3(512), 0, st, src, data, tabs, modmap, period, nr);
+        KERNEL_CHECK();
+        return;
+    }
+    if (latency_limbs == NTT_FORM_AUTO && logn == 13) {          // large gathered launches at n = 8192: 8 coefficients per lane at 8 waves per SIMD
+        hipLaunchKernelGGL((k_ntt_gather<13, 1024, 8, 8>), dim3((unsigned)count), dim3(1024), 0, st, src, data, tabs, modmap, period, nr);
+        KERNEL_CHECK();
+        return;
+    }
     if (logn == 15) {                                            // first stage gathers and reduces, the halves are plain transforms
         const size_t n = (size_t)1 << 15;
         hipLaunchKernelGGL(k_ntt_first_stage, dim3((unsigned)((n / 2 + EW_T - 1) / EW_T), (unsigned)count), dim3(EW_T), 0, st, src, data, n, tabs, modmap, period);
@@ -143,7 +172,7 @@ void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count,
 // the NTT-form operands while it loads (SrcTensor) and writes the coefficient-form limb to job.d[p][e]: the tensor kernel,
 // its 3*E limb writes and the transform's re-read of them are gone.  Workgroups g >= n_tensor transform
 // plain[g - n_tensor] in place (limbs that join the same launch).  Operand polys are src_ps words apart.
-template <int LOGN, int T>
+template <int LOGN, int T, int C = 16>
 __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restrict__ jobs, int limbs, size_t src_ps, size_t n_tensor,
                                                    u64 *__restrict__ plain, const NttTable *__restrict__ tabs,
                                                    const int *__restrict__ modmap, int period)
@@ -172,13 +201,13 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     if (g >= n_tensor) {                                                        // wave-uniform
         u64 *p = plain + (g - n_tensor) * N;
         if (mv & NTT_MAP_RAW) {
-            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
-            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
-            else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
+            else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
         } else {
-            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
-            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
-            else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcStaged>(lds, p, tab, tid, nullptr, SrcStaged());
+            if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
+            else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
+            else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcStaged, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, SrcStaged());
         }
         return;
     }
@@ -194,22 +223,28 @@ __global__ __launch_bounds__(T, 4) void k_intt_tensor(const TensorJob *__restric
     else ops = SrcTensor{ a1, b1, nullptr, nullptr, lazy };
     u64 *p = job.d + (size_t)r * N;
     if (mv & NTT_MAP_RAW) {
-        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, true, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, true, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, 0, true, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
     } else {
-        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
-        else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcTensor>(lds, p, tab, tid, nullptr, ops);
+        if (tab.narrow) ntt_body<LOGN, true, NTT_NARROW, T, 0, false, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
+        else if (tab.wide_d4) ntt_body<LOGN, true, NTT_WIDE_NEAR, T, 0, false, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
+        else ntt_body<LOGN, true, NTT_WIDE, T, 0, false, SrcTensor, true, false, 0, -1, C>(lds, p, tab, tid, nullptr, ops);
     }
 }
 
 void launch_intt_tensor(int logn, const TensorJob *jobs, int njobs, int limbs, size_t src_ps, u64 *plain, size_t n_plain,
-                        const NttTable *tabs, const int *modmap, int period, hipStream_t st)
+                        const NttTable *tabs, const int *modmap, int period, hipStream_t st, size_t latency_limbs)
 {
     const size_t n_tensor = (size_t)njobs * 3 * limbs;
     const size_t count = (n_tensor / 3 + 7) / 8 * 24 + n_plain;                 // the XCD-aware order pads the pairs to blocks of eight
     if (!(n_tensor + n_plain)) return;
+    if (ntt_use_latency_form(logn, NTT_KIND_TENSOR, n_tensor + n_plain, latency_limbs)) {
+        if (logn == 13) hipLaunchKernelGGL((k_intt_tensor<13, 1024, 8>), dim3((unsigned)count), dim3(1024), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period);
+        else hipLaunchKernelGGL((k_intt_tensor<12, 512, 8>), dim3((unsigned)count), dim3(512), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period);
+        KERNEL_CHECK();
+        return;
+    }
 #define T_CASE(LN, T) case LN: hipLaunchKernelGGL((k_intt_tensor<LN, T>), dim3((unsigned)count), dim3(T), 0, st, jobs, limbs, src_ps, n_tensor, plain, tabs, modmap, period); break;
     switch (logn) {
     T_CASE(14, 1024) T_CASE(13, 512) T_CASE(12, 256) T_CASE(11, 128) T_CASE(10, 64) T_CASE(8, 64) T_CASE(6, 64)
@@ -238,9 +273,20 @@ static void launch_ntt_split(bool inverse, const u64 *const *src, u64 *data, siz
 }
 
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                hipStream_t st)
+                hipStream_t st, size_t latency_limbs)
 {
     if (!count) return;
+    if (ntt_use_latency_form(logn, inverse ? NTT_KIND_INVERSE : NTT_KIND_FORWARD, count, latency_limbs)) {   // 8 coefficients per lane
+        if (logn == 13) {
+            if (inverse) hipLaunchKernelGGL((k_ntt<13, true, 1024, 8>), dim3((unsigned)count), dim3(1024), 0, st, data, tabs, modmap, period, 0);
+            else hipLaunchKernelGGL((k_ntt<13, false, 1024, 8>), dim3((unsigned)count), dim3(1024), 0, st, data, tabs, modmap, period, 0);
+        } else {
+            if (inverse) hipLaunchKernelGGL((k_ntt<12, true, 512, 8>), dim3((unsigned)count), dim3(512), 0, st, data, tabs, modmap, period, 0);
+            else hipLaunchKernelGGL((k_ntt<12, false, 512, 8>), dim3((unsigned)count), dim3(512), 0, st, data, tabs, modmap, period, 0);
+        }
+        KERNEL_CHECK();
+        return;
+    }
     switch (logn) {
     case SPLIT_LOGN: launch_ntt_split(inverse, nullptr, data, count, tabs, modmap, period, st); break;
     case 14: launch_ntt_t<14, 1024>(inverse, data, count, tabs, modmap, period, st); break;
@@ -489,10 +535,12 @@ __global__ __launch_bounds__(EW_T) void k_copy_jobs(const CtJob *__restrict__ jo
 }
 
 // The same for the source ciphertexts of a query ([2][L][n] each): while it copies, every word is held against the prime of its limb
-// (seal::is_data_valid_for); a word outside [0, q) raises *bad -- a word of page-locked host memory the engine looks at when it next
-// waits for the device.  The lazy transforms take source limbs as they are, so such a word must not pass silently.
+// (seal::is_data_valid_for); a word outside [0, q) writes the query's sequence number `seq` to *bad -- a word of page-locked host memory
+// the engine looks at when it next waits for the device (one word per query in flight, so the report names the query: round 6).  The lazy
+// transforms take source limbs as they are, so such a word must not pass silently.  src == dst: a check in place (sources that came from
+// the host by a plain copy).
 __global__ __launch_bounds__(EW_T) void k_copy_sources(const CtJob *__restrict__ jobs, size_t words, const DevLevel *__restrict__ lv, int L, size_t n,
-                                                       unsigned *__restrict__ bad)
+                                                       unsigned *__restrict__ bad, unsigned seq)
 {
     const CtJob job = jobs[blockIdx.y];
     bool wrong = false;
@@ -500,16 +548,16 @@ __global__ __launch_bounds__(EW_T) void k_copy_sources(const CtJob *__restrict__
         const u64x2 v = *reinterpret_cast<const u64x2 *>(job.src + k);
         const u64 q = lv->q[(k / n) % (size_t)L].q;                 // (n is even: both words lie in the same limb)
         wrong |= v[0] >= q || v[1] >= q;
-        *reinterpret_cast<u64x2 *>(job.dst + k) = v;
+        if (job.dst != job.src) *reinterpret_cast<u64x2 *>(job.dst + k) = v;
     }
-    if (wrong) atomicOr(bad, 1u);
+    if (wrong) atomicMax(bad, seq);
 }
 
-void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, hipStream_t st)
+void launch_copy_sources(const CtJob *jobs, size_t words, int njobs, const DevLevel *lv, int L, size_t n, unsigned *bad, unsigned seq, hipStream_t st)
 {
     if (!njobs) return;
     unsigned gx = (unsigned)std::min<size_t>((words / 2 + EW_T - 1) / EW_T, 64);
-    hipLaunchKernelGGL(k_copy_sources, dim3(gx, (unsigned)njobs), dim3(EW_T), 0, st, jobs, words, lv, L, n, bad);
+    hipLaunchKernelGGL(k_copy_sources, dim3(gx, (unsigned)njobs), dim3(EW_T), 0, st, jobs, words, lv, L, n, bad, seq);
     KERNEL_CHECK();
 }
 

@@ -409,7 +409,7 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             const bool mask_direct = mask_dev ? reachable(in_device) : (flags & IO_MASKS_PINNED) != 0;
             const bool stage_src = !src_dev && !src_direct, stage_mask = !mask_dev && !mask_direct;
             if (stage_src || stage_mask) ensure_pinned(d.host_in, d.host_in_bytes, in_words * sizeof(u64));
-            if (((src_dev && !src_direct) || (mask_dev && !mask_direct)) && d.in.bytes() < in_words * sizeof(u64)) { E.wait(); d.in.alloc(in_words * sizeof(u64)); }
+            if (((src_dev && !src_direct) || (mask_dev && !mask_direct)) && d.in.bytes() < in_words * sizeof(u64)) { E.drain(); d.in.alloc(in_words * sizeof(u64)); }
             u64 *stage = static_cast<u64 *>(d.host_in);
             // 1. the query ciphertexts, in the order ComputePowers takes them
             std::vector<const u64 *> src(n_src);
@@ -446,7 +446,7 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             std::vector<u64 *> rows(cnt);
             bool scatter_host = false, peer_copy = false;
             if (use_rccl) {
-                if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.wait(); d.out.alloc(max_rows * row * sizeof(u64)); }
+                if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.drain(); d.out.alloc(max_rows * row * sizeof(u64)); }
                 for (int i = 0; i < cnt; i++) rows[i] = d.out.u() + (size_t)i * row;
             } else if (out_device < 0 && (flags & IO_OUT_PINNED)) {
                 for (int i = 0; i < cnt; i++) rows[i] = out + (size_t)d.ids[i] * row;
@@ -457,7 +457,7 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             } else if (reachable(out_device)) {
                 for (int i = 0; i < cnt; i++) rows[i] = out + (size_t)d.ids[i] * row;      // xGMI peer writes: the gather is the store
             } else {
-                if (d.out.bytes() < bytes) { E.wait(); d.out.alloc(bytes); }
+                if (d.out.bytes() < bytes) { E.drain(); d.out.alloc(bytes); }
                 for (int i = 0; i < cnt; i++) rows[i] = d.out.u() + (size_t)i * row;
                 peer_copy = true;
             }
@@ -465,13 +465,26 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             if (peer_copy)
                 for (int i = 0; i < cnt; i++)
                     HIP_CHECK(hipMemcpyPeerAsync(out + (size_t)d.ids[i] * row, out_device, rows[i], d.device, row * sizeof(u64), st));
-            if (!use_rccl) HIP_CHECK(hipStreamSynchronize(st));
+            if (!use_rccl) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                // the query's work is complete: a source coefficient outside [0, q) is THIS call's error (round 6: it used to surface at a
+                // later, valid query's next wait)
+                if (E.take_bad_source()) throw std::invalid_argument("a source ciphertext of apsu_he_eval_all holds a coefficient outside [0, q): "
+                                                                     "the results computed from it are not valid (seal::is_data_valid_for)");
+            }
             if (scatter_host) {
                 stage_jobs.clear();
                 for (int i = 0; i < cnt; i++) stage_jobs.push_back({ out + (size_t)d.ids[i] * row, rows[i] });
                 parallel_stage(stage_jobs, row * sizeof(u64));
             }
             E.recycle_powers(std::move(pw));
+        }
+        if (use_rccl) {
+            // Everything that may wait or throw happens HERE, in front of the rendezvous: between the rendezvous and the collective a
+            // worker that leaves strands its peers inside ncclAllGather (round 6).
+            const size_t need = devs_.size() * max_rows * row * sizeof(u64);
+            if (d.gath.bytes() < need) { E.drain(); d.gath.alloc(need); }
+            if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.drain(); d.out.alloc(max_rows * row * sizeof(u64)); }
         }
         } catch (...) { compute_error = std::current_exception(); }
         if (use_rccl) {
@@ -483,9 +496,6 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
             if (!all_ok) { (void)hipStreamSynchronize(st); throw std::runtime_error("another device failed before the RCCL gather; nothing was gathered"); }
             // ONE all-gather of max_rows fixed-size rows per device, then the output device places them by id
             const int slot = my_slot;
-            const size_t need = devs_.size() * max_rows * row * sizeof(u64);
-            if (d.gath.bytes() < need) { E.wait(); d.gath.alloc(need); }
-            if (d.out.bytes() < max_rows * row * sizeof(u64)) { E.wait(); d.out.alloc(max_rows * row * sizeof(u64)); }
             const int rc = rccl_->all_gather(d.out.u(), d.gath.u(), max_rows * row, /* ncclUint64 */ 5, my_comm, st);
             if (rc != 0) {                                        // the peers may already sit in the collective: abort every communicator so they return
                 const std::string why = rccl_->err ? rccl_->err(rc) : "?";
@@ -499,6 +509,10 @@ void MultiEngine::eval_all(const u64 *const *src_cts, const u64 *const *masks, u
                                                  hipMemcpyDeviceToDevice, st));
             }
             HIP_CHECK(hipStreamSynchronize(st));
+            // every rank has left the all-gather: only now may this rank report its query's invalid source (thrown earlier, it would have
+            // left the peers inside the collective)
+            if (E.take_bad_source()) throw std::invalid_argument("a source ciphertext of apsu_he_eval_all holds a coefficient outside [0, q): "
+                                                                 "the results computed from it are not valid (seal::is_data_valid_for)");
         } else if (compute_error) std::rethrow_exception(compute_error);
     });
     if (phase_on_) {

@@ -310,8 +310,8 @@ HD int ntt_mode(const NttTable &tab) { return tab.narrow ? NTT_NARROW : (tab.wid
 // columns.  Either way (2^K - 1) * GM entries; slot numbering below.  A pass either loads them where it uses them (TwInline)
 // or takes a set that was loaded EARLIER -- by the pass in front of it, just before that pass stored its results, so that
 // the table loads (L2 latency) overlap the LDS turnaround instead of following it (round 4; ntt_wg.h).
-template <int LOGN, int S, int K, bool INV> struct PassShape {
-    static constexpr int R = 1 << K, G = 16 >> K, LOWBITS = LOGN - S - K;
+template <int LOGN, int S, int K, bool INV, int C = 16> struct PassShape {
+    static constexpr int R = 1 << K, G = C >> K, LOWBITS = LOGN - S - K;
     static constexpr bool COLS = (1 << LOWBITS) >= G;
     static constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;
     static constexpr int GM = INV ? (COLS ? G : 1) : (COLS ? 1 : G);
@@ -325,10 +325,10 @@ template <int NT> struct TwRegs { u64x2 t[NT > 0 ? NT : 1]; };
 struct NoHook { HD void operator()() const {} };
 
 // table entries of pass (S, K) for work item w into tw (same index algebra as ntt_pass16 below)
-template <int LOGN, int S, int K, bool INV>
-HD void ntt_load_twiddles(TwRegs<PassShape<LOGN, S, K, INV>::NT> &tw, int w, const NttTable &tab)
+template <int LOGN, int S, int K, bool INV, int C = 16>
+HD void ntt_load_twiddles(TwRegs<PassShape<LOGN, S, K, INV, C>::NT> &tw, int w, const NttTable &tab)
 {
-    using PS = PassShape<LOGN, S, K, INV>;
+    using PS = PassShape<LOGN, S, K, INV, C>;
     constexpr int R = PS::R, G = PS::G, LOWBITS = PS::LOWBITS, CG = PS::CG;
     constexpr bool COLS = PS::COLS;
     constexpr bool UNIFORM_TW = COLS && (CG % 64 == 0);
@@ -362,21 +362,23 @@ HD void ntt_load_twiddles(TwRegs<PassShape<LOGN, S, K, INV>::NT> &tw, int w, con
     (void)R;
 }
 
-// One pass over stages S .. S+K-1 for work item w in [0, n/16).
+// One pass over stages S .. S+K-1 for work item w in [0, n/C): C coefficients per work item (16: the throughput form, one limb per
+// 512-thread workgroup at n = 8192; 8: the latency form of round 6, twice the waves per limb -- see plan_k below).
 //   forward: Cooley-Tukey, stages ascending; inverse: decimation-in-time cyclic inverse, stages descending (gap 1 first).
 //   IN / OUT: where the 16 coefficients come from / go to (LDS image or the limb in global memory).
 // MODE: range discipline of the modulus (wave-uniform per limb): see NTT_NARROW / NTT_WIDE / NTT_WIDE_NEAR
 //   TW: TwInline, or the pass's twiddles loaded earlier (TwRegs);  HOOK: called once between the butterflies and the stores
 //   (ntt_wg.h uses it to issue the NEXT pass's twiddle loads).
 template <int LOGN, int S, int K, bool INV, int MODE, int IN, int OUT, int RED = 0, bool RAW = false, class SRC = SrcPlain,
-          class TW = TwInline, class HOOK = NoHook>
+          class TW = TwInline, class HOOK = NoHook, int C = 16>
 HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab, const SRC &src = SRC(), const TW &tw = TW(),
                    const HOOK &hook = HOOK())
 {
-    using PS = PassShape<LOGN, S, K, INV>;
+    using PS = PassShape<LOGN, S, K, INV, C>;
+    static_assert((C == 16 || C == 8 || C == 4) && (1 << K) <= C, "radix 2^K on C coefficients per work item");
     constexpr bool PRE = !std::is_same<TW, TwInline>::value;
     constexpr int R = 1 << K;                  // radix
-    constexpr int G = 16 >> K;                 // independent groups per thread
+    constexpr int G = C >> K;                  // independent groups per thread
     constexpr int LOWBITS = LOGN - S - K;      // bits of the column index
     constexpr bool COLS = (1 << LOWBITS) >= G; // groups = adjacent columns (else adjacent blocks)
     constexpr int CG = COLS ? ((1 << LOWBITS) / G) : 1;      // column groups per block
@@ -536,12 +538,26 @@ HD u64 ntt_fwd_finish(u64 v, const NttTable &tab)
 }
 
 // ---- pass schedule (stage counts per pass, summing to LOGN), resolved at compile time ----
-constexpr int plan_passes(int logn)
+// c = coefficients per work item.  c = 16: the throughput form (rounds 1-5).  c = 8 (round 6): the LATENCY form for launches that
+// cannot fill the chip -- a limb's workgroup has twice the waves (n = 8192: 1 024 threads = 4 waves per SIMD of its CU instead of 2), so a
+// lone limb's LDS turnarounds, twiddle loads and global round trips are covered by three other waves per SIMD instead of one; the
+// price is one more pass (radix <= 8) and one more workgroup barrier.  Same twiddle tables, same lazy ranges, same bits.
+//   n = 8192: 2,3,3,3,2 -- the first pass (forward: reads global memory; inverse: writes it) keeps column PAIRS, i.e. 16-byte
+//             coalesced global accesses;  n = 4096: 3,3,3,3 (one barrier, 8-byte global accesses).
+constexpr int plan_passes(int logn, int c = 16)
 {
+    if (c == 8) return logn == 13 ? 5 : logn == 12 ? 4 : 0;
     return logn == 14 ? 4 : logn == 13 ? 4 : logn == 12 ? 4 : logn == 11 ? 4 : logn == 10 ? 3 : logn == 8 ? 3 : logn == 6 ? 2 : 0;
 }
-constexpr int plan_k(int logn, int p)
+constexpr int plan_k(int logn, int p, int c = 16)
 {
+    if (c == 8) {
+        switch (logn) {
+        case 13: return (p == 0 || p == 4) ? 2 : 3;   // 2,3,3,3,2
+        case 12: return 3;                            // 3,3,3,3
+        default: return 0;
+        }
+    }
     switch (logn) {
     case 14: return p >= 2 ? 4 : 3;               // 3,3,4,4   (n = 16384: 144 KiB of LDS, one 1024-thread workgroup per CU)
     case 13: return p == 3 ? 4 : 3;               // 3,3,3,4
@@ -553,43 +569,45 @@ constexpr int plan_k(int logn, int p)
     default: return 0;
     }
 }
-constexpr int plan_s(int logn, int p)
+constexpr int plan_s(int logn, int p, int c = 16)
 {
     int s = 0;
-    for (int i = 0; i < p; i++) s += plan_k(logn, i);
+    for (int i = 0; i < p; i++) s += plan_k(logn, i, c);
     return s;
 }
+constexpr bool plan_has_latency_form(int logn) { return plan_passes(logn, 8) > 0; }
 
 // shape of the pass executed PASS-th (for the twiddle sets above)
-template <int LOGN, bool INV, int PASS> struct ExecPass {
-    static constexpr int P = plan_passes(LOGN), p = INV ? P - 1 - PASS : PASS, K = plan_k(LOGN, p), S = plan_s(LOGN, p);
-    using Shape = PassShape<LOGN, S, K, INV>;
+template <int LOGN, bool INV, int PASS, int C = 16> struct ExecPass {
+    static constexpr int P = plan_passes(LOGN, C), p = INV ? P - 1 - PASS : PASS, K = plan_k(LOGN, p, C), S = plan_s(LOGN, p, C);
+    using Shape = PassShape<LOGN, S, K, INV, C>;
     using Tw = TwRegs<Shape::NT>;
 };
-template <int LOGN, bool INV, int PASS>
-HD void ntt_pass_twiddles(typename ExecPass<LOGN, INV, PASS>::Tw &tw, int tid, const NttTable &tab)
+template <int LOGN, bool INV, int PASS, int C = 16>
+HD void ntt_pass_twiddles(typename ExecPass<LOGN, INV, PASS, C>::Tw &tw, int tid, const NttTable &tab)
 {
-    using E = ExecPass<LOGN, INV, PASS>;
-    ntt_load_twiddles<LOGN, E::S, E::K, INV>(tw, tid, tab);
+    using E = ExecPass<LOGN, INV, PASS, C>;
+    ntt_load_twiddles<LOGN, E::S, E::K, INV, C>(tw, tid, tab);
 }
 
 // Executes pass number PASS (in execution order) for "thread" tid of a T-thread workgroup.
 // The caller separates passes with __syncthreads() (device) or by looping tid (host emulation).
 //   forward: pass 0 reads the limb from global memory, the last pass leaves data in LDS (the caller
-//            then stores it coalesced);   inverse: pass 0 reads global memory too (16 contiguous coefficients per lane),
+//            then stores it coalesced);   inverse: pass 0 reads global memory too (C contiguous coefficients per lane),
 //            the last pass writes the scaled result straight to global memory.
 // STAGED: the caller has already put the input into the LDS image (k_intt_tensor forms its products with coalesced loads).
 template <int LOGN, bool INV, int MODE, int PASS, int RED = 0, bool RAW = false, class SRC = SrcPlain, bool STAGED = false,
-          class TW = TwInline, class HOOK = NoHook>
+          class TW = TwInline, class HOOK = NoHook, int C = 16>
 HD void ntt_pass(u64 *lds, u64 *glob, int tid, int T, const NttTable &tab, const SRC &src = SRC(), const TW &tw = TW(),
                  const HOOK &hook = HOOK())
 {
-    constexpr int P = plan_passes(LOGN);
+    constexpr int P = plan_passes(LOGN, C);
     constexpr int p = INV ? P - 1 - PASS : PASS;      // the inverse walks the passes last-to-first
-    constexpr int K = plan_k(LOGN, p);
-    constexpr int S = plan_s(LOGN, p);
+    constexpr int K = plan_k(LOGN, p, C);
+    constexpr int S = plan_s(LOGN, p, C);
     constexpr int IN = (PASS == 0 && !STAGED) ? IO_GLOBAL : IO_LDS;   // both directions read the limb straight from global memory
     constexpr int OUT = (INV && PASS == P - 1) ? IO_GLOBAL : IO_LDS;
-    for (int w = tid; w < (1 << (LOGN - 4)); w += T)
-        ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW, SRC, TW, HOOK>(lds, glob, w, tab, src, tw, hook);
+    constexpr int LOGC = C == 16 ? 4 : C == 8 ? 3 : 2;
+    for (int w = tid; w < (1 << (LOGN - LOGC)); w += T)
+        ntt_pass16<LOGN, S, K, INV, MODE, IN, OUT, RED, RAW, SRC, TW, HOOK, C>(lds, glob, w, tab, src, tw, hook);
 }

@@ -17,8 +17,8 @@
 
 #if defined(__HIPCC__)
 
-// does pass p (forward numbering) of a T-thread workgroup stay inside each wave's own 1024-coefficient range?
-template <int LOGN, int T> constexpr bool ntt_wave_private(int p) { return T == 64 || (LOGN - plan_s(LOGN, p) <= 10); }
+// does pass p (forward numbering) of a T-thread workgroup stay inside each wave's own range of 64 C coefficients (C per lane: 1024 at C = 16)?
+template <int LOGN, int T, int C = 16> constexpr bool ntt_wave_private(int p) { return T == 64 || (LOGN - plan_s(LOGN, p, C) <= (C == 16 ? 10 : C == 8 ? 9 : 8)); }
 
 template <bool WAVE> __device__ __forceinline__ void ntt_sync()
 {
@@ -50,23 +50,29 @@ __device__ __forceinline__ void ntt_touch_line(const void *line, unsigned &sink)
 }
 __device__ __forceinline__ void ntt_touch_done(unsigned &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)); }
 
+// C (round 6): coefficients per lane.  16 = the throughput form (T = n / 16 threads per limb); 8 = the latency form for launches that leave
+// CUs idle (T = n / 8: twice the waves per limb, five passes 2,3,3,3,2 at n = 8192 with two workgroup barriers -- ntt_core.h, plan_k).
 template <int LOGN, bool INV, int MODE, int T, int RED = 0, bool RAW = false, class SRC = SrcPlain, bool WS = true, bool PF = false, int STAGGER = 0,
-          int NEXTPASS = -1>
+          int NEXTPASS = -1, int C = 16>
 __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const NttTable &tab, int tid, const u64 *src = nullptr,
                                          const SRC &operands = SRC(), const void *next = nullptr)
 {
     constexpr int N = 1 << LOGN;
-    constexpr int P = plan_passes(LOGN);
-    static_assert(T % 64 == 0 && T * 16 >= N, "one work item per thread");
+    constexpr int P = plan_passes(LOGN, C);
+    static_assert(T % 64 == 0 && T * C >= N, "one work item per thread");
+    static_assert(P > 0, "no pass schedule for this ring size and coefficients per lane");
+    static_assert(C == 16 || (!PF && STAGGER == 0 && NEXTPASS < 0), "the experiment switches exist for the 16-coefficient form only");
+    constexpr int WCO = 64 * C / 128;                // 16-byte-per-lane sweeps over a wave's own range of 64 C coefficients
     // forward numbering of the pass executed k-th
     auto fp = [](int k) constexpr { return INV ? P - 1 - k : k; };
     // the sync in front of the pass executed k-th (k >= 1) may be wave-level iff that pass and the one before it are wave-private
     // (S grows with the forward numbering, so the lower-numbered of the two decides)
-    constexpr bool W1 = WS && P > 1 && ntt_wave_private<LOGN, T>(fp(0) < fp(1) ? fp(0) : fp(1));
-    constexpr bool W2 = WS && P > 2 && ntt_wave_private<LOGN, T>(fp(1) < fp(2) ? fp(1) : fp(2));
-    constexpr bool W3 = WS && P > 3 && ntt_wave_private<LOGN, T>(fp(2) < fp(3) ? fp(2) : fp(3));
+    constexpr bool W1 = WS && P > 1 && ntt_wave_private<LOGN, T, C>(fp(0) < fp(1) ? fp(0) : fp(1));
+    constexpr bool W2 = WS && P > 2 && ntt_wave_private<LOGN, T, C>(fp(1) < fp(2) ? fp(1) : fp(2));
+    constexpr bool W3 = WS && P > 3 && ntt_wave_private<LOGN, T, C>(fp(2) < fp(3) ? fp(2) : fp(3));
+    constexpr bool W4 = WS && P > 4 && ntt_wave_private<LOGN, T, C>(fp(3) < fp(4) ? fp(3) : fp(4));
     // the wave's own range for the coalesced loops (tensor staging, forward store): 16-byte pieces, 1 KiB per wave instruction
-    const int wbase = (tid & ~63) << 4, lane = tid & 63;
+    const int wbase = (tid & ~63) * C, lane = tid & 63;
     unsigned sink = 0;
     if constexpr (NEXTPASS == 0) { if (next) ntt_touch_line(next, sink); }
     if constexpr (STAGGER > 0 && INV) { if (tid & 256) __builtin_amdgcn_s_sleep(STAGGER); }
@@ -107,15 +113,15 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
         if constexpr (P > 2) { ntt_sync<W2>(); ntt_pass<LOGN, INV, MODE, 2, 0, RAW, SrcPlain, false, decltype(t2), decltype(h3)>(lds, p, tid, T, tab, SrcPlain(), t2, h3); }
         if constexpr (P > 3) { ntt_sync<W3>(); ntt_pass<LOGN, INV, MODE, 3, 0, RAW, SrcPlain, false, decltype(t3)>(lds, p, tid, T, tab, SrcPlain(), t3); }
     } else {
-    if constexpr (RED != 0) ntt_pass<LOGN, INV, MODE, 0, RED>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
+    if constexpr (RED != 0) ntt_pass<LOGN, INV, MODE, 0, RED, false, SrcPlain, false, TwInline, NoHook, C>(lds, const_cast<u64 *>(src), tid, T, tab);   // forward only: pass 0 just reads
     else if constexpr (!std::is_same<SRC, SrcPlain>::value) {
         // computed input (tensor product on load): four operand streams read with the first pass's 128-byte lane stride
         // thrash the vector L1 (measured: the fused launch 65 % slower than tensor + transform apart), so the products are
         // formed with coalesced 16-byte loads into the LDS image and the first pass starts from there
-        constexpr bool WL = WS && ntt_wave_private<LOGN, T>(fp(0));
+        constexpr bool WL = WS && ntt_wave_private<LOGN, T, C>(fp(0));
         if constexpr (WL) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < WCO; i++) {
                 const int e = wbase + 128 * i + 2 * lane;
                 if (e < N) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
             }
@@ -123,24 +129,25 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
             for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
         }
         ntt_sync<WL>();
-        ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, true>(lds, p, tid, T, tab);
-    } else ntt_pass<LOGN, INV, MODE, 0>(lds, p, tid, T, tab);
+        ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, true, TwInline, NoHook, C>(lds, p, tid, T, tab);
+    } else ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab);
     // (RAW only concerns the pass that leaves the inverse transform, the last one)
     if constexpr (P > 1) {
         ntt_sync<W1>();
         if constexpr (STAGGER > 0 && !INV) { if (tid & 256) __builtin_amdgcn_s_sleep(STAGGER); }
         if constexpr (NEXTPASS == 1) { if (next) ntt_touch_line(next, sink); }
-        ntt_pass<LOGN, INV, MODE, 1, 0, RAW>(lds, p, tid, T, tab);
+        ntt_pass<LOGN, INV, MODE, 1, 0, RAW, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab);
     }
-    if constexpr (P > 2) { ntt_sync<W2>(); if constexpr (NEXTPASS == 2) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 2, 0, RAW>(lds, p, tid, T, tab); }
-    if constexpr (P > 3) { ntt_sync<W3>(); if constexpr (NEXTPASS == 3) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 3, 0, RAW>(lds, p, tid, T, tab); }
+    if constexpr (P > 2) { ntt_sync<W2>(); if constexpr (NEXTPASS == 2) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 2, 0, RAW, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab); }
+    if constexpr (P > 3) { ntt_sync<W3>(); if constexpr (NEXTPASS == 3) { if (next) ntt_touch_line(next, sink); } ntt_pass<LOGN, INV, MODE, 3, 0, RAW, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab); }
+    if constexpr (P > 4) { ntt_sync<W4>(); ntt_pass<LOGN, INV, MODE, 4, 0, RAW, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab); }
     }
     if constexpr (!INV) {                        // forward: the last pass left 16 contiguous coefficients per lane in LDS
-        constexpr bool WF = WS && ntt_wave_private<LOGN, T>(P - 1);
+        constexpr bool WF = WS && ntt_wave_private<LOGN, T, C>(P - 1);
         ntt_sync<WF>();
         if constexpr (WF) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < WCO; i++) {
                 const int e = wbase + 128 * i + 2 * lane;
                 if (e < N) {
                     u64x2 v = *reinterpret_cast<const u64x2 *>(lds + lds_slot(e));

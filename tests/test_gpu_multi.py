@@ -87,6 +87,43 @@ def test_eval_all_equals_single_context(cfg):
     G.close()
 
 
+@pytest.mark.parametrize("devs", [[0], [0, 0]])
+def test_eval_all_reports_a_source_outside_its_prime_in_the_same_call(devs):
+    """round 6 (advisor, medium): apsu_he_eval_all queues its whole query and ends with a bare stream synchronise -- a source word >= q_limb
+    used to return results silently and to surface at a LATER, valid query's next wait.  Now the call that carried the bad word fails
+    (peer-copy gather and the RCCL request, which falls back to peer copies for a repeated device), the next valid call succeeds with
+    the right bits, and nothing is left behind for a third one"""
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 30], 1: [77]})
+    nidx = S.p["bundle_idx_count"]
+    flat = []
+    for b in range(nidx):
+        for e in S.sources:
+            flat.append(S.src[b][e] if b in S.src else S.src[S.bundle_indices[0]][e])
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    pw = G.compute_powers(S.bundle_indices, [[S.src[b][e] for e in S.sources] for b in S.bundle_indices], rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    want = G.eval_bundles(gb, pw, rk, masks)
+    units = [(b["bundle_idx"], b["cache_idx"], b["degree"]) for b in S.bundles]
+    M = apsu_amd.MultiContext(js, devs)
+    M.upload_relin_keys(S.rk)
+    slots = apsu_amd.partition_bundles(units, nidx, len(devs))
+    for i, b in enumerate(S.bundles):
+        M.upload_bundle(slots[i], b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"])
+    assert (M.eval_all(flat, masks, G.n) == want).all()
+    wrong = [a.copy() for a in flat]
+    wrong[len(S.sources) + 1][1, 0, 9] = np.uint64(int(S.C.q[0]))   # bundle index 1, second source, polynomial 1, limb 0: == q
+    for fl in (0, M.IO_GATHER_RCCL):
+        with pytest.raises(ValueError, match="outside"):
+            M.eval_all(wrong, masks, G.n, flags=fl)
+        assert (M.eval_all(flat, masks, G.n, flags=fl) == want).all()
+        assert (M.eval_all(flat, masks, G.n) == want).all()
+    M.close()
+    G.close()
+
+
 def test_multi_rejects_bad_devices_and_slots():
     js = common.toy_json()
     with pytest.raises(ValueError):

@@ -161,8 +161,10 @@ def test_golden_ops_on_gpu():
     G.close()
 
 
-def test_ntt_large_batch_streams_correctly():
-    """>= 256 MiB of distinct limbs through one launch (every workgroup index, every limb position)"""
+@pytest.mark.parametrize("form", ["0", "100000000"])
+def test_ntt_large_batch_streams_correctly(form, monkeypatch):
+    """>= 256 MiB of distinct limbs through one launch (every workgroup index, every limb position), in both forms of the workgroup"""
+    monkeypatch.setenv("APSU_HE_NTT_LATENCY_LIMBS", form)
     C = ref.RefContext(8192, [56, 56, 56, 50], 0, 22)
     G = apsu_amd.HeContext(n=8192, coeff_modulus=C.q, plain_modulus=C.t)
     rng = np.random.default_rng(15)
@@ -180,10 +182,14 @@ def test_ntt_large_batch_streams_correctly():
     G.close()
 
 
-@pytest.mark.parametrize("n", [2048, 8192, 16384, 32768])
-def test_ntt_every_prime_width(n):
+@pytest.mark.parametrize("n,form", [(2048, None), (4096, "0"), (4096, "100000000"), (8192, "0"), (8192, "100000000"), (16384, None), (32768, None)])
+def test_ntt_every_prime_width(n, form, monkeypatch):
     # coefficient primes of every width the engine may meet, across the narrow / wide boundary of the lazy butterflies
-    # ((4 log n + 1) q < 2^64 up to 58 bits at n = 8192): forward and inverse transforms against the oracle
+    # ((4 log n + 1) q < 2^64 up to 58 bits at n = 8192): forward and inverse transforms against the oracle.
+    # form (round 6): every launch in the throughput form of the workgroup (16 coefficients per lane, APSU_HE_NTT_LATENCY_LIMBS=0) or
+    # every launch in the latency form (8 per lane), for the ring sizes that have both
+    if form is not None:
+        monkeypatch.setenv("APSU_HE_NTT_LATENCY_LIMBS", form)
     rng = np.random.default_rng(n)
     for bits in (30, 33, 40, 47, 52, 55, 56, 57, 58, 59, 60):
         C = ref.RefContext(n, [bits, bits], 65537, 0)

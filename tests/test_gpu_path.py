@@ -227,6 +227,34 @@ def test_device_resident_sources_outside_their_prime_are_reported():
     G.close()
 
 
+def test_host_sources_outside_their_prime_are_reported_per_query():
+    """round 6 (advisor): sources handed over as HOST pointers (what both integration adapters do) went through a plain copy unchecked;
+    they are now held against their primes on the device behind that copy, and the report names its query: a synchronous evaluation of
+    the bad query fails, one of a good query queued right behind it does not, and downloading a power of the bad query fails too"""
+    js = common.param_json("1M-1024-com")
+    S = common.make_scenario(js, {0: [124, 17]})
+    opw = common.oracle_powers(S)
+    G = apsu_amd.HeContext(js)
+    rk = G.upload_relin_keys(S.rk)
+    gb = [G.upload_bundle(b["bundle_idx"], b["cache_idx"], b["coeffs"], b["flags"]) for b in S.bundles]
+    masks = [b["mask"] for b in S.bundles]
+    good = [[S.src[0][e] for e in S.sources]]
+    wrong = [[a.copy() for a in good[0]]]
+    wrong[0][2][0, 1, 4000] = np.uint64(int(S.C.q[1]) + 5)
+    want = np.stack([common.oracle_eval(S, opw, b) for b in S.bundles])
+    pw_bad = G.compute_powers([0], wrong, rk)
+    pw_good = G.compute_powers([0], good, rk)                        # queued behind it, another powers buffer
+    assert (G.eval_bundles(gb, pw_good, rk, masks) == want).all()    # the good query's evaluation does not inherit the report
+    with pytest.raises(ValueError, match="outside"):
+        pw_bad.download(0, 1)
+    pw_bad2 = G.compute_powers([0], wrong, rk)
+    with pytest.raises(ValueError, match="outside"):
+        G.eval_bundles(gb, pw_bad2, rk, masks)
+    G.sync()                                                         # nothing left to report
+    assert (G.eval_bundles(gb, G.compute_powers([0], good, rk), rk, masks) == want).all()
+    G.close()
+
+
 @pytest.mark.parametrize("overlap", [0, 1, 2, 3])
 def test_async_device_results(overlap):
     """apsu_he_set_query_overlap (modes 1-3): the next query's high-power chain / whole ComputePowers may start before the query in front has finished --
@@ -407,7 +435,9 @@ def test_fallback_paths_match():
     # one / two streams (APSU_HE_SPLIT=0/1); the three-product k_mac forced on / off (APSU_HE_MAC_KARA); the evaluation's side work
     # on the main stream (APSU_HE_EVAL_SIDE=0); the database rows as dense 64-bit words instead of bit-packed
     # (APSU_HE_PACKED_ROWS=0); a 1 MiB initial arena exercises overflow -> grow -> retry (APSU_HE_ARENA_BYTES), and a 1-byte workspace
-    # budget evaluates one BinBundle per chunk (APSU_HE_EVAL_WS_BYTES).  (APSU_HE_SEED_EXPAND_HOST: tests/test_gpu_wire_query.py.)
+    # budget evaluates one BinBundle per chunk (APSU_HE_EVAL_WS_BYTES); round 6: every transform launch in the throughput form (16
+    # coefficients per lane, APSU_HE_NTT_LATENCY_LIMBS=0) / every one in the latency form (8 per lane; by default the launch size
+    # decides).  (APSU_HE_SEED_EXPAND_HOST: tests/test_gpu_wire_query.py.)
     # All must give the same bits; scenarios run in child processes.
     import subprocess, sys, os
     head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu_path as t\n"
@@ -419,6 +449,8 @@ def test_fallback_paths_match():
                            ({"APSU_HE_SPLIT": "0", "APSU_HE_MAC_KARA": "1"}, small + big),
                            ({"APSU_HE_SPLIT": "1", "APSU_HE_EVAL_SIDE": "0", "APSU_HE_MAC_KARA": "0"}, small + big),
                            ({"APSU_HE_PACKED_ROWS": "0"}, small + big),
+                           ({"APSU_HE_NTT_LATENCY_LIMBS": "0"}, small + big),
+                           ({"APSU_HE_NTT_LATENCY_LIMBS": "100000000"}, small + big),
                            ({"APSU_HE_ARENA_BYTES": "1048576", "APSU_HE_EVAL_WS_BYTES": "1"}, small)):
         env = dict(os.environ, **switches)
         r = subprocess.run([sys.executable, "-c", head + code], env=env, capture_output=True, text=True, timeout=900)

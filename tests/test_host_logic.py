@@ -178,6 +178,68 @@ def test_ntt_workgroup_emulation_matches_oracle(emu, n, bits):
         assert (a == x).all()
 
 
+@pytest.mark.parametrize("n,bits", [(4096, 36), (4096, 48), (4096, 60), (8192, 50), (8192, 56), (8192, 58), (8192, 60)])
+def test_ntt_latency_form_emulation_matches_oracle(emu, n, bits):
+    """round 6: the LATENCY form of the transform (8 coefficients per work item: n / 8 threads per limb, passes 2,3,3,3,2 at n = 8192 and
+    3,3,3,3 at n = 4096 -- ntt_core.h plan_k) against the oracle and against the 16-coefficient form, bit for bit; ring sizes without
+    the form are refused"""
+    logn = n.bit_length() - 1
+    c = ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20)
+    q = c.q[0]
+    emu.emu_ntt_limb_c.argtypes = [C.c_int, C.c_int, C.c_uint64, u64p, C.c_int, C.c_int]
+    for seed, T in ((7, 64), (8, n // 8)):
+        x = ref.fill_uniform(seed, q, n)
+        x[:4] = [0, q - 1, 1, q - 2]
+        a = x.copy()
+        assert emu.emu_ntt_limb_c(logn, 0, q, a.ctypes.data_as(u64p), T, 8) == 0, emu.emu_last_error()
+        e = x.copy().reshape(1, 1, n)
+        c.transform_to_ntt(e, 0)
+        assert (a == e.reshape(-1)).all()
+        b = x.copy()
+        assert emu.emu_ntt_limb(logn, 0, C.c_uint64(q), b.ctypes.data_as(u64p), n // 16) == 0
+        assert (a == b).all()
+        assert emu.emu_ntt_limb_c(logn, 1, q, a.ctypes.data_as(u64p), T, 8) == 0
+        assert (a == x).all()
+    z = np.zeros(2048, dtype=np.uint64)
+    assert emu.emu_ntt_limb_c(11, 0, q, z.ctypes.data_as(u64p), 64, 8) == -1          # n = 2048 has no latency form
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_ntt_latency_form_61_bit_primes_and_tensor_loader(emu, n):
+    """the latency form in the wide-near range mode (61-bit BEHZ primes) and behind the tensor-on-load staging: equal to the
+    16-coefficient form on the same inputs"""
+    logn = n.bit_length() - 1
+    emu.emu_ntt_limb_c.argtypes = [C.c_int, C.c_int, C.c_uint64, u64p, C.c_int, C.c_int]
+    emu.emu_intt_tensor_limb_c.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, u64p, u64p, C.c_int, C.c_int]
+    def is_prime(x):
+        return all(pow(w, x - 1, x) == 1 for w in (2, 3, 5, 7, 11, 13))
+    # (the first hits of the downward scan from 2^61 are the context's own auxiliary primes: take the eighth, as the test above does)
+    q, found = ((1 << 61) - 1) // (2 * n) * (2 * n) + 1, 0
+    while True:
+        if is_prime(q):
+            found += 1
+            if found == 8:
+                break
+        q -= 2 * n
+    rng = np.random.default_rng(n + 1)
+    for qq in (q, ref.RefContext(n, [56], 0, 20).q[0]):
+        x0, y0, x1, y1 = (rng.integers(0, qq, n, dtype=np.uint64) for _ in range(4))
+        x0[:3] = [0, qq - 1, 1]; y0[:3] = [qq - 1, qq - 1, 1]
+        for inverse in (0, 1):
+            a, b = x0.copy(), x0.copy()
+            assert emu.emu_ntt_limb_c(logn, inverse, qq, a.ctypes.data_as(u64p), n // 8, 8) == 0, emu.emu_last_error()
+            assert emu.emu_ntt_limb_c(logn, inverse, qq, b.ctypes.data_as(u64p), n // 16, 16) == 0
+            assert (a == b).all() and int(a.max()) < qq
+        for cross in (False, True):
+            o8, o16 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+            null = C.POINTER(C.c_uint64)()
+            for out, co in ((o8, 8), (o16, 16)):
+                rc = emu.emu_intt_tensor_limb_c(logn, qq, x0.ctypes.data_as(u64p), y0.ctypes.data_as(u64p), x1.ctypes.data_as(u64p) if cross else null,
+                                                y1.ctypes.data_as(u64p) if cross else null, out.ctypes.data_as(u64p), n // co, co)
+                assert rc == 0, emu.emu_last_error()
+            assert (o8 == o16).all()
+
+
 @pytest.mark.parametrize("n", [64, 256, 1024, 8192, 16384])
 def test_ntt_workgroup_emulation_61_bit_primes(emu, n):
     """61-bit primes (the BEHZ auxiliary base; the oracle's coefficient primes stop at 60 bits): the pass functions in
@@ -224,6 +286,98 @@ def test_ntt_workgroup_emulation_61_bit_primes(emu, n):
     for k in (range(n) if n <= 256 else [int(v) for v in rng.integers(0, n, 8)]):      # negacyclic product by definition
         want = (sum(ai[i] * bi[k - i] for i in range(k + 1)) - sum(ai[i] * bi[k + n - i] for i in range(k + 1, n))) % q
         assert int(prod[k]) == want
+
+
+def test_scheduler_ordering_rules_hold_in_every_state(emu):
+    """round 6: the decision block of Engine::compute_powers is a pure function (apsu_amd/csrc/sched_policy.h, plan_walk) and is held, in
+    EVERY state, to the invariant the project's one real race violated (a pooled buffer kept an older evaluation's `last_use` mark):
+    a buffer whose writers or readers may still be queued on either stream is never written by a stream that has not been ordered
+    behind all of them.  Model: the previous walk of a pooled buffer left writers on the main stream (one-stream and split walks) and / or
+    on the second stream (split and pipelined walks; `high_ready` is recorded behind those); an evaluation, if one read the buffer, runs on
+    the main stream behind ALL its writers and records `last_use` behind itself."""
+    ONE, SPLIT, PIPE = 0, 1, 2
+    seen = {ONE: 0, SPLIT: 0, PIPE: 0}
+    import itertools
+    for (recycled, prev, evaluated, done, split_ok, prof_on, split_mode, pipe_cp, force_pipe, inputs_ready, on_device, busy) in itertools.product(
+            (0, 1), (ONE, SPLIT, PIPE), (0, 1), (0, 1), (0, 1), (0, 1), (-1, 0, 1), (0, 1), (0, 1), (0, 1), (0, 1), (0, 1)):
+        if not recycled and (prev != ONE or evaluated or done):
+            continue                                              # a fresh buffer has no history
+        if done and not evaluated:
+            continue
+        if force_pipe and not pipe_cp:
+            continue                                              # mode 3 implies mode 1's switch (apsu_he_set_query_overlap)
+        if pipe_cp and not inputs_ready:
+            continue                                              # modes 1 and 3 carry the caller's promise
+        high_async = 1 if (recycled and prev != ONE) else 0
+        bits = (recycled | evaluated << 1 | done << 2 | high_async << 3 | split_ok << 4 | prof_on << 5 | pipe_cp << 6 | force_pipe << 7 |
+                inputs_ready << 8 | on_device << 9 | busy << 10)
+        r = emu.emu_plan_walk(bits, split_mode)
+        walk, main_hr, side_lu, side_main, consumes = r & 3, bool(r & 4), bool(r & 8), bool(r & 16), bool(r & 32)
+        seen[walk] += 1
+        state = dict(recycled=recycled, prev=prev, evaluated=evaluated, done=done, split_ok=split_ok, prof_on=prof_on, split_mode=split_mode,
+                     pipe_cp=pipe_cp, force_pipe=force_pipe, inputs_ready=inputs_ready, on_device=on_device, busy=busy, plan=r)
+        # what may still be queued on the buffer
+        pending = set()
+        if recycled:
+            if evaluated:
+                if not done:
+                    pending.add("reader@main")                    # (its writers are all in front of it)
+            else:
+                if prev in (ONE, SPLIT):
+                    pending.add("writer@main")
+                if prev in (SPLIT, PIPE):
+                    pending.add("writer@side")
+        writers = {ONE: ["main"], SPLIT: ["main", "side"], PIPE: ["side"]}[walk]
+        for x in writers:
+            for a in pending:
+                kind, y = a.split("@")
+                if x == y:
+                    continue                                      # stream order
+                if x == "main":                                   # the second stream's writers: only high_ready orders the main stream behind them
+                    assert main_hr, state
+                else:                                             # main-stream writers / readers in front of the second stream
+                    covered = side_main or (side_lu and evaluated)   # last_use lies behind the evaluation, which lies behind every writer
+                    assert covered, state
+        # the walks themselves
+        if walk != ONE:
+            assert split_ok and not prof_on and split_mode != 0, state
+        if walk == PIPE:
+            assert pipe_cp and inputs_ready and on_device and (busy or force_pipe), state
+            assert (not recycled) or evaluated, state             # never into a buffer whose reader left no mark
+            assert done or not recycled or force_pipe, state      # ... and, unless forced, only into an idle one
+        if not recycled:
+            assert not main_hr and not side_lu, state             # nothing to wait for on a fresh buffer
+        if side_lu:
+            assert evaluated, state                               # a mark is only waited for when an evaluation left it
+        assert consumes, state
+    assert all(v > 0 for v in seen.values()), seen
+    # the check has teeth: round 5's bug in this model's terms -- the engine BELIEVES a mark (last_use_set, done) on a buffer that was
+    # re-written by a split walk and never evaluated since; the plan then orders the second stream behind nothing that covers the
+    # main stream's pending writers
+    r = emu.emu_plan_walk(1 | 1 << 1 | 1 << 2 | 1 << 3 | 1 << 4 | 1 << 8 | 1 << 9, -1)
+    assert (r & 3) == SPLIT and not (r & 16), r                   # second stream does not wait for the main stream ...
+    assert not ((r & 16) or ((r & 8) and False))                  # ... and the mark it waits for is not behind those writers: a violation
+    # (Engine::compute_powers therefore consumes last_use_set on every walk and only eval_bundles sets it: consumes_last_use above)
+
+
+def test_scheduler_pool_pick_rule(emu):
+    """sched_policy.h, pick_pooled_buffer, against its statement: without the caller's overlap promise the first pooled buffer that fits;
+    with it the first fitting one whose reader is done or that carries no mark, else -- three fitting ones all busy -- the oldest, else a
+    new buffer (-1)"""
+    import itertools
+    states = [0, 1, 3, 7, 2, 6]                                   # bit 0 fits, 1 last_use_set, 2 last_use_done (done implies set)
+    for count in range(0, 5):
+        for pool in itertools.product(states, repeat=count):
+            buf = (C.c_ubyte * max(1, count))(*pool)
+            fitting = [i for i, e in enumerate(pool) if e & 1]
+            for ready in (0, 1):
+                got = emu.emu_pick_pooled_buffer(buf, count, ready)
+                if not ready:
+                    want = fitting[0] if fitting else -1
+                else:
+                    free = [i for i in fitting if not (pool[i] & 2) or (pool[i] & 4)]
+                    want = free[0] if free else (fitting[0] if len(fitting) >= 3 else -1)
+                assert got == want, (pool, ready, got, want)
 
 
 def test_c_abi_exports_every_declared_symbol():
