@@ -215,9 +215,10 @@ void launch_pack_rows(const DevLevel *lv, int L, const u64 *dense, void *packed,
 void launch_unpack_rows(const DevLevel *lv, int L, const void *packed, size_t slot_bytes, u64 *dense, size_t n, size_t slots, hipStream_t st);
 // Fused tail of eval / eval_patstock (bin_bundle.cpp:159-171, 345-357): (c0,c1) (+ optional exact addends) + Delta*a0 +
 // Delta*mask, drop limbs down to the last level, clear the irrelevant bits, write the 2n-word result.
-struct EpiJob { const u64 *ct; const u64 *add1; const u64 *add2; const u64 *a0; const u64 *mask; u64 *out; };
+struct EpiJob { const u64 *ct; const u64 *add1; const u64 *add2; const u64 *a0; const u64 *mask; u64 *out;
+                const u64 *ks_acc = nullptr; };   // round 6: RAW key-switch sums [2][L+1][n] whose mod-down the epilogue performs (launch_eval_epilogue with a key)
 void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, size_t ct_poly_stride, int clear_bits, size_t n,
-                          int njobs, hipStream_t st);
+                          int njobs, hipStream_t st, const DevKey *key = nullptr);
 // i = 0 block of eval_patstock when exactly one limb is dropped (bin_bundle.cpp:314-324, note N1):
 // acc[p][m] += (S[p][m] + terms*half - sum_t ((V[t][p] + half) mod q_last)) * q_last^-1  mod q_m
 struct I0Job { const u64 *s; const u64 *v; u64 *acc; int terms; int store; };   // s:[2][L-1][n] v:[terms][2][n] acc:[2][L-1][n] (store: = instead of +=)

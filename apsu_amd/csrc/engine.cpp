@@ -162,6 +162,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         //   APSU_HE_EVAL_PER_TERM=1    eval_patstock's products finished one by one (the fallback of the summed finish)
         //   APSU_HE_MAC_KARA=0/1       three-product k_mac forced off / on (default: by chain length)
         //   APSU_HE_SEED_EXPAND_HOST=1 seeded objects expanded by the host codec (the fallback of the device sampler)
+        //   APSU_HE_FUSE_TAIL=0        eval_patstock's last mod-down as its own launch instead of inside the epilogue kernel (round 6)
         //   APSU_HE_NTT_LATENCY_LIMBS=n transform launches of at most n limbs take the latency form (8 coefficients per lane; round 6);
         //                              0 = always the throughput form.  Default: the measured crossover per ring size and kind of launch.
         if (const char *v = std::getenv("APSU_HE_SPLIT")) two_stream_default_ = std::atoi(v) != 0 ? 1 : 0;
@@ -180,6 +181,7 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // that gives a CU at most one limb hides that limb's LDS turnarounds and table loads behind three other waves per SIMD.
         // Crossovers: kernels.hip, ntt_use_latency_form (tools/microbench/ntt_forms.hip, profiles/r06_ntt_forms_n8192.txt / _n4096.txt).
         ntt_latency_limbs_ = NTT_FORM_AUTO;
+        if (const char *v = std::getenv("APSU_HE_FUSE_TAIL")) fuse_tail_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_NTT_LATENCY_LIMBS")) ntt_latency_limbs_ = std::strtoull(v, nullptr, 10);
     }
     // level constants
@@ -883,7 +885,7 @@ void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool 
     launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_, ntt_latency_limbs_);
 }
 
-bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out, int n_ext)
+bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out, int n_ext, u64 **defer_moddown)
 {
     const int L = chain_idx + 1;
     const size_t n = hp_.n;
@@ -910,6 +912,10 @@ bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKey
     //  2 % SLOWER on the whole query -- six operand streams per output and tdec read twice; tools/microbench/intt_ks_experiment.hip)
     { PROFW(P_KEYSWITCH, (size_t)batch * n * ((size_t)L * (L + 1) + 2 * (L + 1))); launch_ks_inner(dkey(), L, tdec, rk.data.u(), acc, n, batch, st_); }
     d_ntt(acc, (size_t)batch * 2 * (L + 1), amap, L + 1, true);
+    if (defer_moddown) {
+        *defer_moddown = raw ? acc : nullptr;
+        if (raw) return false;                                   // the caller's epilogue kernel takes it from here
+    }
     const bool fuse_ext = ext_out && n_ext > 0 && hlevel(chain_idx).L == hlevel(chain_idx).nB && L <= 3;
     { PROFW(P_KEYSWITCH, (size_t)batch * n * (2 * (L + 1) + 4 * L) + (fuse_ext ? (size_t)n_ext * 2 * (hlevel(chain_idx).L + hlevel(chain_idx).nB + 1) * n : 0));
       launch_ks_moddown(dkey(), L, acc, ct3, ct_stride, n, batch, st_, dlevel(chain_idx), fuse_ext ? ext_out : nullptr, fuse_ext ? n_ext : 0, raw); }
@@ -2521,7 +2527,10 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
         { PROF(P_BEHZ_FINISH, 0); launch_behz_finish(dlevel(high), hlevel(high).L, hlevel(high).nB, upload_jobs(fj), false, n, (int)fj.size(), st_); }
         { PROF(P_BEHZ_FINISH, 0); launch_sum_jobs(dlevel(high), (int)Lh, upload_jobs(sj), 3, n, Bs, st_); }
     }
-    d_relinearize(result, 3 * Lh * n, Bs, *rk, high);                                          // :308-310
+    // (round 6: the mod-down of this last key switch is performed by the epilogue kernel below, on the way in: one launch fewer at the
+    //  end of every query, the updated (c0, c1) never go to memory; APSU_HE_FUSE_TAIL=0 keeps the launch)
+    u64 *ks_acc = nullptr;
+    d_relinearize(result, 3 * Lh * n, Bs, *rk, high, nullptr, 0, fuse_tail_ ? &ks_acc : nullptr);   // :308-310
 
     // i = 0 block, reduced to one exact [2][Lh][n] addend per BinBundle
     u64 *i0 = nullptr;
@@ -2554,8 +2563,10 @@ void Engine::ps_run(EvalCall &c, const PsPlan &plan, PsBatch &g)
     std::vector<EpiJob> ej;
     for (int x = 0; x < Bs; x++)
         ej.push_back(EpiJob{ result + (size_t)x * 3 * Lh * n, i0 + (size_t)x * 2 * Lh * n, g.cf + (size_t)x * 2 * Lh * n,
-                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]) });
-    { PROFW(P_MODSWITCH, (size_t)Bs * n * (7 * Lh + 4)); launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_); }
+                             bundles[c0 + g.ids[x]]->a0.u(), mask_ptr(g.ids[x]), res_ptr(g.ids[x]),
+                             ks_acc ? ks_acc + (size_t)x * 2 * (Lh + 1) * n : nullptr });
+    { PROFW(P_MODSWITCH, (size_t)Bs * n * (7 * Lh + 4 + (ks_acc ? 2 * (Lh + 1) : 0)));
+      launch_eval_epilogue(dlevel(0), high, upload_jobs(ej), Lh * n, hp_.irrelevant_bit_count, n, Bs, st_, ks_acc ? dkey() : nullptr); }
 
 }
 

@@ -258,7 +258,12 @@ private:
     // BFV multiply of `njobs` (a, b) pairs given as ext-NTT operands; writes size-3 results
     // ext_out / n_ext: the first n_ext ciphertexts also get their BEHZ extension written to ext_out[b][2][E][n] (fused into
     // the mod-down; returns false when the level has no unrolled extension and the caller must run launch_behz_ext itself)
-    bool d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out = nullptr, int n_ext = 0);
+    // defer_moddown (round 6): the caller's next kernel performs the rounding mod-down itself (k_eval_epilogue<true>): the RAW inverse transforms
+    // of the key-switch sums are left at *defer_moddown ([batch][2][L+1][n], workspace) and ct3 is NOT updated.  Refused (nullptr stored) when the
+    // level has no RAW mod-down constants (L > 4).
+    bool d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out = nullptr, int n_ext = 0,
+                       u64 **defer_moddown = nullptr);
+    bool fuse_tail_ = true;           // eval_patstock: the last key switch's mod-down inside the epilogue kernel (APSU_HE_FUSE_TAIL=0: its own launch)
     void check_level(int chain_idx) const;
     // BEHZ steps 4-8 for operands given as ext-NTT polynomials [size][E][n]; out: [sa + sb - 1][L][n], coefficient form
     void d_multiply_sized(const u64 *ea, int sa, const u64 *eb, int sb, u64 *out, int chain_idx);

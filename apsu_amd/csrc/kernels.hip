@@ -1934,8 +1934,12 @@ __device__ __forceinline__ u64 plain_fix(const DevLevel *__restrict__ lv, u64 m)
     return fix;
 }
 
+// MD (round 6): the key switch's mod-down (k_ks_moddown<., false, RAW>, App. B10) runs HERE, on the way in: job.ks_acc = the RAW inverse
+// transforms of the key-switch sums [2][L+1][n]; (c0, c1) + the rounded quotient never goes to memory and the mod-down launch in front
+// of this kernel is gone (one launch and one boundary per query: -6 us on the N = 8 shard's critical path, profiles/r06_ab_fused_tail.txt).
+template <bool MD>
 __global__ __launch_bounds__(EW_T) void k_eval_epilogue(const DevLevel *__restrict__ levels, int lvl, const EpiJob *__restrict__ jobs,
-                                                        size_t ct_poly_stride, u64 clear_mask, size_t n)
+                                                        size_t ct_poly_stride, u64 clear_mask, size_t n, const DevKey *__restrict__ key)
 {
     const size_t k = (size_t)blockIdx.x * EW_T + threadIdx.x;
     if (k >= n) return;
@@ -1944,16 +1948,33 @@ __global__ __launch_bounds__(EW_T) void k_eval_epilogue(const DevLevel *__restri
     const int L = lvl + 1;
     u64 v[2][DMAXL];
 #pragma unroll
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < 2; p++) {
+        u64 tl = 0;
+        const u64 *a = nullptr;
+        if constexpr (MD) {                                      // the special limb of this polynomial's key-switch sum, twisted and rounded
+            a = job.ks_acc + (size_t)p * (L + 1) * n;
+            const Mod pm = key->q[key->K - 1];
+            const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(key->p_tw + k));
+            tl = barrett64(mul_shoup(a[(size_t)L * n + k], tw[0], tw[1], pm.q) + key->p_half, pm);
+        }
 #pragma unroll
         for (int j = 0; j < DMAXL; j++)
             if (j < L) {
                 const u64 q = lv->q[j].q;
                 u64 x = job.ct[p * ct_poly_stride + (size_t)j * n + k];
+                if constexpr (MD) {                              // exactly k_ks_moddown's RAW arithmetic
+                    const Mod m = key->q[j];
+                    const u64 tk = submod(barrett64(tl, m), key->p_half_mod[j], m.q);
+                    const u64x2 tw = ldg16(reinterpret_cast<const u64 *>(key->md_tw[j] + k));
+                    const u64 u = mul_shoup_lazy(a[(size_t)j * n + k], tw[0], tw[1], m.q);
+                    const u64 w = mul_shoup_lazy(tk, key->inv_p[j].w, key->inv_p[j].wq, m.q);
+                    x = addmod(x, csub(csub(u + (m.q << 1) - w, m.q << 1), m.q), m.q);
+                }
                 if (job.add1) x = addmod(x, job.add1[((size_t)p * L + j) * n + k], q);
                 if (job.add2) x = addmod(x, job.add2[((size_t)p * L + j) * n + k], q);
                 v[p][j] = x;
             }
+    }
     {   // c0 += round(a0 * Q / t) + round(mask * Q / t)
         const u64 m0 = job.a0[k], m1 = job.mask[k];
         const u64 f0 = plain_fix(lv, m0), f1 = plain_fix(lv, m1);
@@ -1986,12 +2007,14 @@ __global__ __launch_bounds__(EW_T) void k_eval_epilogue(const DevLevel *__restri
     job.out[n + k] = v[1][0] & clear_mask;
 }
 
+// key != nullptr: every job carries ks_acc and the key switch's mod-down is part of this launch (k_eval_epilogue<true>)
 void launch_eval_epilogue(const DevLevel *levels, int lvl, const EpiJob *jobs, size_t ct_poly_stride, int clear_bits, size_t n,
-                          int njobs, hipStream_t st)
+                          int njobs, hipStream_t st, const DevKey *key)
 {
     if (!njobs) return;
     const u64 mask = clear_bits > 0 ? ~(((u64)1 << clear_bits) - 1) : ~(u64)0;
-    hipLaunchKernelGGL(k_eval_epilogue, ew_grid(n, njobs), dim3(EW_T), 0, st, levels, lvl, jobs, ct_poly_stride, mask, n);
+    if (key) hipLaunchKernelGGL(k_eval_epilogue<true>, ew_grid(n, njobs), dim3(EW_T), 0, st, levels, lvl, jobs, ct_poly_stride, mask, n, key);
+    else hipLaunchKernelGGL(k_eval_epilogue<false>, ew_grid(n, njobs), dim3(EW_T), 0, st, levels, lvl, jobs, ct_poly_stride, mask, n, key);
     KERNEL_CHECK();
 }
 

@@ -437,7 +437,8 @@ def test_fallback_paths_match():
     # (APSU_HE_PACKED_ROWS=0); a 1 MiB initial arena exercises overflow -> grow -> retry (APSU_HE_ARENA_BYTES), and a 1-byte workspace
     # budget evaluates one BinBundle per chunk (APSU_HE_EVAL_WS_BYTES); round 6: every transform launch in the throughput form (16
     # coefficients per lane, APSU_HE_NTT_LATENCY_LIMBS=0) / every one in the latency form (8 per lane; by default the launch size
-    # decides).  (APSU_HE_SEED_EXPAND_HOST: tests/test_gpu_wire_query.py.)
+    # decides); eval_patstock's last mod-down as its own launch instead of inside the epilogue kernel (APSU_HE_FUSE_TAIL=0).
+    # (APSU_HE_SEED_EXPAND_HOST: tests/test_gpu_wire_query.py.)
     # All must give the same bits; scenarios run in child processes.
     import subprocess, sys, os
     head = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu_path as t\n"
@@ -449,7 +450,7 @@ def test_fallback_paths_match():
                            ({"APSU_HE_SPLIT": "0", "APSU_HE_MAC_KARA": "1"}, small + big),
                            ({"APSU_HE_SPLIT": "1", "APSU_HE_EVAL_SIDE": "0", "APSU_HE_MAC_KARA": "0"}, small + big),
                            ({"APSU_HE_PACKED_ROWS": "0"}, small + big),
-                           ({"APSU_HE_NTT_LATENCY_LIMBS": "0"}, small + big),
+                           ({"APSU_HE_NTT_LATENCY_LIMBS": "0", "APSU_HE_FUSE_TAIL": "0"}, small + big),
                            ({"APSU_HE_NTT_LATENCY_LIMBS": "100000000"}, small + big),
                            ({"APSU_HE_ARENA_BYTES": "1048576", "APSU_HE_EVAL_WS_BYTES": "1"}, small)):
         env = dict(os.environ, **switches)

@@ -56,6 +56,30 @@ if [ "$part" = pmc ]; then
   python3 tools/mac_pmc_summary.py $O/pmc "k_intt_tensor<13" > $O/ntt_tensor_pmc_inpath.txt 2>&1
   tail -30 $O/mac_pmc_ta_td.txt
 fi
+if [ "$part" = pmc_ta ]; then
+  # the TA block holds TWO counters per pass on gfx950: three (pass 1 of `pmc`) are refused like round 5's five ("error code 38")
+  i=7
+  for pass in \
+    "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
+    "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUSY_avr GRBM_GUI_ACTIVE" ; do
+    i=$((i+1))
+    d=$O/pmc/p$(printf %02d $i)
+    mkdir -p $d
+    if ! timeout -k 10 240 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -- python3 tools/mac_prof_one.py 3 > $d.log 2>&1; then
+      echo "pass $i FAILED ($pass): $(grep -v '^W\|^I\|^    @' $d.log | tail -2 | tr '\n' ' ')"
+    else
+      echo "pass $i ok"
+    fi
+  done
+fi
+if [ "$part" = ab ]; then
+  # in-process A/B of the transform forms: every launch in the 16-coefficient form against the default selection
+  for spec in "16M-4096 1" "16M-4096 8" "16M-4096 4" "1M-1024-com 1" "256M-4096 8"; do
+    set -- $spec
+    timeout -k 10 500 python3 tools/ab_compare.py --a APSU_HE_NTT_LATENCY_LIMBS=0 --b "" --config $1 --world $2 >> $O/ab_ntt_forms_$tag.txt 2>&1 || { echo "ab $spec failed"; tail -3 $O/ab_ntt_forms_$tag.txt; exit 1; }
+  done
+  grep -v amdgpu.ids $O/ab_ntt_forms_$tag.txt
+fi
 if [ "$part" = place ]; then
   cd tools/microbench/_bin || exit 1
   OO=../../../$O/place
