@@ -2579,7 +2579,7 @@ void Engine::eval_bundles(const Bundle *const *bundles, int count, const Powers 
     if (count <= 0) return;
     const size_t n = hp_.n;
     job_seq_base_ = 256;                                     // job-cache slots 256..: eval_bundles
-    if (pw.low_async && pw.high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // (APSU_HE_PIPE_CP: every power comes from the second stream)
+    if (pw.low_async && pw.high_ready) HIP_CHECK(hipStreamWaitEvent(st_, pw.high_ready, 0));   // (pipelined walk: every power comes from the second stream)
     // the powers' last reader (see Powers::last_use): marked on the main stream when this call leaves, also by an exception --
     // kernels that read the powers may have been queued by then
     struct LastUse {

@@ -391,12 +391,13 @@ def main():
             "note": "achieved / frac count 16 n bytes per limb like a plain transform; *_actual_bytes count the operand limbs the load "
                     "really reads (served by L2 / Infinity Cache, an upper bound when the launch also carries plain limbs)"}
         result["roofline"]["note"] = ("the transform is instruction-issue bound, not HBM-bound: 9 integer multiplies + 64-bit add-class instructions "
-                                      "per butterfly at 4.6-5.4 cycles each (profiles/r01_intmul_microbench.txt); round 4: 18.7 (forward, its cross "
-                                      "products as one v_mad_u64_u32 chain) / 21.6 (inverse with twist) VALU instructions per butterfly, VALU busy "
-                                      "83 / 80 % at 2.05 GHz (profiles/r04_ntt_pmc.txt), HBM traffic 1.04x algorithmic; the forward butterfly alone in "
-                                      "registers would reach 6.3 TB/s = 0.79 (profiles/r04_bfly_mad_chain.txt). "
-                                      "In-path launches are mostly Infinity-Cache resident and 13 of 15 are below 2 000 limbs (launch-round bound); "
-                                      "see ntt_stream for >= 1 GiB batches")
+                                      "per butterfly at 4.6-5.4 cycles each (profiles/r01_intmul_microbench.txt); round 6 counters of the query's own "
+                                      "launches (profiles/r06_ntt_pmc.txt): forward 6 840 limbs 21.1 VALU wave-instructions per butterfly, VALU busy 80.5 % "
+                                      "at 2.13 GHz; staged RAW inverse 6 792 limbs 18.1, 77.3 % at 2.05 GHz; tensor-on-load inverse 25.2, 70.6 %; HBM traffic "
+                                      "1.04x algorithmic (profiles/r05_ntt_traffic.json); the forward butterfly alone in registers would reach 6.3 TB/s = 0.79 "
+                                      "(profiles/r04_bfly_mad_chain.txt). In-path launches are mostly Infinity-Cache resident and 13 of 15 are below 2 000 limbs "
+                                      "(launch-round bound); launches of <= 256 limbs take the 8-coefficient-per-lane form since round 6 "
+                                      "(profiles/r06_ntt_forms_n8192.txt: -3 ... -16 % there); see ntt_stream for >= 1 GiB batches")
         result["roofline"]["all_transforms"] = {"achieved": round(a_ach, 1), "frac": round(a_ach / HBM_PEAK_GBS, 4),
                                                 "limb_transforms_per_step": a_li / steps, "ms_per_step": round(a_ms / steps, 4)}
         # the same figure over the two untimed steps that carry events around EVERY launch (cross-check of the sample)

@@ -13,6 +13,11 @@
 // Nothing else of the reference changes: the query is still deserialised by SEAL, masks are still drawn by the block at
 // receiver_osn.cpp:217-284, results still leave as ResultPackages through send_rp_fun.
 //
+// This file reproduces statements of the reference ON PURPOSE: it is a patch to receiver_osn.cpp / bin_bundle.cpp / receiver_db.cpp, and the
+// lines around each replaced Evaluator call are repeated so that a maintainer can paste the bodies over the originals (about half of its code
+// lines also occur in receiver_{osn,ddh}.cpp).  It is never compiled into the engine and never runs on the GPU box; if it is published outside
+// this tree it falls under the reference's licence, not the engine's.
+//
 // This file cannot be compiled in the engine's repository (no SEAL, no APSU headers).  tests/test_integration_syntax.py runs
 // `g++ -fsyntax-only` on it against forward declarations the test writes from the signatures cited above; that check shows the
 // file is well-formed and matches include/apsu_he.h -- it pins nothing about SEAL.

@@ -189,8 +189,11 @@ def test_queued_queries_are_isolated(world, monkeypatch, mode, side, two_stream,
     if mode == 3:
         assert piped == K, "forced mode: every ComputePowers takes the pipelined walk"
     elif mode == 1 and two_stream != 0:
-        # (measured: 8 of 12 on a context's first, cold pass -- allocations, job-table uploads --, 11 of 12 from then on, at both sizes)
-        assert piped >= K // 2, "an evaluation of a gigabyte of BinBundles outlasts the host's queueing of the next query"
+        # How MANY walks the shipped policy pipelines depends on the host's speed relative to the device's (measured: 8 of 12 on a context's
+        # first, cold pass -- allocations, job-table uploads --, 11 of 12 from then on, at both sizes): a scheduling heuristic, not a
+        # correctness property -- a slower or loaded host, a faster GPU or a profiler may lower it with the engine fully correct (round-5
+        # advisor).  The count is bounded here and reported by bench.py (`pipelined_steps`); mode 3 above pins the walk itself.
+        assert 0 <= piped <= K
     else:
         assert piped == 0
     for k in range(K):
