@@ -98,6 +98,28 @@ if [ "$part" = place ]; then
   tail -40 $O/mac_placement_by_instance.txt
   find $O/place -name "*.json" -size +20M -delete
 fi
+if [ "$part" = place2 ]; then
+  # second look at the placement effect, on a box where copies differ: where do the memory-side reads go (local DRAM / GMI / IO), per TCC instance
+  cd tools/microbench/_bin || exit 1
+  OO=../../../$O/place2
+  mkdir -p $OO
+  i=0
+  for pass in \
+    "TCC_EA0_RDREQ TCC_EA0_RDREQ_LEVEL GRBM_GUI_ACTIVE" \
+    "TCC_EA0_RDREQ_DRAM TCC_EA0_RDREQ_DRAM_32B TCC_EA0_RDREQ_GMI_32B TCC_EA0_RDREQ_IO_32B GRBM_GUI_ACTIVE" \
+    "TCC_EA0_RDREQ TCC_EA0_RDREQ_LEVEL GRBM_GUI_ACTIVE" \
+    "TCC_EA0_RDREQ_DRAM TCC_EA0_RDREQ_DRAM_32B TCC_EA0_RDREQ_GMI_32B TCC_EA0_RDREQ_IO_32B GRBM_GUI_ACTIVE" \
+    "TCC_HIT TCC_MISS TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_EA0_RDREQ_GMI_CREDIT_STALL GRBM_GUI_ACTIVE" \
+    "TCC_HIT TCC_MISS TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_EA0_RDREQ_GMI_CREDIT_STALL GRBM_GUI_ACTIVE" ; do
+    i=$((i+1)); d=$OO/p$i; mkdir -p $d
+    PLACEMENT=4 timeout -k 10 240 rocprofv3 --kernel-trace --pmc $pass --output-format csv json -d $d -- ./macbench_place 1 > $d.log 2>&1 || echo "pass $i failed: $(grep -v '^W\|^I\|^    @' $d.log | tail -2 | tr '\n' ' ')"
+    grep "^pass 2" $d.log
+  done
+  cd ../../..
+  python3 tools/pmc_by_instance.py $O/place2 "k_mac<" 32 > $O/mac_placement2_by_instance.txt 2>&1
+  find $O/place2 -name "*.json" -delete
+  grep -c dispatch $O/mac_placement2_by_instance.txt
+fi
 if [ "$part" = bench ]; then
   bash tools/collect_profiles.sh r06 || exit 1
   APSU_HE_SPLIT=0 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_one_stream -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-io --no-profile > $O/trace_one_stream.log 2>&1 || exit 1

@@ -18,6 +18,22 @@ __global__ void k_fillrand(u64* p, size_t words, u64 mask) {
         u64 z = i * 0x9e3779b97f4a7c15ULL + 0x1234; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; p[i] = (z ^ (z >> 31)) & mask; }
 }
 
+// Round 6, PLACEMENT mode with PROBE=1: what does ADDRESS TRANSLATION cost on this copy of the database?  65 536 lanes each read one 8-byte word
+// from a different page per iteration (page = `stride` bytes; the next page a large odd step further), the addresses independent of the data:
+// nothing is reused, every access is a new line and, at 4 KiB ... 2 MiB strides, a new page -- the time per iteration is the translation
+// path's (UTCL1 miss -> UTCL2 -> page walk), which depends on how large the fragments are the driver mapped this copy with.
+__global__ __launch_bounds__(256) void k_tlb_probe(const u64 *__restrict__ base, size_t npages, size_t stride_words, int iters, u64 *__restrict__ sink)
+{
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t p = (gid * 7919) % npages;
+    u64 acc = 0;
+    for (int i = 0; i < iters; i++) {
+        acc += __builtin_nontemporal_load(base + p * stride_words + (gid & 7));
+        p += 104729; if (p >= npages) p -= npages; if (p >= npages) p %= npages;
+    }
+    if (acc == 0x123456789abcdefULL) sink[0] = acc;
+}
+
 // ---- bisect kernels: same loads as k_mac<2,2>, different bodies
 template <int MODE>
 __global__ __launch_bounds__(256) void k_morph(const MacJob *__restrict__ jobs, size_t n, u64 *sink)
@@ -150,6 +166,19 @@ int main(int argc, char** argv) {
                     std::sort(t.begin(), t.end());
                     printf("pass %d  copy %zu at %p  skew %5zu words: median %.3f ms (%.0f GB/s)\n", pass, c, (void *)dbs[c], sk, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9);
                     CHECK(hipFree(djc));
+                    if (getenv("PROBE") && pass == 2 && sk == 0) {
+                        for (size_t stride : { (size_t)4096, (size_t)65536, (size_t)(2u << 20) }) {
+                            const size_t npages = words * 8 / stride;
+                            std::vector<float> tp;
+                            for (int rep = 0; rep < 7; rep++) {
+                                CHECK(hipEventRecord(e0)); k_tlb_probe<<<256, 256>>>(dbs[c], npages, stride / 8, 64, out); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) tp.push_back(ms);
+                            }
+                            std::sort(tp.begin(), tp.end());
+                            printf("        probe copy %zu: one word per %7zu-byte page, 65536 lanes x 64 pages: median %.1f us (%.1f ns per wave-access)\n", c, stride, tp[tp.size() / 2] * 1e3,
+                                   tp[tp.size() / 2] * 1e6 / 64.0);
+                        }
+                    }
                 }
     }
     if (getenv("TILED")) {
