@@ -1649,7 +1649,16 @@ __global__ __launch_bounds__(EW_T, APSU_MAC_MINWAVES) void k_mac(const DevLevel 
             for (int p = 0; p < 2; p++) s00[g][c][p] = sx[g][c][p] = s11[g][c][p] = 0;
 
     struct Term { u64 c[2][C]; u64 a[G][C]; };                  // powers (poly, coef) and plaintext values (stream, coef)
+#ifdef APSU_MAC_TILED_EXPERIMENT
+    // macbench ROTATE (round 6): every workgroup walks its chain from another starting term (the sum is exact in any order), so that the
+    // workgroups resident together do not all read offset t x row-stride of their streams at the same time: -0.9 % stand-alone, does
+    // not remove the placement effect (profiles/r06_mac_rotate.txt); not in the library
+    const u32 rot_ = jp->pad == 3 ? (u32)((b_job * 7u + b_limb * 13u + b_x * 5u) % job.cnt) : 0u;
+#endif
     auto load_term = [&](u32 i, Term &t) {
+#ifdef APSU_MAC_TILED_EXPERIMENT
+        i += rot_; if (i >= job.cnt) i -= job.cnt;
+#endif
         if (C == 2) {
             const u64x2 v0 = ldg16(p0 + (size_t)i * job.pw_stride), v1 = ldg16(p1 + (size_t)i * job.pw_stride);
             t.c[0][0] = v0[0]; t.c[0][C - 1] = v0[1]; t.c[1][0] = v1[0]; t.c[1][C - 1] = v1[1];

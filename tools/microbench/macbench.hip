@@ -165,6 +165,18 @@ int main(int argc, char** argv) {
                     }
                     std::sort(t.begin(), t.end());
                     printf("pass %d  copy %zu at %p  skew %5zu words: median %.3f ms (%.0f GB/s)\n", pass, c, (void *)dbs[c], sk, t[t.size() / 2], words * 8 / (t[t.size() / 2] * 1e-3) / 1e9);
+                    if (getenv("ROTATE")) {                          // the same copy, every workgroup starting at another term (MacJob::pad = 3)
+                        for (auto &x : jc) x.pad = 3;
+                        CHECK(hipMemcpy(djc, jc.data(), jc.size() * sizeof(MacJob), hipMemcpyHostToDevice));
+                        std::vector<float> tr;
+                        for (int rep = 0; rep < 8; rep++) {
+                            CHECK(hipEventRecord(e0)); launch_mac(lv, 3, djc, n, (int)jc.size(), 0); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) tr.push_back(ms);
+                        }
+                        std::sort(tr.begin(), tr.end());
+                        printf("        rotated start terms on copy %zu: median %.3f ms (%.0f GB/s)  %+.1f %%\n", c, tr[tr.size() / 2], words * 8 / (tr[tr.size() / 2] * 1e-3) / 1e9,
+                               100.0 * (tr[tr.size() / 2] / t[t.size() / 2] - 1));
+                    }
                     CHECK(hipFree(djc));
                     if (getenv("PROBE") && pass == 2 && sk == 0) {
                         for (size_t stride : { (size_t)4096, (size_t)65536, (size_t)(2u << 20) }) {
