@@ -119,8 +119,10 @@ constexpr int NTT_MAP_RAW = 1 << 30, NTT_MAP_MASK = NTT_MAP_RAW - 1;
 // waves per limb; ntt_core.h plan_k) where the ring size has one (n = 8192, 4096); 0 = always the throughput form; NTT_FORM_AUTO = the
 // measured crossover per ring size and kind of launch (kernels.hip, ntt_use_latency_form).  Same bits.
 constexpr size_t NTT_FORM_AUTO = ~(size_t)0;
+// narrow_only: the caller knows that every modulus of the launch is narrow (ntt_is_narrow: the data primes of every shipped parameter set) --
+// large forward launches then take the 8-coefficient form compiled for 8 waves per SIMD (NTT_FORM_AUTO only).
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap,
-                int period, hipStream_t st, size_t latency_limbs = 0);
+                int period, hipStream_t st, size_t latency_limbs = 0, bool narrow_only = false);
 // forward NTT of limbs gathered from src[g] (reduced into the table's modulus on load), written to data + g*n.
 // nored: the caller has checked ntt_gather_nored_ok for every (source, target) pair of the launch: no reduction on load
 void launch_ntt_gather(int logn, const u64 *const *src, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,

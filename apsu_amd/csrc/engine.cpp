@@ -181,6 +181,8 @@ Engine::Engine(const HeParams &hp, const PSUParams *psu, int device) : hp_(hp), 
         // that gives a CU at most one limb hides that limb's LDS turnarounds and table loads behind three other waves per SIMD.
         // Crossovers: kernels.hip, ntt_use_latency_form (tools/microbench/ntt_forms.hip, profiles/r06_ntt_forms_n8192.txt / _n4096.txt).
         ntt_latency_limbs_ = NTT_FORM_AUTO;
+        data_primes_narrow_ = true;
+        for (int j = 0; j < hp_.K; j++) data_primes_narrow_ = data_primes_narrow_ && ntt_is_narrow(hp_.key_q[j], hp_.logn);
         if (const char *v = std::getenv("APSU_HE_FUSE_TAIL")) fuse_tail_ = std::atoi(v) != 0;
         if (const char *v = std::getenv("APSU_HE_NTT_LATENCY_LIMBS")) ntt_latency_limbs_ = std::strtoull(v, nullptr, 10);
     }
@@ -882,7 +884,9 @@ bool Engine::mac_kara(int lvl, uint32_t mean_cnt) const
 void Engine::d_ntt(u64 *data, size_t count, const int *modmap, int period, bool inverse)
 {
     PROF(inverse ? P_NTT_INV : P_NTT_FWD, count);
-    launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_, ntt_latency_limbs_);
+    // (launches over the data primes alone -- map_ct() and its suffixes -- may take the narrow-moduli build, kernels.hip launch_ntt)
+    const bool narrow_only = data_primes_narrow_ && modmap >= map_ct() && (modmap - map_ct()) + period <= hp_.K;
+    launch_ntt(hp_.logn, inverse, data, count, tabs(), modmap, period, st_, ntt_latency_limbs_, narrow_only);
 }
 
 bool Engine::d_relinearize(u64 *ct3, size_t ct_stride, int batch, const RelinKeys &rk, int chain_idx, u64 *ext_out, int n_ext, u64 **defer_moddown)

@@ -302,6 +302,7 @@ private:
     bool inputs_ready_ = false;       // the caller's promise behind apsu_he_set_query_overlap: the second stream then waits for the last reader of its powers buffer only
     bool pipe_cp_ = true;             // queued queries: the whole ComputePowers on the second stream, next to the evaluation in front (set_query_overlap 1 / 3)
     bool force_pipe_ = false;         // ... whether or not an evaluation is still running (set_query_overlap 3)
+    bool data_primes_narrow_ = false; // every key prime runs the transform without range control (ntt_is_narrow)
     size_t ntt_latency_limbs_ = 0;    // transform launches of at most this many limbs take the 8-coefficient-per-lane form (APSU_HE_NTT_LATENCY_LIMBS)
     bool eval_side_ = true;           // cf sums + i = 0 finish of eval_patstock on a side stream (APSU_HE_EVAL_SIDE=0: on the main stream)
     bool async_results_ = false;      // eval_bundles with device masks + device output returns once the work is queued

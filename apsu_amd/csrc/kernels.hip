@@ -27,8 +27,10 @@ void throw_hip(hipError_t e, const char *file, int line);
 // front (k_ntt_first_stage), the inverse's last stage and twist behind (k_ntt_last_stage), so the inverse halves are always RAW.
 // C: coefficients per lane -- 16 (T = n / 16 threads per limb: the throughput form) or 8 (T = n / 8: the latency form of round 6 for
 // launches that leave CUs idle, ntt_core.h plan_k; chosen by the launch wrappers from the number of limbs, same bits).
-template <int LOGN, bool INV, int T, int C = 16>
-__global__ __launch_bounds__(T, 4) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
+// MINW: waves per SIMD the register budget must admit (8: <= 64 VGPRs, two 1024-thread workgroups per CU at n = 8192 -- large forward launches
+// over narrow moduli only: -4 ... -7 %, tools/microbench/ntt_forms.hip; slower on 61-bit limbs and on every inverse)
+template <int LOGN, bool INV, int T, int C = 16, int MINW = 4>
+__global__ __launch_bounds__(T, MINW) void k_ntt(u64 *__restrict__ data, const NttTable *__restrict__ tabs,
                                            const int *__restrict__ modmap, int period, int split)
 {
     constexpr int N = 1 << LOGN;
@@ -273,9 +275,15 @@ static void launch_ntt_split(bool inverse, const u64 *const *src, u64 *data, siz
 }
 
 void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable *tabs, const int *modmap, int period,
-                hipStream_t st, size_t latency_limbs)
+                hipStream_t st, size_t latency_limbs, bool narrow_only)
 {
     if (!count) return;
+    if (latency_limbs == NTT_FORM_AUTO && logn == 13 && !inverse && narrow_only && count >= 512) {
+        // large forward launches whose moduli are all narrow (the data primes): 8 coefficients per lane at 8 waves per SIMD
+        hipLaunchKernelGGL((k_ntt<13, false, 1024, 8, 8>), dim3((unsigned)count), dim3(1024), 0, st, data, tabs, modmap, period, 0);
+        KERNEL_CHECK();
+        return;
+    }
     if (ntt_use_latency_form(logn, inverse ? NTT_KIND_INVERSE : NTT_KIND_FORWARD, count, latency_limbs)) {   // 8 coefficients per lane
         if (logn == 13) {
             if (inverse) hipLaunchKernelGGL((k_ntt<13, true, 1024, 8>), dim3((unsigned)count), dim3(1024), 0, st, data, tabs, modmap, period, 0);

@@ -161,10 +161,12 @@ def test_golden_ops_on_gpu():
     G.close()
 
 
-@pytest.mark.parametrize("form", ["0", "100000000"])
+@pytest.mark.parametrize("form", ["0", "100000000", None])
 def test_ntt_large_batch_streams_correctly(form, monkeypatch):
-    """>= 256 MiB of distinct limbs through one launch (every workgroup index, every limb position), in both forms of the workgroup"""
-    monkeypatch.setenv("APSU_HE_NTT_LATENCY_LIMBS", form)
+    """>= 256 MiB of distinct limbs through one launch (every workgroup index, every limb position), in both forms of the workgroup and
+    with the default selection (None: a large forward launch over the data primes takes the 8-coefficient form built for 8 waves per SIMD)"""
+    if form is not None:
+        monkeypatch.setenv("APSU_HE_NTT_LATENCY_LIMBS", form)
     C = ref.RefContext(8192, [56, 56, 56, 50], 0, 22)
     G = apsu_amd.HeContext(n=8192, coeff_modulus=C.q, plain_modulus=C.t)
     rng = np.random.default_rng(15)
