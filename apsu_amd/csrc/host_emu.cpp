@@ -25,7 +25,7 @@ template <int LOGN, int MODE, int PASS, int C = 16> static void emu_pass_tensor(
             for (int tid = 0; tid < T; tid++)
                 for (int e = 2 * tid; e < (1 << LOGN); e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(ops, glob, e, tab);
         for (int tid = 0; tid < T; tid++) {
-            if constexpr (PASS == 0) ntt_pass<LOGN, true, MODE, 0, false, false, SrcPlain, true, TwInline, NoHook, C>(lds, glob, tid, T, tab);
+            if constexpr (PASS == 0) ntt_pass<LOGN, true, MODE, 0, false, false, SrcTensor, true, TwInline, NoHook, C>(lds, glob, tid, T, tab, ops);   // (the source's input bound rides along, as in ntt_body)
             else ntt_pass<LOGN, true, MODE, PASS, 0, false, SrcPlain, false, TwInline, NoHook, C>(lds, glob, tid, T, tab);
         }
         emu_pass_tensor<LOGN, MODE, PASS + 1, C>(lds, glob, T, tab, ops);
@@ -125,7 +125,7 @@ int emu_intt_tensor_limb_c(int logn, uint64_t q, const uint64_t *x0, const uint6
                            uint64_t *out, int threads, int coeffs)
 {
     try {
-        if (coeffs != 16 && !(coeffs == 8 && plan_has_latency_form(logn))) throw std::invalid_argument("no pass schedule for this ring size and coefficients per work item");
+        if ((coeffs & 0xff) != 16 && !((coeffs & 0xff) == 8 && plan_has_latency_form(logn))) throw std::invalid_argument("no pass schedule for this ring size and coefficients per work item");
         size_t n = (size_t)1 << logn;
         HeParams hp = HeParams::Create(n, { q }, 65537 < q ? 65537 : 3);
         const NttTablesHost &t = hp.ntt[0];
@@ -138,7 +138,11 @@ int emu_intt_tensor_limb_c(int logn, uint64_t q, const uint64_t *x0, const uint6
         ntt_fold_params(q, tab.fold_k, tab.fold_c);
         tab.wide_d4 = ntt_wide_d4(q, tab.narrow != 0);
         if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return -2;
-        const SrcTensor ops{ x0, y0, x1, y1, false };
+        // coeffs | 0x100: the products enter as the fold's last word (< 4q) where the engine would take them so (k_intt_tensor: ntt_lazy_input_ok)
+        const bool lazy = (coeffs & 0x100) != 0;
+        coeffs &= 0xff;
+        if (lazy && !ntt_lazy_input_ok(tab, logn)) return -3;
+        const SrcTensor ops{ x0, y0, x1, y1, lazy };
         if (coeffs == 8) {
             if (logn == 13) emu_intt_tensor<13, 8>(out, tab, threads, ops); else emu_intt_tensor<12, 8>(out, tab, threads, ops);
             return 0;

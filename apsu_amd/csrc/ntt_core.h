@@ -125,13 +125,28 @@ HD u64 ntt_reduce128(u64 hi, u64 lo, const NttTable &tab)
     return barrett128(u128p{ lo, hi }, Mod{ tab.q, tab.r0, tab.r1 });
 }
 // The same value as the INPUT of an inverse transform, which does not need a canonical residue: the fold's last word w
-// (< 2^(k+1) + 2^56 + 2^50, i.e. below 4q) enters as it is -- the closing ntt_reduce_any (a multiply and a conditional
+// (< 2^(k+1) + 2^32 c + 4 c^2: below 4q for the 56-bit primes, up to ~8q for a 50-bit prime with a large c -- ntt_lazy_bound_q) enters as it is -- the closing ntt_reduce_any (a multiply and a conditional
 // subtraction per coefficient) is left out -- when the transform's range discipline takes it: a wide modulus takes any 64-bit
 // value (csub_top), a narrow one runs without range control and needs 4q + 4 logn q < 2^64 (round 4).
+// Upper bound, in units of q, of ntt_reduce128_lazy's result: w = pl + a + t' c + (t'' << 32) < 2^(k+1) + 2^32 c + 4 c^2 (a = low word of
+// ph times c, up to 2^32 c: for a 50-bit prime with c ~ 2^20 that alone is 4q, so "below 4q" holds for k >= 56 only -- the 256M-4096
+// workload caught this in round 6).  With q > 2^(k-1): w / q < 4 + ((c 2^32 + 4 c^2) >> (k - 1)) + 1.  Shifts only: evaluated per workgroup.
+HD u64 ntt_lazy_bound_q(const NttTable &tab)
+{
+    const u64 c = tab.fold_c;
+    return 5 + ((((c << 32) + 4 * c * c)) >> (tab.fold_k - 1));
+}
+// (round 6: a narrow modulus' first inverse pass runs its psi^0 butterflies without a product, which doubles the bound per stage there:
+//  2^K b0 q after the K stages of that pass + 4q for each of the others; K = the larger of the two forms' first inverse passes)
+constexpr int plan_passes(int logn, int c);
+constexpr int plan_k(int logn, int p, int c);
 HD bool ntt_lazy_input_ok(const NttTable &tab, int logn)
 {
     if (!ntt_fold128_ok(tab.fold_k, tab.fold_c)) return false;
-    return !tab.narrow || tab.q <= ~(u64)0 / (u64)(4 * logn + 4);
+    if (!tab.narrow) return true;
+    const int k16 = plan_k(logn, plan_passes(logn, 16) - 1, 16);
+    const u64 mult = (ntt_lazy_bound_q(tab) << k16) + (u64)(4 * (logn - k16));
+    return (unsigned __int128)tab.q * mult < ((unsigned __int128)1 << 64);
 }
 HD u64 ntt_reduce128_lazy(u64 hi, u64 lo, const NttTable &tab)
 {
@@ -184,6 +199,11 @@ HD u64 src_load1(const SrcTensor &s, const u64 *, int e, const NttTable &tab)
     if (s.x1) mac128(p, s.x1[e], s.y1[e]);
     return s.lazy ? ntt_reduce128_lazy(p.hi, p.lo, tab) : ntt_reduce128(p.hi, p.lo, tab);
 }
+// Upper bound, in units of q, of what a source hands to the inverse transform's first pass: canonical residues (1) or the tensor fold's
+// last word (ntt_lazy_bound_q) -- the constant the multiplication-free butterflies of that pass add (ntt_pass16, round 6).
+HD u64 src_in_bound(const SrcPlain &, const NttTable &) { return 1; }
+HD u64 src_in_bound(const SrcStaged &, const NttTable &) { return 1; }
+HD u64 src_in_bound(const SrcTensor &s, const NttTable &tab) { return s.lazy ? ntt_lazy_bound_q(tab) : 1; }
 // LDS padding: 16 bytes per 16 coefficients.  Keeps coefficient pairs 16-B aligned (ds_*_b128) and
 // makes the 128-B-per-lane stride of the contiguous pass conflict free (lane stride 144 B = 36 banks).
 HD int lds_slot(int e) { return e + ((e >> 4) << 1); }
@@ -386,6 +406,7 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
     const TwPair *__restrict__ W = tab.fwd;
     const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2, n4 = (u64)0 - q4;
     const u32 d4 = tab.wide_d4;                // wave-uniform
+    const u64 qb0 = (INV && MODE == NTT_NARROW && LOWBITS == 0) ? q * src_in_bound(src, tab) : 0;   // wave-uniform: b0 q of the product-free butterflies below
 
     int block, c0;
     if (COLS) { block = w / CG; c0 = (w % CG) * G; }
@@ -460,6 +481,19 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         if constexpr (PRE) tv = tw.t[PS::inv_slot(bit, j, gg)];
                         else tv = ldg16(reinterpret_cast<const u64 *>(tab.dit + gap + jj));
                         u64 &x = r[gg][j], &y = r[gg][j | bit];
+                        // Round 6: the pass executed first (LOWBITS == 0: 2^K contiguous coefficients per group) meets the twiddle psi^0 = 1
+                        // wherever the row's low bits are zero -- all of stage 1, half of stage 2, a quarter of stage 3 ... (15 of the 32
+                        // butterflies of a radix-16 pass): (x, y) -> (x + y, x - y + M) needs no product.  M is the multiple of q that bounds
+                        // y there: both operands are sums of `bit` inputs, each below b0 q (b0 = 1 for canonical input,
+                        // ntt_lazy_bound_q for the tensor fold's last word).  Narrow moduli only (no range control to keep: the values stay below (2^K b0 + 4 (log n - K)) q,
+                        // inside the narrow criterion for b0 = 1 and checked by ntt_lazy_input_ok for b0 = 4); -3 ... -7 % on inverse
+                        // launches over the data primes (tools/microbench/ntt_forms.hip, profiles/r06_ntt_trivial_twiddles.txt).
+                        if (MODE == NTT_NARROW && LOWBITS == 0 && (j & (bit - 1)) == 0) {
+                            const u64 M = qb0 * (u64)bit, sum = x + y;                    // (bit is a power of two and a constant here: a shift)
+                            y = x + M - y;
+                            x = sum;
+                            continue;
+                        }
                         if (MODE == NTT_WIDE) x = csub_top(x, n4);
                     if (MODE == NTT_WIDE_NEAR) x = csub_top_near(x, d4);
                         bfly_lazy4<(!COLS && !PRE), (APSU_NTT_MAD_CHAIN_MODE == 3 ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 4 || APSU_NTT_MAD_CHAIN_MODE == 5) ? 2 : (APSU_NTT_MAD_CHAIN_MODE == 6 && !COLS && !PRE) ? 1 : (APSU_NTT_MAD_CHAIN_MODE == 7 || APSU_NTT_MAD_CHAIN_MODE == 8) ? 3 : 0)>(x, y, tv[0], tv[1], nq, q4);   // !COLS: the twiddle index is a compile-time constant

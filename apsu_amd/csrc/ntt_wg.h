@@ -106,7 +106,7 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
                 for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
             }
             ntt_sync<WL>();
-            ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, true, TwInline, decltype(h1)>(lds, p, tid, T, tab, SrcPlain(), TwInline(), h1);
+            ntt_pass<LOGN, INV, MODE, 0, 0, false, SRC, true, TwInline, decltype(h1)>(lds, p, tid, T, tab, operands, TwInline(), h1);
         } else ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, false, TwInline, decltype(h1)>(lds, p, tid, T, tab, SrcPlain(), TwInline(), h1);
         ntt_sync<W1>();
         ntt_pass<LOGN, INV, MODE, 1, 0, RAW, SrcPlain, false, decltype(t1), decltype(h2)>(lds, p, tid, T, tab, SrcPlain(), t1, h2);
@@ -129,7 +129,9 @@ __device__ __forceinline__ void ntt_body(u64 *lds, u64 *__restrict__ p, const Nt
             for (int e = 2 * tid; e < N; e += 2 * T) *reinterpret_cast<u64x2 *>(lds + lds_slot(e)) = src_load2(operands, p, e, tab);
         }
         ntt_sync<WL>();
-        ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, true, TwInline, NoHook, C>(lds, p, tid, T, tab);
+        // (the source rides along although the pass reads the LDS image: its input bound sets the constant of the first pass's
+        //  multiplication-free butterflies, ntt_core.h src_in_bound)
+        ntt_pass<LOGN, INV, MODE, 0, 0, false, SRC, true, TwInline, NoHook, C>(lds, p, tid, T, tab, operands);
     } else ntt_pass<LOGN, INV, MODE, 0, 0, false, SrcPlain, false, TwInline, NoHook, C>(lds, p, tid, T, tab);
     // (RAW only concerns the pass that leaves the inverse transform, the last one)
     if constexpr (P > 1) {

@@ -577,6 +577,76 @@ def test_intt_tensor_loader_emulation(emu, n, bits):
         assert (out == prod).all()
 
 
+def _shipped_primes(n):
+    """every coefficient prime of the shipped parameter files with this ring size"""
+    out = set()
+    for name in ALL_PARAM_FILES:
+        js = json.load(open(os.path.join(common.PARAM_DIR, name + ".json")))
+        sp = js["seal_params"]
+        if sp["poly_modulus_degree"] != n:
+            continue
+        c = ref.RefContext(n, sp["coeff_modulus_bits"], sp.get("plain_modulus", 0), sp.get("plain_modulus_bits", 0))
+        out.update(int(q) for q in c.q)
+    return sorted(out)
+
+
+@pytest.mark.parametrize("n,bits", [(4096, 48), (4096, 36), (8192, 50), (8192, 56), (8192, 57), (8192, 58), (8192, 60), (16384, 56), (4096, 0), (8192, 0)])
+def test_intt_tensor_lazy_input_and_product_free_butterflies(emu, n, bits):
+    """round 6: the inverse transform's first pass runs its psi^0 butterflies without a product (narrow moduli); with the tensor fold's last
+    word as input the constant they add is ntt_lazy_bound_q(q) times larger -- NOT 4: for a 50-bit prime 2^50 - c with c ~ 2^20 the fold's
+    last word reaches ~6q (the full 256M-4096 workload caught a first version that assumed 4q; 0x3ffffffef4001 is that prime) -- and the
+    bound check of ntt_lazy_input_ok decides whether the modulus takes lazy input at all.  Lazy and canonical input give the same
+    canonical output, in both forms of the workgroup; bits = 0: every coefficient prime of the shipped parameter files of that ring size"""
+    logn = n.bit_length() - 1
+    emu.emu_intt_tensor_limb_c.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, u64p, u64p, C.c_int, C.c_int]
+    if bits:
+        primes = [ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20).q[0]]
+    else:
+        primes = _shipped_primes(n)
+        assert len(primes) >= 4
+        if n == 8192:
+            assert 0x3ffffffef4001 in primes
+    lazy_runs = 0
+    for q in primes:
+        q = int(q)
+        rng = np.random.default_rng(q % 1000003)
+        x0, y0, x1, y1 = (rng.integers(0, q, n, dtype=np.uint64) for _ in range(4))
+        for a in (x0, y0, x1, y1):
+            a[:32] = q - 1                                        # a whole first-pass group of extreme inputs
+        forms = [16] + ([8] if n in (4096, 8192) else [])
+        ref_out = None
+        refused = 0
+        usable = True
+        for co in forms:
+            for lazy in (0, 0x100):
+                out = np.zeros(n, dtype=np.uint64)
+                rc = emu.emu_intt_tensor_limb_c(logn, q, x0.ctypes.data_as(u64p), y0.ctypes.data_as(u64p), x1.ctypes.data_as(u64p), y1.ctypes.data_as(u64p),
+                                                out.ctypes.data_as(u64p), n // co, co | lazy)
+                if rc == -2:
+                    usable = False                                # no fold reduction for this modulus: the engine keeps the separate tensor kernel
+                    break
+                if rc == -3:
+                    assert lazy
+                    refused += 1
+                    continue
+                assert rc == 0, emu.emu_last_error()
+                assert int(out.max()) < q
+                lazy_runs += 1 if lazy else 0
+                if ref_out is None:
+                    ref_out = out
+                assert (out == ref_out).all(), (hex(q), co, lazy)
+            if not usable:
+                break
+        if not usable:
+            continue
+        prod = np.array([(int(a) * int(b) + int(u) * int(v)) % q for a, b, u, v in zip(x0, y0, x1, y1)], dtype=np.uint64)
+        assert emu.emu_ntt_limb(logn, 1, C.c_uint64(q), prod.ctypes.data_as(u64p), n // 16) == 0
+        assert (ref_out == prod).all(), hex(q)
+        if bits == 58 and n == 8192:
+            assert refused > 0                                    # a 58-bit narrow prime has no room for lazy input under the doubled bounds
+    assert lazy_runs > 0 or bits in (36, 58)
+
+
 def test_ntt_final_reduction_fold_and_barrett(emu):
     """ntt_reduce_any: x mod q for ANY 64-bit x.  Primes of the shape 2^k - c (all of SEAL's coefficient and BEHZ primes
     of 33 bits and more) take the one-multiply fold, the others Barrett; both against Python integers, extremes included"""

@@ -162,6 +162,20 @@ int main(int argc, char **argv)
         printf("  %-66s %s\n", what, ok ? "same bits" : "MISMATCH");
         if (!ok) exit(2);
     };
+    // RAW outputs are lazy representatives (the consumer's constants absorb twist and reduction): two forms whose first inverse pass covers
+    // different stages may leave different representatives of the same residues -- compare modulo the limb's modulus
+    auto same_mod = [&](const char *what, const std::vector<int> &map, size_t w = 0) {
+        if (!w) w = words;
+        CHECK(hipMemcpy(ra.data(), d_a, w * 8, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(rb.data(), d_b, w * 8, hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (size_t i = 0; i < w && ok; i++) {
+            const u64 q = tabs[map[(i / N) % map.size()]].q;
+            ok = ra[i] % q == rb[i] % q;
+        }
+        printf("  %-66s %s\n", what, ok ? "same residues" : "MISMATCH");
+        if (!ok) exit(2);
+    };
     auto copy_in = [&](u64 *dst) { CHECK(hipMemcpy(dst, d_in, words * 8, hipMemcpyDeviceToDevice)); };
     const int limbs = E;
     const size_t prods = big / (3 * limbs) / 2 * 2, tgrid = prods * 3 * limbs;
@@ -182,9 +196,9 @@ int main(int argc, char **argv)
         if (std::memcmp(ra.data(), host.data(), words * 8)) { printf("inverse(forward(x)) != x\n"); return 2; }
         copy_in(d_a); copy_in(d_b);
         LAUNCH_PLAIN(true, true, 16, 4, d_a, big, map, period); LAUNCH_PLAIN(true, true, 8, 4, d_b, big, map, period);
-        snprintf(msg, sizeof msg, "inverse RAW, %s: F8", base); same(msg);
+        snprintf(msg, sizeof msg, "inverse RAW, %s: F8", base); same_mod(msg, which ? map_ext : map_q);
         copy_in(d_b); LAUNCH_PLAIN(true, true, 8, 8, d_b, big, map, period);
-        snprintf(msg, sizeof msg, "inverse RAW, %s: F8o", base); same(msg);
+        snprintf(msg, sizeof msg, "inverse RAW, %s: F8o", base); same_mod(msg, which ? map_ext : map_q);
         copy_in(d_a); copy_in(d_b);
         LAUNCH_PLAIN(true, false, 16, 4, d_a, big, map, period); LAUNCH_PLAIN(true, false, 8, 8, d_b, big, map, period);
         snprintf(msg, sizeof msg, "inverse (with twist), %s: F8o", base); same(msg);
@@ -197,9 +211,9 @@ int main(int argc, char **argv)
     {
         hipLaunchKernelGGL((k_tensor<16, 4>), dim3(tgrid), dim3(N / 16), 0, 0, d_in, d_in + (big / 3) * N, d_a, limbs, d_tabs, d_map_ext, E);
         hipLaunchKernelGGL((k_tensor<8, 4>), dim3(tgrid), dim3(N / 8), 0, 0, d_in, d_in + (big / 3) * N, d_b, limbs, d_tabs, d_map_ext, E);
-        same("tensor-on-load inverse: F8", tgrid * N);
+        same_mod("tensor-on-load inverse: F8", map_ext, tgrid * N);
         hipLaunchKernelGGL((k_tensor<8, 8>), dim3(tgrid), dim3(N / 8), 0, 0, d_in, d_in + (big / 3) * N, d_b, limbs, d_tabs, d_map_ext, E);
-        same("tensor-on-load inverse: F8o", tgrid * N);
+        same_mod("tensor-on-load inverse: F8o", map_ext, tgrid * N);
     }
     // ---- timing
     Timer tm;
