@@ -406,7 +406,10 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
     const TwPair *__restrict__ W = tab.fwd;
     const u64 q = tab.q, nq = (u64)0 - q, q4 = q << 2, n4 = (u64)0 - q4;
     const u32 d4 = tab.wide_d4;                // wave-uniform
-    const u64 qb0 = (INV && MODE == NTT_NARROW && LOWBITS == 0) ? q * src_in_bound(src, tab) : 0;   // wave-uniform: b0 q of the product-free butterflies below
+    // wave-uniform: b0 q of the product-free butterflies below (narrow moduli: every psi^0 butterfly of the first inverse pass; wide moduli:
+    // only stage 1, and only behind the tensor loader, whose output range is known)
+    constexpr bool TRIV_WIDE1 = INV && MODE != NTT_NARROW && LOWBITS == 0 && std::is_same<SRC, SrcTensor>::value;
+    const u64 qb0 = ((INV && MODE == NTT_NARROW && LOWBITS == 0) || TRIV_WIDE1) ? q * src_in_bound(src, tab) : 0;
 
     int block, c0;
     if (COLS) { block = w / CG; c0 = (w % CG) * G; }
@@ -488,7 +491,10 @@ HD void ntt_pass16(u64 *lds, u64 *__restrict__ glob, int w, const NttTable &tab,
                         // ntt_lazy_bound_q for the tensor fold's last word).  Narrow moduli only (no range control to keep: the values stay below (2^K b0 + 4 (log n - K)) q,
                         // inside the narrow criterion for b0 = 1 and checked by ntt_lazy_input_ok for b0 = 4); -3 ... -7 % on inverse
                         // launches over the data primes (tools/microbench/ntt_forms.hip, profiles/r06_ntt_trivial_twiddles.txt).
-                        if (MODE == NTT_NARROW && LOWBITS == 0 && (j & (bit - 1)) == 0) {
+                        // Wide moduli (61-bit BEHZ primes, values anywhere in 64 bits): only stage 1 behind the tensor loader -- both operands are
+                        // its outputs, below b0 q <= 5q < 2^63.4 (canonical: q), so x + y < 2^63.1 and x - y + b0 q < 2^64 fit, and stage 2 is a
+                        // regular butterfly again, whose csub_top takes any 64-bit value.
+                        if (((MODE == NTT_NARROW && LOWBITS == 0) || (TRIV_WIDE1 && bit == 1)) && (j & (bit - 1)) == 0) {
                             const u64 M = qb0 * (u64)bit, sum = x + y;                    // (bit is a power of two and a constant here: a shift)
                             y = x + M - y;
                             x = sum;

@@ -590,7 +590,7 @@ def _shipped_primes(n):
     return sorted(out)
 
 
-@pytest.mark.parametrize("n,bits", [(4096, 48), (4096, 36), (8192, 50), (8192, 56), (8192, 57), (8192, 58), (8192, 60), (16384, 56), (4096, 0), (8192, 0)])
+@pytest.mark.parametrize("n,bits", [(4096, 48), (4096, 36), (8192, 50), (8192, 56), (8192, 57), (8192, 58), (8192, 60), (16384, 56), (4096, 0), (8192, 0), (4096, 61), (8192, 61)])
 def test_intt_tensor_lazy_input_and_product_free_butterflies(emu, n, bits):
     """round 6: the inverse transform's first pass runs its psi^0 butterflies without a product (narrow moduli); with the tensor fold's last
     word as input the constant they add is ntt_lazy_bound_q(q) times larger -- NOT 4: for a 50-bit prime 2^50 - c with c ~ 2^20 the fold's
@@ -599,7 +599,17 @@ def test_intt_tensor_lazy_input_and_product_free_butterflies(emu, n, bits):
     canonical output, in both forms of the workgroup; bits = 0: every coefficient prime of the shipped parameter files of that ring size"""
     logn = n.bit_length() - 1
     emu.emu_intt_tensor_limb_c.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, u64p, u64p, C.c_int, C.c_int]
-    if bits:
+    if bits == 61:                                                # the BEHZ base's range mode (wide-near): stage 1 only, behind the tensor loader
+        def is_prime(x):
+            return all(pow(w, x - 1, x) == 1 for w in (2, 3, 5, 7, 11, 13))
+        q, found, primes = ((1 << 61) - 1) // (2 * n) * (2 * n) + 1, 0, []
+        while len(primes) < 2:                                    # (the first hits of the scan are the context's own auxiliary primes)
+            if is_prime(q):
+                found += 1
+                if found >= 8:
+                    primes.append(q)
+            q -= 2 * n
+    elif bits:
         primes = [ref.RefContext(n, [bits], 65537 if (65537 - 1) % (2 * n) == 0 else 0, 0 if (65537 - 1) % (2 * n) == 0 else 20).q[0]]
     else:
         primes = _shipped_primes(n)
