@@ -278,7 +278,7 @@ void launch_ntt(int logn, bool inverse, u64 *data, size_t count, const NttTable 
                 hipStream_t st, size_t latency_limbs, bool narrow_only)
 {
     if (!count) return;
-    if (latency_limbs == NTT_FORM_AUTO && logn == 13 && !inverse && narrow_only && count >= 512) {
+    if (latency_limbs == NTT_FORM_AUTO && logn == 13 && !inverse && narrow_only && count > 256) {
         // large forward launches whose moduli are all narrow (the data primes): 8 coefficients per lane at 8 waves per SIMD
         hipLaunchKernelGGL((k_ntt<13, false, 1024, 8, 8>), dim3((unsigned)count), dim3(1024), 0, st, data, tabs, modmap, period, 0);
         KERNEL_CHECK();
